@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the point-to-plane extrinsic LM path on MI355X.
+
+Contract:  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (BASELINE.json configs[1], "C2"): a single T_cl problem with 10^6 synthetic
+point-to-plane observations (2000 board poses x 500 scan points, range noise sigma = 0.01 m,
+seeded restatement of simulation_lasercamcal_node's generator), initial guess Tcl = I,
+Cauchy loss, Ceres-default LM options — exactly what CamLaserCalibration() runs.
+A "step" is one complete solve (clc_solve) with the observation array already resident in HBM.
+With N GPUs every rank solves its own independent 10^6-observation problem (problems shard
+across GPUs, no data-path collective) and the result records are gathered once with RCCL
+(torch.distributed all_gather) inside the timed region: weak scaling.
+
+value = residual+Jacobian evaluations per second, whole job:
+        sum over ranks of (observations x evaluation passes) / max-over-ranks wall time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured achievable
+BYTES_PER_EVAL = 64     # one clc_observation record read once per evaluation
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--poses", type=int, default=2000)
+    ap.add_argument("--pts", type=int, default=500)
+    ap.add_argument("--noise", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket the evaluation kernel with HIP events inside the timed region")
+    ap.add_argument("--large-obs", type=int, default=8_000_000,
+                    help="extra >Infinity-Cache evaluation-kernel measurement (0 disables)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import camlasercalibratool_amd as clc
+    from camlasercalibratool_amd import simdata as sd
+
+    # ---- synthetic input (one independent problem per rank), resident in HBM before timing ----
+    S = sd.sim_fixed_count(1000 + rank, args.poses, args.pts, noise_sigma=args.noise)
+    rec = clc.flatten_observations(S, use_linefitting_data=False)  # calibr_simulation.cpp:130 flags
+    n_obs = rec.shape[0]
+    x0 = sd.pose7_from_T(np.eye(4))
+    solver = clc.Solver(local_rank)
+    dev_name, n_cus = solver.device_info()
+    solver.upload(rec)
+
+    opt = clc.default_options()
+    opt.profile_events = 0 if args.no_kernel_events else 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = solver.solve(x0, opt)
+    result_rec = torch.zeros(12, dtype=torch.float64, device=f"cuda:{local_rank}")
+    gathered = torch.zeros(12 * world, dtype=torch.float64, device=f"cuda:{local_rank}") if dist is not None else None
+    if dist is not None:
+        dist.all_gather_into_tensor(gathered, result_rec)  # warm up the RCCL communicator
+
+    barrier()
+    t0 = time.perf_counter()
+    evals = 0
+    iters = 0
+    k_ms = 0.0
+    k_launches = 0
+    for _ in range(args.steps):
+        res = solver.solve(x0, opt)
+        evals += res.summary.num_evaluations * n_obs
+        iters += res.summary.num_iterations
+        k_ms += res.summary.eval_kernel_ms
+        k_launches += res.summary.eval_kernel_launches
+    if dist is not None:  # final gather of the per-problem result records over xGMI
+        s = res.summary
+        result_rec.copy_(torch.tensor(list(res.pose) + [s.final_cost, s.initial_cost, float(s.num_iterations),
+                                                        float(s.termination), float(rank)], dtype=torch.float64))
+        dist.all_gather_into_tensor(gathered, result_rec)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # max time over ranks, summed work
+    if dist is not None:
+        t = torch.tensor([elapsed, float(evals), float(iters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed_max = float(tmax[0])
+        evals_total, iters_total = float(t[1]), float(t[2])
+    else:
+        elapsed_max, evals_total, iters_total = elapsed, float(evals), float(iters)
+
+    out = None
+    if rank == 0:
+        value = evals_total / elapsed_max
+        out = {
+            "metric": "residual+Jacobian evals/s (LM solve, 1e6-obs synthetic point-to-plane problem per GPU)",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: single T_cl, {n_obs} point-to-plane observations ({args.poses} poses x {args.pts} pts, "
+                            f"sigma={args.noise} m), init Tcl=I, Cauchy loss, Ceres-default LM; one independent problem per GPU",
+                "step": "one complete clc_solve (observations resident in HBM)",
+                "observations": n_obs,
+                "parallelism": f"problem-sharded x{world}, RCCL all_gather of result records" if world > 1 else "single GPU",
+                "device": dev_name,
+                "compute_units": n_cus,
+            },
+            "lm_iters_per_s": iters_total / elapsed_max,
+            "lm_iterations_per_solve": res.summary.num_iterations,
+            "evaluation_passes_per_solve": res.summary.num_evaluations,
+            "final_cost": res.summary.final_cost,
+            "termination": clc.TERMINATION.get(res.summary.termination),
+        }
+
+        # ---- roofline of the dominant kernel (eval_kernel<loss,jac>) ----
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "kernel": "clc::eval_kernel<true,true>", "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs}
+        if k_launches > 0:
+            avg_ms = k_ms / k_launches
+            roof["achieved"] = BYTES_PER_EVAL * n_obs / (avg_ms * 1e-3) / 1e9
+            roof["avg_kernel_ms"] = avg_ms
+            roof["launches_timed"] = int(k_launches)
+            roof["timing"] = "hipEvent pairs around every launch inside the timed region, on the solver's stream"
+        b2b = solver.time_eval(x0, reps=200)
+        roof["back_to_back_ms"] = b2b
+        if k_launches == 0:
+            roof["achieved"] = BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9
+            roof["avg_kernel_ms"] = b2b
+            roof["timing"] = "200 back-to-back launches between two hipEvents (post timed region)"
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["note"] = (f"{BYTES_PER_EVAL * n_obs / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state "
+                        "passes may be served on-die; see roofline_large for a >L3 working set")
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = tj.get("source")
+            except Exception:
+                pass
+        out["roofline"] = roof
+
+    # ---- >L3 working set: evaluation kernel only (rank 0, N=1) ----
+    if rank == 0 and world == 1 and args.large_obs > 0:
+        reps = (args.large_obs + n_obs - 1) // n_obs
+        big = np.ascontiguousarray(np.tile(rec, (reps, 1))[: args.large_obs])
+        solver.upload(big)
+        ms = solver.time_eval(x0, reps=20)
+        gbs = BYTES_PER_EVAL * big.shape[0] / (ms * 1e-3) / 1e9
+        out["roofline_large"] = {"observations": int(big.shape[0]), "bytes": int(BYTES_PER_EVAL * big.shape[0]),
+                                 "avg_kernel_ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs / HBM_PEAK_GBS, "evals_per_s": big.shape[0] / (ms * 1e-3)}
+        del big
+        solver.upload(rec)
+
+    # ---- CPU baseline + parity (rank 0, N=1): the oracle's DENSE_QR Ceres restatement, 1 thread ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+
+        ref = None
+        cpu_t = 0.0
+        cpu_evals = 0
+        cpu_iters = 0
+        n_rep = 0
+        while cpu_t < args.cpu_seconds and n_rep < 64:
+            t1 = time.perf_counter()
+            ref = oracle.solve(rec, x0, linear_solver="qr", threads=1)
+            cpu_t += time.perf_counter() - t1
+            cpu_evals += ref.summary.num_residual_evaluations * n_obs
+            cpu_iters += ref.summary.num_iterations
+            n_rep += 1
+        out["cpu_baseline"] = {
+            "value": cpu_evals / cpu_t, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{n_rep} full solves of the same 1e6-obs problem by oracle/clc_oracle.cpp (Ceres-LM restatement, dense "
+                      f"N x 6 Jacobian + Householder QR, -O3, 1 thread; the reference runs Ceres with num_threads=1), "
+                      f"{cpu_t:.1f} s of CPU time; counts cost-only and Jacobian passes alike",
+            "lm_iters_per_s": cpu_iters / cpu_t,
+            "ms_per_solve": 1e3 * cpu_t / n_rep,
+            "host_cpus": os.cpu_count(),
+        }
+        dT = float(np.abs(sd.T_from_pose7(res.pose) - sd.T_from_pose7(ref.pose)).max())
+        out["parity"] = {
+            "T_cl_max_abs_err_vs_oracle": dT,
+            "final_cost_abs_err_vs_oracle": abs(res.summary.final_cost - ref.summary.final_cost),
+            "iterations_gpu": res.summary.num_iterations, "iterations_oracle": ref.summary.num_iterations,
+            "gates": {"T_cl": 1e-6, "final_cost": 1e-8},
+            "oracle": "CPU restatement of the reference + Ceres LM (parity unpinned: no Ceres available)",
+        }
+
+    if rank == 0:
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,15 @@
+"""camlasercalibratool_amd — MI355X-native (gfx950) solver for CamLaserCalibraTool's
+point-to-plane camera/2-D-lidar extrinsic least-squares path.
+
+The package is a thin host layer over a C-ABI shared library of hand-written HIP kernels
+(csrc/, include/clc.h).  It mirrors the reference's call surface
+(CamLaserCalibration / CamLaserCalClosedSolution / Oberserve) and has no CPU fallback."""
+from .simdata import GenerateSimData, Oberserve, ObservationSet  # noqa: F401
+from ._capi import ClcError, Options, Summary, Iteration, TERMINATION, default_options  # noqa: F401
+from .solver import Solver, SolveResult, flatten_observations  # noqa: F401
+from .calib import CamLaserCalibration, CamLaserCalClosedSolution, CalibrationReport  # noqa: F401
+
+__all__ = [
+    "CamLaserCalibration", "CamLaserCalClosedSolution", "Oberserve", "ObservationSet", "GenerateSimData",
+    "Solver", "SolveResult", "Options", "default_options", "flatten_observations", "ClcError",
+]

@@ -1,0 +1,39 @@
+"""Build of the HIP extension (in-tree, gfx950 only): csrc/clc_abi.hip -> csrc/libclc_hip.so."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libclc_hip.so")
+SOURCES = ["clc_abi.hip", "clc_kernels.hpp", "clc_lm.hpp", "clc_math.hpp", "clc_host.hpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (no CPU fallback exists)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "clc.h")]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> str:
+    """Compile the extension with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "clc_abi.hip"), "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH

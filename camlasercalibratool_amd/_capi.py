@@ -1,0 +1,140 @@
+"""ctypes binding of the C-ABI (include/clc.h) exported by csrc/libclc_hip.so.
+
+There is no CPU fallback: if the HIP extension is missing this module raises on first use,
+and every entry point that needs the device raises when no gfx950 GPU is present."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+CLC_OK = 0
+ERRORS = {
+    -1: "CLC_ERR_INVALID_ARG", -2: "CLC_ERR_HIP", -3: "CLC_ERR_NONFINITE", -4: "CLC_ERR_EMPTY_SCAN",
+    -5: "CLC_ERR_NO_DATA", -6: "CLC_ERR_LINALG", -7: "CLC_ERR_NO_DEVICE",
+}
+TERMINATION = {
+    0: "RUNNING", 1: "CONVERGENCE(gradient)", 2: "CONVERGENCE(parameter)", 3: "CONVERGENCE(function)",
+    4: "CONVERGENCE(radius)", 5: "NO_CONVERGENCE", 6: "FAILURE",
+}
+
+# every symbol include/clc.h declares (checked by tests/test_abi_symbols.py)
+EXPORTED = [
+    "clc_version", "clc_last_error", "clc_options_default", "clc_create", "clc_destroy", "clc_set_stream",
+    "clc_set_launch", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
+    "clc_factor_evaluate", "clc_pose_plus", "clc_pose_plus_jacobian", "clc_eval", "clc_solve",
+    "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
+]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("use_loss", C.c_int32),
+        ("loss_scale_factor", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("sync_interval", C.c_int32),
+        ("profile_events", C.c_int32),
+    ]
+
+
+class Iteration(C.Structure):
+    _fields_ = [
+        ("iteration", C.c_int32),
+        ("step_is_valid", C.c_int32),
+        ("step_is_successful", C.c_int32),
+        ("pad_", C.c_int32),
+        ("cost", C.c_double),
+        ("cost_change", C.c_double),
+        ("gradient_max_norm", C.c_double),
+        ("step_norm", C.c_double),
+        ("relative_decrease", C.c_double),
+        ("trust_region_radius", C.c_double),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int32),
+        ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32),
+        ("num_evaluations", C.c_int64),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("solve_ms", C.c_double),
+        ("eval_kernel_ms", C.c_double),
+        ("eval_kernel_launches", C.c_int64),
+    ]
+
+
+class ClcError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str):
+        super().__init__(f"{where}: {ERRORS.get(code, code)} — {detail}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load csrc/libclc_hip.so (raises if the HIP extension has not been built)."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"HIP extension {path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(needs hipcc).  camlasercalibratool_amd has no CPU fallback.")
+        L = C.CDLL(path)
+        L.clc_last_error.restype = C.c_char_p
+        L.clc_num_observations.restype = C.c_size_t
+        L.clc_num_problems.restype = C.c_size_t
+        L.clc_num_observations.argtypes = [C.c_void_p]
+        L.clc_num_problems.argtypes = [C.c_void_p]
+        L.clc_destroy.argtypes = [C.c_void_p]
+        L.clc_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def check(rc: int, where: str) -> None:
+    if rc != CLC_OK:
+        raise ClcError(rc, where, lib().clc_last_error().decode("utf-8", "replace"))
+
+
+def dptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], "need C-contiguous float64"
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def iptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.int64 and a.flags["C_CONTIGUOUS"], "need C-contiguous int64"
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def default_options() -> Options:
+    o = Options()
+    lib().clc_options_default(C.byref(o))
+    return o

@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference's call surface (include/LaseCamCalCeres.h:27-28):
+
+    CamLaserCalClosedSolution(obs, Tlc)                          src/LaseCamCalCeres.cpp:112
+    CamLaserCalibration(obs, Tcl, use_linefitting_data=True,
+                        use_boundary_constraint=False)           src/LaseCamCalCeres.cpp:213
+
+Same names, argument meaning and in/out conventions (4x4 matrices are modified in place, like
+the Eigen::Matrix4d& of the reference); the bodies flatten the observations and call the HIP
+library through the C-ABI.  Diagnostics the reference prints to stdout (summary, singular
+values of H, null space, "recover chi2") are printed too and also returned."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import simdata
+from ._capi import Options, TERMINATION, default_options
+from .simdata import Oberserve, ObservationSet
+from .solver import SolveResult, Solver, flatten_observations
+
+ObsLike = Union[ObservationSet, Sequence[Oberserve]]
+
+
+def _as_set(obs: ObsLike) -> ObservationSet:
+    return obs if isinstance(obs, ObservationSet) else ObservationSet.from_list(list(obs))
+
+
+@dataclass
+class CalibrationReport:
+    result: SolveResult
+    H: np.ndarray
+    b: np.ndarray
+    chi2: float
+    singular_values: np.ndarray
+    null_space: np.ndarray  # [6, n_null]
+
+
+def CamLaserCalClosedSolution(obs: ObsLike, Tlc: np.ndarray, solver: Optional[Solver] = None, verbose: bool = True):
+    """Closed-form initialiser; overwrites Tlc (camera->laser) like LaseCamCalCeres.cpp:198-200."""
+    S = _as_set(obs)
+    rec = flatten_observations(S, use_linefitting_data=True, use_boundary_constraint=False)  # points_on_line only, :143
+    own = solver is None
+    sv = solver or Solver()
+    try:
+        sv.upload(rec)
+        T, unobservable, sv9 = sv.closed_form()
+    finally:
+        if own:
+            sv.close()
+    if unobservable and verbose:  # :173-178
+        print("\n~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~")
+        print(" Notice Notice Notice: system unobservable !!!!!!!")
+        print("~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~\n")
+    Tlc[...] = T
+    if verbose:
+        print("------- Closed-form solution Tlc: -------\n", Tlc)  # :202
+    return unobservable, sv9
+
+
+def CamLaserCalibration(obs: ObsLike, Tcl: np.ndarray, use_linefitting_data: bool = True,
+                        use_boundary_constraint: bool = False, options: Optional[Options] = None,
+                        solver: Optional[Solver] = None, verbose: bool = True) -> CalibrationReport:
+    """Nonlinear refinement; Tcl (laser->camera) is in/out like LaseCamCalCeres.cpp:215,:311-314."""
+    S = _as_set(obs)
+    rec = flatten_observations(S, use_linefitting_data, use_boundary_constraint)
+    pose0 = simdata.pose7_from_T(np.asarray(Tcl, dtype=np.float64))  # :215-219
+    own = solver is None
+    sv = solver or Solver()
+    try:
+        sv.upload(rec)
+        res = sv.solve(pose0, options)
+        if verbose:  # stands in for summary.FullReport(), :309
+            s = res.summary
+            print(f"Solver Summary: iterations {s.num_iterations} (successful {s.num_successful_steps - 1}, "
+                  f"unsuccessful {s.num_unsuccessful_steps}), initial cost {s.initial_cost:.6e}, "
+                  f"final cost {s.final_cost:.6e}, termination {TERMINATION.get(s.termination)}, "
+                  f"residuals {rec.shape[0]}, passes {s.num_evaluations}, time {s.solve_ms:.3f} ms")
+        Tcl[...] = simdata.T_from_pose7(res.pose)  # :311-314
+        # analysis pass: no loss, no boundary terms (:316-362)
+        rec_pts = rec if not (use_boundary_constraint and use_linefitting_data) else flatten_observations(
+            S, use_linefitting_data, False)
+        if rec_pts is not rec:
+            sv.upload(rec_pts)
+        H, b, chi2, svals, V, n_null = sv.information(res.pose)
+    finally:
+        if own:
+            sv.close()
+    null = V[:, 6 - n_null:] if n_null > 0 else np.zeros((6, 0))
+    if verbose:  # :365-381
+        print("----- H singular values--------:")
+        print(svals)
+        if n_null > 0:
+            print("====== null space basis, it's means the unobservable direction for Tcl ======")
+            print("       please note the unobservable direction is for Tcl, not for Tlc        ")
+            print(null)
+        print("\nrecover chi2: ", chi2 / 2.0)
+    return CalibrationReport(res, H, b, chi2, svals, null)

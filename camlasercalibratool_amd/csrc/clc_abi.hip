@@ -1,0 +1,687 @@
+// clc_abi.hip — implementation of the C-ABI declared in include/clc.h: HIP host code that
+// owns device memory, the stream and the launch sequence of the kernels in
+// clc_kernels.hpp.  Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC clc_abi.hip -o libclc_hip.so
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/clc.h"
+#include "clc_host.hpp"
+#include "clc_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess)
+    std::snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  else
+    std::snprintf(buf, sizeof(buf), "%s", what);
+  g_last_error = buf;
+  return code;
+}
+
+#define CLC_HIP(expr)                                                 \
+  do {                                                                \
+    hipError_t e_ = (expr);                                           \
+    if (e_ != hipSuccess) return fail(CLC_ERR_HIP, #expr, e_);        \
+  } while (0)
+
+bool all_finite(const double* p, int n) {
+  for (int i = 0; i < n; ++i)
+    if (!std::isfinite(p[i])) return false;
+  return true;
+}
+
+constexpr int kDefaultSyncInterval = 4;
+constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
+
+}  // namespace
+
+struct clc_handle {
+  int device = 0;
+  int num_cus = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // single problem
+  double* d_tiles = nullptr;
+  size_t tiles_cap_bytes = 0;
+  size_t n_obs = 0;
+  // launch geometry
+  int grid_override = 0;
+  int reduce_mode = 0;
+  double* d_partials = nullptr;
+  int partials_cap_blocks = 0;
+  // LM state
+  clc::LmState* d_state = nullptr;
+  clc_iteration* d_trace = nullptr;
+  int trace_cap = 0;
+  // scratch
+  double* d_small = nullptr;
+  double* h_small = nullptr;  // pinned
+  std::vector<hipEvent_t> ev;
+  // batched problems
+  double* d_btiles = nullptr;
+  size_t btiles_cap_bytes = 0;
+  long long* d_tile_off = nullptr;
+  long long* d_nobs = nullptr;
+  double* d_poses = nullptr;
+  clc_summary* d_summaries = nullptr;
+  unsigned int* d_queue = nullptr;  // small device counter (active problems)
+  clc::LmState* d_states = nullptr;
+  double* d_bpartials = nullptr;
+  size_t bpartials_cap_blocks = 0;
+  long long batch_max_tiles = 0;
+  size_t n_problems = 0;
+  size_t problems_cap = 0;
+};
+
+namespace {
+
+int eval_grid(const clc_handle* h, size_t n) {
+  const long long tiles = (long long)((n + clc::TILE - 1) / clc::TILE);
+  long long want = (tiles + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64);  // one tile per wave
+  long long cap = h->grid_override > 0 ? h->grid_override : 2LL * h->num_cus;
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+int ensure_partials(clc_handle* h, int blocks) {
+  if (blocks <= h->partials_cap_blocks) return CLC_OK;
+  if (h->d_partials) CLC_HIP(hipFree(h->d_partials));
+  h->d_partials = nullptr;
+  CLC_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)blocks * clc::NACC9));
+  h->partials_cap_blocks = blocks;
+  return CLC_OK;
+}
+
+int ensure_trace(clc_handle* h, int cap) {
+  if (cap <= h->trace_cap) return CLC_OK;
+  if (h->d_trace) CLC_HIP(hipFree(h->d_trace));
+  h->d_trace = nullptr;
+  CLC_HIP(hipMalloc(&h->d_trace, sizeof(clc_iteration) * (size_t)cap));
+  h->trace_cap = cap;
+  return CLC_OK;
+}
+
+int ensure_events(clc_handle* h, size_t n) {
+  while (h->ev.size() < n) {
+    hipEvent_t e;
+    CLC_HIP(hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  return CLC_OK;
+}
+
+template <bool WITH_JAC>
+void launch_eval(clc_handle* h, int grid, bool with_loss, const double* d_pose,
+                 const int32_t* d_status, double lf) {
+  if (with_loss)
+    hipLaunchKernelGGL((clc::eval_kernel<true, WITH_JAC>), dim3(grid), dim3(clc::BLOCK), 0, h->stream,
+                       h->d_tiles, (long long)h->n_obs, d_pose, d_status, lf, h->reduce_mode,
+                       h->d_partials);
+  else
+    hipLaunchKernelGGL((clc::eval_kernel<false, WITH_JAC>), dim3(grid), dim3(clc::BLOCK), 0, h->stream,
+                       h->d_tiles, (long long)h->n_obs, d_pose, d_status, lf, h->reduce_mode,
+                       h->d_partials);
+}
+
+int retile_into(clc_handle* h, const double* d_aos, size_t n, double** d_tiles, size_t* cap_bytes) {
+  const size_t n_padded = ((n + clc::TILE - 1) / clc::TILE) * clc::TILE;
+  const size_t bytes = std::max<size_t>(n_padded, clc::TILE) * 8 * sizeof(double);
+  if (bytes > *cap_bytes) {
+    if (*d_tiles) CLC_HIP(hipFree(*d_tiles));
+    *d_tiles = nullptr;
+    *cap_bytes = 0;
+    CLC_HIP(hipMalloc(d_tiles, bytes));
+    *cap_bytes = bytes;
+  }
+  if (n_padded > 0) {
+    const int threads = 256;
+    const long long blocks = ((long long)n_padded + threads - 1) / threads;
+    hipLaunchKernelGGL(clc::retile_kernel, dim3((unsigned)blocks), dim3(threads), 0, h->stream, d_aos,
+                       *d_tiles, (long long)n, (long long)n_padded);
+    CLC_HIP(hipGetLastError());
+  }
+  return CLC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int clc_version(void) { return CLC_VERSION; }
+
+const char* clc_last_error(void) { return g_last_error.c_str(); }
+
+void clc_options_default(clc_options* o) {
+  if (!o) return;
+  o->max_num_iterations = 100;  // src/LaseCamCalCeres.cpp:304
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->use_loss = 1;              // #define LOSSFUNCTION, :212
+  o->loss_scale_factor = 0.05;  // CauchyLoss(0.05 * scale), :249
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->sync_interval = 0;
+  o->profile_events = 0;
+}
+
+int clc_create(clc_handle** out, int device) {
+  if (!out) return fail(CLC_ERR_INVALID_ARG, "clc_create: out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(CLC_ERR_NO_DEVICE, "clc_create: no HIP device available (this library has no CPU fallback)", e);
+  if (device < 0 || device >= count) return fail(CLC_ERR_INVALID_ARG, "clc_create: bad device index");
+  CLC_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  CLC_HIP(hipGetDeviceProperties(&prop, device));
+  clc_handle* h = new clc_handle();
+  h->device = device;
+  h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  CLC_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  CLC_HIP(hipMalloc(&h->d_state, sizeof(clc::LmState)));
+  CLC_HIP(hipMalloc(&h->d_small, sizeof(double) * kSmallDoubles));
+  CLC_HIP(hipHostMalloc(&h->h_small, sizeof(double) * kSmallDoubles, hipHostMallocDefault));
+  CLC_HIP(hipMalloc(&h->d_queue, sizeof(unsigned int)));
+  *out = h;
+  return CLC_OK;
+}
+
+void clc_destroy(clc_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  void* ptrs[] = {h->d_tiles, h->d_partials, h->d_state, h->d_trace, h->d_small, h->d_btiles,
+                  h->d_tile_off, h->d_nobs, h->d_poses, h->d_summaries, h->d_queue, h->d_states,
+                  h->d_bpartials};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+int clc_set_stream(clc_handle* h, void* hip_stream) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_set_stream: NULL handle");
+  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return CLC_OK;
+}
+
+int clc_set_launch(clc_handle* h, int grid_blocks, int reduce_mode) {
+  if (!h || grid_blocks < 0 || reduce_mode < 0 || reduce_mode > 1)
+    return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
+  h->grid_override = grid_blocks;
+  h->reduce_mode = reduce_mode;
+  return CLC_OK;
+}
+
+int clc_device_info(clc_handle* h, char* name, int name_cap, int* num_cus) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_device_info: NULL handle");
+  hipDeviceProp_t prop;
+  CLC_HIP(hipGetDeviceProperties(&prop, h->device));
+  if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+  if (num_cus) *num_cus = h->num_cus;
+  return CLC_OK;
+}
+
+int clc_flatten_observations(int n_poses, const double* tag_q_wxyz, const double* tag_t,
+                             const int64_t* pts_off, const double* pts, const int64_t* ptl_off,
+                             const double* ptl, int use_linefitting_data,
+                             int use_boundary_constraint, clc_observation* records,
+                             int64_t* n_records) {
+  if (n_poses < 0 || !n_records || (n_poses > 0 && (!tag_q_wxyz || !tag_t || !pts_off || !ptl_off)))
+    return fail(CLC_ERR_INVALID_ARG, "clc_flatten_observations: bad argument");
+  int rc = clc::host::flatten(n_poses, tag_q_wxyz, tag_t, pts_off, pts, ptl_off, ptl,
+                              use_linefitting_data != 0, use_boundary_constraint != 0, records, n_records);
+  if (rc == CLC_ERR_EMPTY_SCAN)
+    return fail(rc, "clc_flatten_observations: boundary constraint on an empty scan (reference: std::out_of_range at LaseCamCalCeres.cpp:278)");
+  return rc;
+}
+
+int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t n) {
+  if (!h || (n > 0 && !records_dev)) return fail(CLC_ERR_INVALID_ARG, "clc_upload_device: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
+  if (rc != CLC_OK) return rc;
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  h->n_obs = n;
+  return CLC_OK;
+}
+
+int clc_upload(clc_handle* h, const clc_observation* records, size_t n) {
+  if (!h || (n > 0 && !records)) return fail(CLC_ERR_INVALID_ARG, "clc_upload: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  double* d_aos = nullptr;
+  if (n > 0) {
+    CLC_HIP(hipMalloc(&d_aos, n * sizeof(clc_observation)));
+    hipError_t e = hipMemcpy(d_aos, records, n * sizeof(clc_observation), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_aos); return fail(CLC_ERR_HIP, "clc_upload: hipMemcpy", e); }
+  }
+  int rc = clc_upload_device(h, reinterpret_cast<const clc_observation*>(d_aos), n);
+  if (d_aos) (void)hipFree(d_aos);
+  return rc;
+}
+
+size_t clc_num_observations(const clc_handle* h) { return h ? h->n_obs : 0; }
+
+int clc_factor_evaluate(clc_handle* h, const double pose[7], double* residuals, double* jacobians) {
+  if (!h || !pose || !residuals) return fail(CLC_ERR_INVALID_ARG, "clc_factor_evaluate: bad argument");
+  if (!h->d_tiles) return fail(CLC_ERR_NO_DATA, "clc_factor_evaluate: no observations uploaded");
+  CLC_HIP(hipSetDevice(h->device));
+  const size_t n = h->n_obs;
+  if (n == 0) return CLC_OK;
+  double *d_r = nullptr, *d_j = nullptr;
+  CLC_HIP(hipMalloc(&d_r, n * sizeof(double)));
+  if (jacobians) CLC_HIP(hipMalloc(&d_j, n * 7 * sizeof(double)));
+  std::memcpy(h->h_small, pose, 7 * sizeof(double));
+  CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int threads = 256;
+  hipLaunchKernelGGL(clc::factor_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, h->d_tiles, (long long)n, h->d_small, d_r, d_j);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  CLC_HIP(hipMemcpy(residuals, d_r, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (jacobians) CLC_HIP(hipMemcpy(jacobians, d_j, n * 7 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(d_r);
+  if (d_j) (void)hipFree(d_j);
+  return CLC_OK;
+}
+
+int clc_pose_plus(clc_handle* h, const double* x, const double* delta, double* out, size_t n) {
+  if (!h || (n > 0 && (!x || !delta || !out))) return fail(CLC_ERR_INVALID_ARG, "clc_pose_plus: bad argument");
+  if (n == 0) return CLC_OK;
+  CLC_HIP(hipSetDevice(h->device));
+  double* d = nullptr;
+  CLC_HIP(hipMalloc(&d, n * 20 * sizeof(double)));
+  double *d_x = d, *d_d = d + 7 * n, *d_o = d + 13 * n;
+  CLC_HIP(hipMemcpy(d_x, x, n * 7 * sizeof(double), hipMemcpyHostToDevice));
+  CLC_HIP(hipMemcpy(d_d, delta, n * 6 * sizeof(double), hipMemcpyHostToDevice));
+  const int threads = 256;
+  hipLaunchKernelGGL(clc::plus_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, d_x, d_d, d_o, (long long)n);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  CLC_HIP(hipMemcpy(out, d_o, n * 7 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return CLC_OK;
+}
+
+int clc_pose_plus_jacobian(const double* /*x*/, double jacobian[42]) {
+  if (!jacobian) return fail(CLC_ERR_INVALID_ARG, "clc_pose_plus_jacobian: NULL output");
+  for (int i = 0; i < 42; ++i) jacobian[i] = 0.0;
+  for (int i = 0; i < 6; ++i) jacobian[6 * i + i] = 1.0;  // [I6; 0], pose_local_parameterization.cpp:36-37
+  return CLC_OK;
+}
+
+int clc_eval(clc_handle* h, const double pose[7], int with_loss, double loss_scale_factor,
+             double* cost, double g[6], double H[21]) {
+  if (!h || !pose || !cost) return fail(CLC_ERR_INVALID_ARG, "clc_eval: bad argument");
+  if (!h->d_tiles) return fail(CLC_ERR_NO_DATA, "clc_eval: no observations uploaded");
+  if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_eval: non-finite pose");
+  CLC_HIP(hipSetDevice(h->device));
+  const int grid = eval_grid(h, h->n_obs);
+  int rc = ensure_partials(h, grid);
+  if (rc != CLC_OK) return rc;
+  std::memcpy(h->h_small, pose, 7 * sizeof(double));
+  CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const bool want_jac = (g != nullptr) || (H != nullptr);
+  if (want_jac)
+    launch_eval<true>(h, grid, with_loss != 0, h->d_small, nullptr, loss_scale_factor);
+  else
+    launch_eval<false>(h, grid, with_loss != 0, h->d_small, nullptr, loss_scale_factor);
+  CLC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(clc::reduce_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
+                     h->d_small + 16);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipMemcpyAsync(h->h_small + 16, h->d_small + 16, clc::NACC * sizeof(double), hipMemcpyDeviceToHost,
+                         h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  const double* r = h->h_small + 16;
+  *cost = r[27];
+  if (g) for (int i = 0; i < 6; ++i) g[i] = want_jac ? r[21 + i] : 0.0;
+  if (H) for (int i = 0; i < 21; ++i) H[i] = r[i];
+  return CLC_OK;
+}
+
+int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summary* summary,
+              clc_iteration* trace, int trace_cap) {
+  if (!h || !pose || !summary || trace_cap < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve: bad argument");
+  if (!h->d_tiles) return fail(CLC_ERR_NO_DATA, "clc_solve: no observations uploaded");
+  if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve: non-finite initial pose");
+  clc_options opt;
+  if (opt_in) opt = *opt_in; else clc_options_default(&opt);
+  if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve: max_num_iterations < 0");
+  CLC_HIP(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+
+  const int grid = eval_grid(h, h->n_obs);
+  int rc = ensure_partials(h, grid);
+  if (rc != CLC_OK) return rc;
+  const int max_evals = opt.max_num_iterations + 1;
+  const int dev_trace_cap = opt.max_num_iterations + 8;
+  rc = ensure_trace(h, dev_trace_cap);
+  if (rc != CLC_OK) return rc;
+  if (opt.profile_events) {
+    rc = ensure_events(h, 2 * (size_t)max_evals);
+    if (rc != CLC_OK) return rc;
+  }
+  const int sync_interval = opt.sync_interval > 0 ? opt.sync_interval : kDefaultSyncInterval;
+
+  std::memcpy(h->h_small, pose, 7 * sizeof(double));
+  CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, h->d_small);
+  CLC_HIP(hipGetLastError());
+
+  const double* d_x_eval = reinterpret_cast<const double*>(
+      reinterpret_cast<const char*>(h->d_state) + offsetof(clc::LmState, x_eval));
+  const int32_t* d_status = reinterpret_cast<const int32_t*>(
+      reinterpret_cast<const char*>(h->d_state) + offsetof(clc::LmState, status));
+  int32_t* h_status = reinterpret_cast<int32_t*>(h->h_small + 48);
+
+  int launched = 0;
+  bool done = false;
+  while (!done && launched < max_evals) {
+    if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
+    launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor);
+    if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
+    hipLaunchKernelGGL(clc::lm_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
+                       h->d_state, opt, h->d_trace, h->trace_cap);
+    ++launched;
+    if (launched % sync_interval == 0 || launched == max_evals) {
+      CLC_HIP(hipGetLastError());
+      CLC_HIP(hipMemcpyAsync(h_status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+      CLC_HIP(hipStreamSynchronize(h->stream));
+      if (*h_status != CLC_RUNNING) done = true;
+    }
+  }
+  // final read-back of the controller state and trace
+  clc::LmState* h_state = reinterpret_cast<clc::LmState*>(h->h_small + 256);
+  static_assert(sizeof(clc::LmState) <= (kSmallDoubles - 256) * sizeof(double), "pinned scratch too small");
+  CLC_HIP(hipMemcpyAsync(h_state, h->d_state, sizeof(clc::LmState), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  clc::lm_fill_summary(*h_state, *summary);
+  if (summary->termination == CLC_RUNNING) summary->termination = CLC_FAILURE;  // cannot happen
+  for (int i = 0; i < 7; ++i) pose[i] = h_state->x_out[i];
+  if (trace && trace_cap > 0) {
+    const int n = std::min(std::min(h_state->n_trace, trace_cap), h->trace_cap);
+    if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  summary->eval_kernel_ms = 0.0;
+  summary->eval_kernel_launches = 0;
+  if (opt.profile_events) {
+    const int n_real = (int)std::min<int64_t>(h_state->n_evals, launched);
+    double tot = 0.0;
+    for (int i = 0; i < n_real; ++i) {
+      float ms = 0.f;
+      CLC_HIP(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+      tot += ms;
+    }
+    summary->eval_kernel_ms = tot;
+    summary->eval_kernel_launches = n_real;
+  }
+  summary->solve_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve: non-finite result");
+  return CLC_OK;
+}
+
+int clc_information(clc_handle* h, const double pose[7], double H[36], double b[6], double* chi2,
+                    double sv[6], double V[36], int* n_null) {
+  if (!h || !pose || !H || !b || !chi2 || !sv || !n_null)
+    return fail(CLC_ERR_INVALID_ARG, "clc_information: bad argument");
+  double cost, g[6], H21[21];
+  int rc = clc_eval(h, pose, /*with_loss=*/0, 0.0, &cost, g, H21);  // :323-362: no loss
+  if (rc != CLC_OK) return rc;
+  int idx = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int c = a; c < 6; ++c) {
+      H[6 * a + c] = H21[idx];
+      H[6 * c + a] = H21[idx];
+      ++idx;
+    }
+  for (int a = 0; a < 6; ++a) b[a] = -g[a];  // b -= J^T r, :357
+  *chi2 = 2.0 * cost;                        // chi += r*r, :359
+  double Vtmp[36];
+  clc::host::jacobi_eig_sym(H, 6, sv, V ? V : Vtmp);  // JacobiSVD(H), :366
+  int n = 0;
+  for (int i = 0; i < 6; ++i)
+    if (sv[i] < 1e-8) ++n;  // :371
+  *n_null = n;
+  return CLC_OK;
+}
+
+int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9[9]) {
+  if (!h || !Tlc || !unobservable) return fail(CLC_ERR_INVALID_ARG, "clc_closed_form: bad argument");
+  if (!h->d_tiles || h->n_obs == 0) return fail(CLC_ERR_NO_DATA, "clc_closed_form: no observations uploaded");
+  CLC_HIP(hipSetDevice(h->device));
+  const int grid = eval_grid(h, h->n_obs);
+  int rc = ensure_partials(h, grid);
+  if (rc != CLC_OK) return rc;
+  hipLaunchKernelGGL(clc::normal9_kernel, dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_tiles,
+                     (long long)h->n_obs, h->d_partials);
+  CLC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(clc::reduce9_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
+                     h->d_small + 128);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipMemcpyAsync(h->h_small + 128, h->d_small + 128, clc::NACC9 * sizeof(double),
+                         hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  const double* r = h->h_small + 128;
+  auto tri3 = [](int a, int b) { if (a > b) std::swap(a, b); return a * 3 - (a * (a - 1)) / 2 + (b - a); };
+  double AtA[81], Atb[9];
+  for (int ci = 0; ci < 3; ++ci)
+    for (int ri = 0; ri < 3; ++ri) {
+      for (int cj = 0; cj < 3; ++cj)
+        for (int rj = 0; rj < 3; ++rj) AtA[9 * (3 * ci + ri) + (3 * cj + rj)] = r[6 * tri3(ci, cj) + tri3(ri, rj)];
+      Atb[3 * ci + ri] = r[36 + 3 * ci + ri];
+    }
+  rc = clc::host::closed_form_from_normal(AtA, Atb, Tlc, unobservable, sv9);
+  if (rc != CLC_OK) return fail(rc, "clc_closed_form: 9x9 normal equation is not positive definite");
+  return CLC_OK;
+}
+
+// ---- batched ---------------------------------------------------------------------------
+int clc_upload_batched(clc_handle* h, const clc_observation* records, const int64_t* offsets,
+                       size_t n_problems) {
+  if (!h || !offsets || (n_problems > 0 && !records))
+    return fail(CLC_ERR_INVALID_ARG, "clc_upload_batched: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  const size_t P = n_problems;
+  std::vector<long long> tile_off(P + 1, 0), nobs(P, 0);
+  long long max_tiles = 0;
+  for (size_t k = 0; k < P; ++k) {
+    const int64_t n = offsets[k + 1] - offsets[k];
+    if (n < 0) return fail(CLC_ERR_INVALID_ARG, "clc_upload_batched: offsets not monotone");
+    nobs[k] = n;
+    tile_off[k + 1] = tile_off[k] + (n + clc::TILE - 1) / clc::TILE;
+    max_tiles = std::max<long long>(max_tiles, tile_off[k + 1] - tile_off[k]);
+  }
+  h->batch_max_tiles = max_tiles;
+  const size_t total_tiles = (size_t)tile_off[P];
+  const size_t bytes = std::max<size_t>(total_tiles, 1) * clc::TILE_DOUBLES * sizeof(double);
+  if (bytes > h->btiles_cap_bytes) {
+    if (h->d_btiles) CLC_HIP(hipFree(h->d_btiles));
+    h->d_btiles = nullptr; h->btiles_cap_bytes = 0;
+    CLC_HIP(hipMalloc(&h->d_btiles, bytes));
+    h->btiles_cap_bytes = bytes;
+  }
+  if (P > h->problems_cap) {
+    void* olds[] = {h->d_tile_off, h->d_nobs, h->d_poses, h->d_summaries, h->d_states};
+    for (void* p : olds) if (p) CLC_HIP(hipFree(p));
+    h->d_tile_off = nullptr; h->d_nobs = nullptr; h->d_poses = nullptr; h->d_summaries = nullptr;
+    h->d_states = nullptr;
+    h->problems_cap = 0;
+    CLC_HIP(hipMalloc(&h->d_tile_off, sizeof(long long) * (P + 1)));
+    CLC_HIP(hipMalloc(&h->d_nobs, sizeof(long long) * P));
+    CLC_HIP(hipMalloc(&h->d_poses, sizeof(double) * 7 * P));
+    CLC_HIP(hipMalloc(&h->d_summaries, sizeof(clc_summary) * P));
+    CLC_HIP(hipMalloc(&h->d_states, sizeof(clc::LmState) * P));
+    h->problems_cap = P;
+  }
+  if (P == 0) { h->n_problems = 0; return CLC_OK; }
+  CLC_HIP(hipMemcpy(h->d_tile_off, tile_off.data(), sizeof(long long) * (P + 1), hipMemcpyHostToDevice));
+  CLC_HIP(hipMemcpy(h->d_nobs, nobs.data(), sizeof(long long) * P, hipMemcpyHostToDevice));
+  // stage the AoS records, then re-tile every problem into its own whole tiles
+  const size_t n_total = (size_t)(offsets[P] - offsets[0]);
+  double* d_aos = nullptr;
+  long long* d_off = nullptr;
+  if (n_total > 0) {
+    CLC_HIP(hipMalloc(&d_aos, n_total * sizeof(clc_observation)));
+    CLC_HIP(hipMemcpy(d_aos, records + offsets[0], n_total * sizeof(clc_observation), hipMemcpyHostToDevice));
+  }
+  std::vector<long long> rel(P + 1);
+  for (size_t k = 0; k <= P; ++k) rel[k] = offsets[k] - offsets[0];
+  CLC_HIP(hipMalloc(&d_off, sizeof(long long) * (P + 1)));
+  CLC_HIP(hipMemcpy(d_off, rel.data(), sizeof(long long) * (P + 1), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(clc::retile_batched_kernel, dim3((unsigned)P), dim3(256), 0, h->stream, d_aos, d_off,
+                     h->d_tile_off, h->d_btiles);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (d_aos) (void)hipFree(d_aos);
+  (void)hipFree(d_off);
+  if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
+  h->n_problems = P;
+  return CLC_OK;
+}
+
+size_t clc_num_problems(const clc_handle* h) { return h ? h->n_problems : 0; }
+
+int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, clc_summary* summaries) {
+  if (!h || !poses || !summaries) return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: bad argument");
+  if (!h->d_btiles || h->n_problems == 0) return fail(CLC_ERR_NO_DATA, "clc_solve_batched: no problems uploaded");
+  clc_options opt;
+  if (opt_in) opt = *opt_in; else clc_options_default(&opt);
+  if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: max_num_iterations < 0");
+  const size_t P = h->n_problems;
+  for (size_t i = 0; i < 7 * P; ++i)
+    if (!std::isfinite(poses[i])) return fail(CLC_ERR_NONFINITE, "clc_solve_batched: non-finite initial pose");
+  CLC_HIP(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  // enough workgroups to fill the chip: >= 2 per CU in total, never more than one per 4 tiles
+  int bpp = (int)((2 * (size_t)h->num_cus + P - 1) / P);
+  const long long max_tiles = h->batch_max_tiles;
+  const int bpp_cap = (int)std::max<long long>(1, max_tiles / 4);
+  bpp = std::max(1, std::min(bpp, bpp_cap));
+  const size_t n_blocks = P * (size_t)bpp;
+  if (n_blocks > h->bpartials_cap_blocks) {
+    if (h->d_bpartials) CLC_HIP(hipFree(h->d_bpartials));
+    h->d_bpartials = nullptr; h->bpartials_cap_blocks = 0;
+    CLC_HIP(hipMalloc(&h->d_bpartials, sizeof(double) * n_blocks * clc::NACC));
+    h->bpartials_cap_blocks = n_blocks;
+  }
+  CLC_HIP(hipMemcpyAsync(h->d_poses, poses, sizeof(double) * 7 * P, hipMemcpyHostToDevice, h->stream));
+  const int lm_threads = 64;
+  const unsigned lm_blocks = (unsigned)((P + lm_threads - 1) / lm_threads);
+  hipLaunchKernelGGL(clc::batched_init_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
+                     opt, h->d_poses, (int)P);
+  CLC_HIP(hipGetLastError());
+  const int sync_interval = opt.sync_interval > 0 ? opt.sync_interval : kDefaultSyncInterval;
+  const int max_evals = opt.max_num_iterations + 1;
+  unsigned int* h_active = reinterpret_cast<unsigned int*>(h->h_small + 48);
+  int launched = 0;
+  bool done = false;
+  while (!done && launched < max_evals) {
+    const bool check = ((launched + 1) % sync_interval == 0) || (launched + 1 == max_evals);
+    if (check) CLC_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), h->stream));
+    if (opt.use_loss)
+      hipLaunchKernelGGL((clc::batched_eval_kernel<true>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
+                         h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
+                         opt.loss_scale_factor, h->d_bpartials);
+    else
+      hipLaunchKernelGGL((clc::batched_eval_kernel<false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
+                         h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
+                         opt.loss_scale_factor, h->d_bpartials);
+    hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
+                       h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue);
+    ++launched;
+    if (check) {
+      CLC_HIP(hipGetLastError());
+      CLC_HIP(hipMemcpyAsync(h_active, h->d_queue, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+      CLC_HIP(hipStreamSynchronize(h->stream));
+      if (*h_active == 0) done = true;
+    }
+  }
+  hipLaunchKernelGGL(clc::batched_finish_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
+                     (int)P, h->d_poses, h->d_summaries);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipMemcpyAsync(poses, h->d_poses, sizeof(double) * 7 * P, hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipMemcpyAsync(summaries, h->d_summaries, sizeof(clc_summary) * P, hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (size_t k = 0; k < P; ++k) {
+    summaries[k].solve_ms = ms;
+    if (summaries[k].termination == CLC_RUNNING) summaries[k].termination = CLC_FAILURE;
+  }
+  return CLC_OK;
+}
+
+// ---- test hooks --------------------------------------------------------------------------
+// Runs only the wavefront reduction on in[64*28] -> out[28] (reduce_mode 0 butterfly, 1 shuffle).
+int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int reduce_mode) {
+  if (!h || !in || !out) return fail(CLC_ERR_INVALID_ARG, "clc_debug_wave_reduce: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  double* d = nullptr;
+  CLC_HIP(hipMalloc(&d, sizeof(double) * (64 * clc::NACC + clc::NACC)));
+  CLC_HIP(hipMemcpy(d, in, sizeof(double) * 64 * clc::NACC, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(clc::wave_reduce_test_kernel, dim3(1), dim3(64), 0, h->stream, d, d + 64 * clc::NACC,
+                     reduce_mode);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  CLC_HIP(hipMemcpy(out, d + 64 * clc::NACC, sizeof(double) * clc::NACC, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return CLC_OK;
+}
+
+// Times `reps` back-to-back launches of the evaluation kernel (K1 only) with HIP events on
+// the handle's stream; *avg_ms = mean kernel-to-kernel period.
+int clc_time_eval(clc_handle* h, const double pose[7], int with_loss, double lf, int with_jac, int reps,
+                  double* avg_ms) {
+  if (!h || !pose || !avg_ms || reps < 1) return fail(CLC_ERR_INVALID_ARG, "clc_time_eval: bad argument");
+  if (!h->d_tiles) return fail(CLC_ERR_NO_DATA, "clc_time_eval: no observations uploaded");
+  CLC_HIP(hipSetDevice(h->device));
+  const int grid = eval_grid(h, h->n_obs);
+  int rc = ensure_partials(h, grid);
+  if (rc != CLC_OK) return rc;
+  rc = ensure_events(h, 2);
+  if (rc != CLC_OK) return rc;
+  std::memcpy(h->h_small, pose, 7 * sizeof(double));
+  CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  for (int w = 0; w < 3; ++w) {
+    if (with_jac) launch_eval<true>(h, grid, with_loss != 0, h->d_small, nullptr, lf);
+    else launch_eval<false>(h, grid, with_loss != 0, h->d_small, nullptr, lf);
+  }
+  CLC_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int r = 0; r < reps; ++r) {
+    if (with_jac) launch_eval<true>(h, grid, with_loss != 0, h->d_small, nullptr, lf);
+    else launch_eval<false>(h, grid, with_loss != 0, h->d_small, nullptr, lf);
+  }
+  CLC_HIP(hipEventRecord(h->ev[1], h->stream));
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  CLC_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  *avg_ms = (double)ms / reps;
+  return CLC_OK;
+}
+
+}  // extern "C"

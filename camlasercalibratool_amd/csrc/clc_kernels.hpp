@@ -1,0 +1,625 @@
+// clc_kernels.hpp — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the point-to-plane
+// extrinsic path.  Included by clc_abi.hip only.
+//
+// Data layout in HBM ("tiled records"): the observation array handed over the C-ABI is an
+// array of 64-byte records {n[3], d, p[3], scale} (clc_observation).  On upload it is
+// re-tiled once into AoSoA tiles of TILE=128 records:
+//     tile t, field f (0..7), slot j (0..127)  ->  tiles[t*1024 + f*128 + j]
+// so that a wavefront reads one field of one tile with ONE fully coalesced 1-KiB
+// `global_load_dwordx4` (lane l gets slots 2l, 2l+1 as a double2).  A wave consumes a tile
+// per loop trip: 8 such loads, 2 observations per lane.  Every observation is read exactly
+// once per evaluation pass: 64 algorithmic bytes per residual+Jacobian evaluation.
+//
+// Kernels
+//   retile_kernel        AoS records -> tiles (once per upload)
+//   eval_kernel          K1: per-observation residual + analytic 6-DoF Jacobian (a3), Cauchy
+//                        corrector (a4), rank-1 accumulation of {H(21), g(6), cost} in 28 FP64
+//                        registers per lane, wave butterfly reduction (permlane32/16 swap +
+//                        DPP), LDS-staged per-wave partials, one 28-double partial per block
+//   lm_kernel            K2: fixed-order reduction of the block partials + the LM controller
+//                        (clc_lm.hpp) for the single-problem solve
+//   reduce_kernel        fixed-order reduction of block partials for clc_eval
+//   factor_kernel        per-record residual / 1x7 Jacobian rows (plug-in level parity)
+//   plus_kernel          batched PoseLocalParameterization::Plus
+//   normal9_kernel       K5: 9x9 normal equation of the closed-form initialiser
+//   batched_*_kernel     K4: independent problems in lockstep (eval + controller per iteration)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "clc_lm.hpp"
+#include "clc_math.hpp"
+
+namespace clc {
+
+constexpr int TILE = 128;               // records per tile
+constexpr int TILE_DOUBLES = TILE * 8;  // 1024 doubles = 8 KiB
+constexpr int NACC = 28;                // 21 (H upper triangle) + 6 (g) + 1 (cost)
+constexpr int BLOCK = 256;              // threads per workgroup (4 waves)
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double make_uniform(double v) {
+  // value is wave-uniform: move it to SGPRs so it costs no VGPRs in the streaming loop
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+struct PoseU {  // wave-uniform pose: rotation matrix (row-major) + translation
+  double R[9];
+  double t[3];
+};
+
+__device__ __forceinline__ void load_pose(const double* __restrict__ pose, PoseU& P) {
+  double x[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) x[i] = pose[i];
+  double R[9];
+  quat_to_rot(x + 3, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) P.R[i] = make_uniform(R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) P.t[i] = make_uniform(x[i]);
+}
+
+// One observation: residual r = s (n.(R p + t) + d)            (LaseCamCalCeres.cpp:47-48)
+//                  J_t = s n, J_theta = s (p x R^T n)            (:56-57, tangent space of Plus)
+//                  Cauchy a = lf*s: rho0 = b log(1 + r^2/b), rho1 = 1/(1 + r^2/b)   (:249)
+// Corrector (rho'' <= 0 branch): J~ = sqrt(rho1) J, r~ = sqrt(rho1) r, so
+//   H += rho1 J^T J, g += rho1 J^T r, cost += rho0 (halved at the end).
+template <bool WITH_LOSS, bool WITH_JAC>
+__device__ __forceinline__ void accumulate_observation(const PoseU& P, const double lf,
+                                                       const double nx, const double ny,
+                                                       const double nz, const double d,
+                                                       const double px, const double py,
+                                                       const double pz, const double s,
+                                                       double (&acc)[NACC]) {
+  // m = R^T n
+  const double mx = fma(P.R[6], nz, fma(P.R[3], ny, P.R[0] * nx));
+  const double my = fma(P.R[7], nz, fma(P.R[4], ny, P.R[1] * nx));
+  const double mz = fma(P.R[8], nz, fma(P.R[5], ny, P.R[2] * nx));
+  // n.(R p + t) + d = m.p + (n.t + d)
+  const double c0 = fma(P.t[2], nz, fma(P.t[1], ny, fma(P.t[0], nx, d)));
+  const double r = s * fma(mz, pz, fma(my, py, fma(mx, px, c0)));
+  double w = 1.0;
+  if (WITH_LOSS) {
+    const double a = lf * s;
+    const double b = a * a;
+    const double c = 1.0 / b;
+    const double sum = fma(r * r, c, 1.0);
+    acc[27] = fma(b, log(sum), acc[27]);
+    w = fmax(2.2250738585072014e-308, 1.0 / sum);
+  } else {
+    acc[27] = fma(r, r, acc[27]);
+  }
+  if (WITH_JAC) {
+    double J[6], wJ[6];
+    J[0] = s * nx;
+    J[1] = s * ny;
+    J[2] = s * nz;
+    J[3] = s * fma(py, mz, -(pz * my));
+    J[4] = s * fma(pz, mx, -(px * mz));
+    J[5] = s * fma(px, my, -(py * mx));
+#pragma unroll
+    for (int a = 0; a < 6; ++a) wJ[a] = WITH_LOSS ? w * J[a] : J[a];
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) {
+        acc[idx] = fma(wJ[a], J[b], acc[idx]);
+        ++idx;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] = fma(wJ[a], r, acc[21 + a]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// wavefront reduction of 28 FP64 accumulators
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_read(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// x.lanes[32..63] <-> y.lanes[0..31]
+__device__ __forceinline__ void swap_halves(double& x, double& y) {
+  auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// x.rows{1,3} <-> y.rows{0,2}   (rows of 16 lanes)
+__device__ __forceinline__ void swap_rows(double& x, double& y) {
+  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// Butterfly (reduce-scatter) wave reduction: 28 -> 14 registers with v_permlane32_swap,
+// 14 -> 7 with v_permlane16_swap, then a 4-step DPP all-reduce inside each 16-lane row.
+// 147 cross-lane/add instructions instead of 28*6*3 for 28 independent shuffles.
+// Result: wave total of acc[i + 7*rho] is in register i of every lane of row rho; the
+// lanes with (lane & 15) == 0 store it to out[i + 7*rho].
+__device__ __forceinline__ void wave_reduce_butterfly(double (&acc)[NACC], double* out, int lane) {
+  double r[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    double x = acc[i], y = acc[i + 14];
+    swap_halves(x, y);
+    r[i] = x + y;  // lanes 0-31: acc[i] over {l, l+32}; lanes 32-63: acc[i+14]
+  }
+  double u[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    double x = r[i], y = r[i + 7];
+    swap_rows(x, y);
+    u[i] = x + y;  // row rho holds partial sums of acc[i + 7*rho]
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    double v = u[i];
+    v += dpp_read<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_read<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_read<0x141>(v);  // row_half_mirror
+    v += dpp_read<0x140>(v);  // row_mirror
+    u[i] = v;
+  }
+  if ((lane & 15) == 0) {
+    const int rho = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) out[i + 7 * rho] = u[i];
+  }
+}
+
+// Reference reduction: 28 independent xor-shuffles (kept for A/B and as the checker of the
+// butterfly in tests).
+__device__ __forceinline__ void wave_reduce_shuffle(double (&acc)[NACC], double* out, int lane) {
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) out[k] = v;
+  }
+}
+
+// Block-level: per-wave totals staged in LDS, summed in wave order by the first 28 threads.
+template <int NWAVES>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], int reduce_mode,
+                                                   double* __restrict__ out28) {
+  __shared__ double wsum[NWAVES][NACC];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  if (reduce_mode == 0)
+    wave_reduce_butterfly(acc, wsum[wave], lane);
+  else
+    wave_reduce_shuffle(acc, wsum[wave], lane);
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) s += wsum[w][threadIdx.x];
+    out28[threadIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// retile: AoS records -> tiles.  One thread per record (one-time cost per upload).
+// ---------------------------------------------------------------------------------------
+__global__ void retile_kernel(const double* __restrict__ aos, double* __restrict__ tiles,
+                              long long n, long long n_padded) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_padded) return;
+  const long long t = k / TILE;
+  const int j = (int)(k % TILE);
+  double v[8];
+  if (k < n) {
+    const double2* src = reinterpret_cast<const double2*>(aos + 8 * k);
+    const double2 a = src[0], b = src[1], c = src[2], d = src[3];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
+  } else {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) v[f] = 0.0;
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) tiles[t * TILE_DOUBLES + f * TILE + j] = v[f];
+}
+
+// Batched variant: one workgroup per problem; problem k's records [rec_off[k], rec_off[k+1])
+// go to its own whole tiles starting at tile_off[k].
+__global__ void retile_batched_kernel(const double* __restrict__ aos,
+                                      const long long* __restrict__ rec_off,
+                                      const long long* __restrict__ tile_off,
+                                      double* __restrict__ tiles) {
+  const int prob = blockIdx.x;
+  const long long r0 = rec_off[prob];
+  const long long n = rec_off[prob + 1] - r0;
+  const long long n_padded = (tile_off[prob + 1] - tile_off[prob]) * TILE;
+  double* tb = tiles + tile_off[prob] * TILE_DOUBLES;
+  for (long long k = threadIdx.x; k < n_padded; k += blockDim.x) {
+    double v[8];
+    if (k < n) {
+      const double2* src = reinterpret_cast<const double2*>(aos + 8 * (r0 + k));
+      const double2 a = src[0], b = src[1], c = src[2], d = src[3];
+      v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
+    } else {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) v[f] = 0.0;
+    }
+    const long long t = k / TILE;
+    const int j = (int)(k % TILE);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) tb[t * TILE_DOUBLES + f * TILE + j] = v[f];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K1 — fused evaluation + reduction.
+// grid: any number of 256-thread blocks; waves stride over tiles.  Output: one 28-double
+// partial per block (deterministic: fixed lane->record map, fixed reduction shape).
+// status (nullable): device-side termination flag of the LM controller; a finished solve
+// turns the remaining enqueued launches into no-ops.
+// ---------------------------------------------------------------------------------------
+template <bool WITH_LOSS, bool WITH_JAC>
+__global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ tiles,
+                                                     const long long n,
+                                                     const double* __restrict__ pose,
+                                                     const int32_t* __restrict__ status,
+                                                     const double lf, const int reduce_mode,
+                                                     double* __restrict__ partials) {
+  if (status != nullptr && *status != CLC_RUNNING) return;
+  PoseU P;
+  load_pose(pose, P);
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+
+  const int lane = threadIdx.x & 63;
+  const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
+  const long long n_full = n / TILE;
+
+  for (long long tile = wave_global; tile < n_full; tile += n_waves) {
+    const double2* base = reinterpret_cast<const double2*>(tiles + tile * TILE_DOUBLES) + lane;
+    double2 f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
+    accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x,
+                                                f[5].x, f[6].x, f[7].x, acc);
+    accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
+                                                f[5].y, f[6].y, f[7].y, acc);
+  }
+  const int rem = (int)(n % TILE);
+  if (rem != 0 && wave_global == (n_full % n_waves)) {  // ragged last tile: masked lanes
+    const double2* base = reinterpret_cast<const double2*>(tiles + n_full * TILE_DOUBLES) + lane;
+    double2 f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
+    if (2 * lane < rem)
+      accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x,
+                                                  f[5].x, f[6].x, f[7].x, acc);
+    if (2 * lane + 1 < rem)
+      accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
+                                                  f[5].y, f[6].y, f[7].y, acc);
+  }
+  block_reduce_store<BLOCK / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
+}
+
+// Fixed-order sum of the block partials: thread (c, rg) sums rows rg, rg+8, ... of column c,
+// then column c is finished in row-group order.  Result in tot[28] of thread 0's caller via LDS.
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks,
+                                                double (*red)[32]) {
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  double s = 0.0;
+  if (c < NACC)
+    for (int b = rg; b < n_blocks; b += BLOCK / 32) s += partials[(size_t)b * NACC + c];
+  red[rg][c] = s;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(BLOCK) void reduce_kernel(const double* __restrict__ partials,
+                                                       int n_blocks, double* __restrict__ out28) {
+  __shared__ double red[BLOCK / 32][32];
+  reduce_partials(partials, n_blocks, red);
+  if (threadIdx.x < NACC) {
+    double s = 0.0;
+#pragma unroll
+    for (int rg = 0; rg < BLOCK / 32; ++rg) s += red[rg][threadIdx.x];
+    out28[threadIdx.x] = (threadIdx.x == 27) ? 0.5 * s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2 — reduction of the block partials + LM controller (single problem).
+// ---------------------------------------------------------------------------------------
+constexpr int LM_STATE_WORDS = (int)((sizeof(LmState) + 7) / 8);
+
+__global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ partials,
+                                                   int n_blocks, LmState* __restrict__ state,
+                                                   const clc_options opt,
+                                                   clc_iteration* __restrict__ trace,
+                                                   int trace_cap) {
+  __shared__ double red[BLOCK / 32][32];
+  __shared__ double sh_state[LM_STATE_WORDS];
+  __shared__ LmScratch scratch;
+  if (state->status != CLC_RUNNING) return;
+  for (int i = threadIdx.x; i < LM_STATE_WORDS; i += BLOCK)
+    sh_state[i] = reinterpret_cast<const double*>(state)[i];
+  reduce_partials(partials, n_blocks, red);
+  if (threadIdx.x == 0) {
+    double tot[NACC];
+#pragma unroll
+    for (int c = 0; c < NACC; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int rg = 0; rg < BLOCK / 32; ++rg) s += red[rg][c];
+      tot[c] = s;
+    }
+    LmState& st = *reinterpret_cast<LmState*>(sh_state);
+    lm_advance(st, scratch, opt, trace, trace_cap, 0.5 * tot[27], tot + 21, tot);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < LM_STATE_WORDS; i += BLOCK)
+    reinterpret_cast<double*>(state)[i] = sh_state[i];
+}
+
+__global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt,
+                               const double* __restrict__ pose0) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double p[7];
+    for (int i = 0; i < 7; ++i) p[i] = pose0[i];
+    LmState s;
+    lm_init(s, opt, p);
+    *state = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// plug-in level kernels (element-wise parity with the reference's Ceres callbacks)
+// ---------------------------------------------------------------------------------------
+// PointInPlaneFactor::Evaluate per record, literal operation order of
+// src/LaseCamCalCeres.cpp:43-66 (pt_c = R p + t; r = s (n.pt_c + d); J = s [n, n^T(-R [p]x), 0]).
+__global__ void factor_kernel(const double* __restrict__ tiles, long long n,
+                              const double* __restrict__ pose, double* __restrict__ residuals,
+                              double* __restrict__ jac7) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double* tb = tiles + (k / TILE) * TILE_DOUBLES + (k % TILE);
+  const double nx = tb[0], ny = tb[TILE], nz = tb[2 * TILE], d = tb[3 * TILE];
+  const double p[3] = {tb[4 * TILE], tb[5 * TILE], tb[6 * TILE]};
+  const double s = tb[7 * TILE];
+  double x[7], R[9];
+  for (int i = 0; i < 7; ++i) x[i] = pose[i];
+  quat_to_rot(x + 3, R);
+  double ptc[3];
+  for (int i = 0; i < 3; ++i)
+    ptc[i] = ((R[3 * i] * p[0] + R[3 * i + 1] * p[1]) + R[3 * i + 2] * p[2]) + x[i];
+  residuals[k] = s * (((nx * ptc[0] + ny * ptc[1]) + nz * ptc[2]) + d);
+  if (jac7 != nullptr) {
+    const double S[9] = {0.0, -p[2], p[1], p[2], 0.0, -p[0], -p[1], p[0], 0.0};
+    double* j = jac7 + 7 * k;
+    j[0] = s * nx;
+    j[1] = s * ny;
+    j[2] = s * nz;
+    for (int c = 0; c < 3; ++c) {
+      double M[3];
+      for (int i = 0; i < 3; ++i)
+        M[i] = ((-R[3 * i]) * S[c] + (-R[3 * i + 1]) * S[3 + c]) + (-R[3 * i + 2]) * S[6 + c];
+      j[3 + c] = s * ((nx * M[0] + ny * M[1]) + nz * M[2]);
+    }
+    j[6] = 0.0;
+  }
+}
+
+// PoseLocalParameterization::Plus, one thread per (x, delta) pair.
+__global__ void plus_kernel(const double* __restrict__ x, const double* __restrict__ delta,
+                            double* __restrict__ out, long long n) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double a[7], d[6], o[7];
+  for (int i = 0; i < 7; ++i) a[i] = x[7 * k + i];
+  for (int i = 0; i < 6; ++i) d[i] = delta[6 * k + i];
+  pose_plus(a, d, o);
+  for (int i = 0; i < 7; ++i) out[7 * k + i] = o[i];
+}
+
+// Debug/test entry: run only the wave reduction on caller-provided lane values
+// in[64][28] -> out[28].
+__global__ void wave_reduce_test_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                        int reduce_mode) {
+  const int lane = threadIdx.x & 63;
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = in[lane * NACC + k];
+  __shared__ double o[NACC];
+  if (reduce_mode == 0)
+    wave_reduce_butterfly(acc, o, lane);
+  else
+    wave_reduce_shuffle(acc, o, lane);
+  __syncthreads();
+  if (threadIdx.x < NACC) out[threadIdx.x] = o[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------
+// K5 — 9x9 normal equation of the closed-form initialiser (LaseCamCalCeres.cpp:144-161).
+// Row A_k = kron([x, y, 1], n), b_k = -d.  A^T A = sum kron(bb^T, nn^T): 6 x 6 unique
+// products, A^T b: 9.  45 accumulators per lane; same streaming/reduction shape as K1.
+// Output per block: 45 doubles: [bb(6: xx xy x yy y 1)][nn(6: 00 01 02 11 12 22)] then 9.
+// ---------------------------------------------------------------------------------------
+constexpr int NACC9 = 45;
+
+__device__ __forceinline__ void accumulate_normal9(double nx, double ny, double nz, double d,
+                                                   double x, double y, double (&acc)[NACC9]) {
+  const double nn[6] = {nx * nx, nx * ny, nx * nz, ny * ny, ny * nz, nz * nz};
+  const double bb[6] = {x * x, x * y, x, y * y, y, 1.0};
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[6 * i + j] = fma(bb[i], nn[j], acc[6 * i + j]);
+  const double md = -d;
+  const double bv[3] = {x, y, 1.0};
+  const double nv[3] = {nx, ny, nz};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[36 + 3 * i + j] = fma(bv[i] * nv[j], md, acc[36 + 3 * i + j]);
+}
+
+__global__ __launch_bounds__(BLOCK) void normal9_kernel(const double* __restrict__ tiles,
+                                                        const long long n,
+                                                        double* __restrict__ partials) {
+  double acc[NACC9];
+#pragma unroll
+  for (int i = 0; i < NACC9; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
+  const long long n_tiles = (n + TILE - 1) / TILE;
+  for (long long tile = wave_global; tile < n_tiles; tile += n_waves) {
+    const double2* base = reinterpret_cast<const double2*>(tiles + tile * TILE_DOUBLES) + lane;
+    double2 f[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] = base[k * 64];
+    const long long k0 = tile * TILE + 2 * lane;
+    if (k0 < n) accumulate_normal9(f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x, acc);
+    if (k0 + 1 < n) accumulate_normal9(f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y, acc);
+  }
+  __shared__ double wsum[BLOCK / 64][NACC9];
+#pragma unroll
+  for (int k = 0; k < NACC9; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) wsum[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC9) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) s += wsum[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * NACC9 + threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void reduce9_kernel(const double* __restrict__ partials,
+                                                        int n_blocks, double* __restrict__ out) {
+  // 45 columns: thread c < 45 of each of 4 row groups (64 threads per group)
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  double s = 0.0;
+  if (c < NACC9)
+    for (int b = rg; b < n_blocks; b += 4) s += partials[(size_t)b * NACC9 + c];
+  red[rg][c] = s;
+  __syncthreads();
+  if (threadIdx.x < NACC9)
+    out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------
+// K4 — batched independent problems (lockstep): every LM iteration is one launch of
+// batched_eval_kernel (blocks_per_problem workgroups stream each still-running problem at
+// its own candidate pose) followed by batched_lm_kernel (one thread per problem runs the LM
+// controller).  Problems that have terminated cost nothing in later launches.  Problem k
+// owns tiles [tile_off[k], tile_off[k+1]) (padded to whole tiles) and n_obs[k] records; no
+// communication between problems.
+// ---------------------------------------------------------------------------------------
+template <bool WITH_LOSS>
+__global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
+    const double* __restrict__ tiles, const long long* __restrict__ tile_off,
+    const long long* __restrict__ n_obs, const LmState* __restrict__ states,
+    const int blocks_per_problem, const double lf, double* __restrict__ partials) {
+  const int prob = blockIdx.x / blocks_per_problem;
+  const int j = blockIdx.x - prob * blocks_per_problem;
+  const LmState* st = states + prob;
+  if (st->status != CLC_RUNNING) return;
+  PoseU P;
+  load_pose(st->x_eval, P);
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const long long wave_global = (long long)j * (BLOCK / 64) + (threadIdx.x >> 6);
+  const long long n_waves = (long long)blocks_per_problem * (BLOCK / 64);
+  const double* ptiles = tiles + tile_off[prob] * TILE_DOUBLES;
+  const long long n = n_obs[prob];
+  const long long n_full = n / TILE;
+  for (long long tile = wave_global; tile < n_full; tile += n_waves) {
+    const double2* base = reinterpret_cast<const double2*>(ptiles + tile * TILE_DOUBLES) + lane;
+    double2 f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
+    accumulate_observation<WITH_LOSS, true>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
+                                            f[6].x, f[7].x, acc);
+    accumulate_observation<WITH_LOSS, true>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
+                                            f[6].y, f[7].y, acc);
+  }
+  const int rem = (int)(n % TILE);
+  if (rem != 0 && wave_global == (n_full % n_waves)) {
+    const double2* base = reinterpret_cast<const double2*>(ptiles + n_full * TILE_DOUBLES) + lane;
+    double2 f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
+    if (2 * lane < rem)
+      accumulate_observation<WITH_LOSS, true>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
+                                              f[6].x, f[7].x, acc);
+    if (2 * lane + 1 < rem)
+      accumulate_observation<WITH_LOSS, true>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
+                                              f[6].y, f[7].y, acc);
+  }
+  block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
+}
+
+__global__ void batched_init_kernel(LmState* __restrict__ states, const clc_options opt,
+                                    const double* __restrict__ poses, int n_problems) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_problems) return;
+  double x[7];
+  for (int i = 0; i < 7; ++i) x[i] = poses[7 * (size_t)p + i];
+  LmState s;
+  lm_init(s, opt, x);
+  states[p] = s;
+}
+
+// One thread per problem: fixed-order sum of the problem's block partials, then the LM
+// controller.  *active counts the problems that still need another evaluation.
+__global__ void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
+                                  LmState* __restrict__ states, const clc_options opt,
+                                  const int n_problems, unsigned int* __restrict__ active) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_problems) return;
+  if (states[p].status != CLC_RUNNING) return;
+  double tot[NACC];
+  for (int c = 0; c < NACC; ++c) tot[c] = 0.0;
+  for (int j = 0; j < blocks_per_problem; ++j) {
+    const double* pp = partials + ((size_t)p * blocks_per_problem + j) * NACC;
+    for (int c = 0; c < NACC; ++c) tot[c] += pp[c];
+  }
+  LmState s = states[p];
+  LmScratch w;
+  lm_advance(s, w, opt, nullptr, 0, 0.5 * tot[27], tot + 21, tot);
+  states[p] = s;
+  if (s.status == CLC_RUNNING) atomicAdd(active, 1u);
+}
+
+__global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_problems,
+                                      double* __restrict__ poses, clc_summary* __restrict__ summaries) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_problems) return;
+  const LmState* s = states + p;
+  for (int i = 0; i < 7; ++i) poses[7 * (size_t)p + i] = s->x_out[i];
+  clc_summary sm;
+  lm_fill_summary(*s, sm);
+  sm.solve_ms = 0.0;
+  sm.eval_kernel_ms = 0.0;
+  sm.eval_kernel_launches = 0;
+  summaries[p] = sm;
+}
+
+}  // namespace clc

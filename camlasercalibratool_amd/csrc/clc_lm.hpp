@@ -1,0 +1,273 @@
+// clc_lm.hpp — the Levenberg-Marquardt trust-region controller that replaces
+// ceres::Solve for the problem CamLaserCalibration builds (src/LaseCamCalCeres.cpp:299-307).
+//
+// It is a re-entrant state machine, not a loop: the evaluation kernels stream the
+// observation array and reduce {cost, g = J~^T r~, H = J~^T J~} at the point `x_eval`;
+// `lm_advance` consumes that 28-number result, runs everything Ceres does between two
+// evaluations (step acceptance, radius update, termination tests, Jacobi scaling, LM
+// damping, the 6x6 solve, Plus) and leaves the next point to evaluate in `x_eval`.
+// One thread executes it: in the tail of the single-problem reduction kernel, and once per
+// iteration inside the batched persistent kernel.  All state lives in device memory so a
+// whole solve is enqueued without host round trips.
+//
+// Semantics follow Ceres 1.13-2.1 TrustRegionMinimizer / LevenbergMarquardtStrategy with
+// the options of SURVEY.md Appendix A.  Differences by design (results equal to rounding,
+// verified against the oracle): the linear step solves the damped 6x6 normal equations by
+// Cholesky instead of Householder QR of [J;D]; the candidate is evaluated with its
+// Jacobian in the same pass, so an accepted step needs no second pass.
+// Written for device code; also compiled for the host by the unit shim in tests/.
+#pragma once
+#include "clc_math.hpp"
+#include "../../include/clc.h"
+
+namespace clc {
+
+struct LmState {
+  int32_t status;  // CLC_RUNNING or a termination code
+  int32_t phase;   // 0: x_eval is the initial point, 1: x_eval is a candidate
+  int32_t iteration;
+  int32_t n_invalid;
+  int32_t reuse_diagonal;
+  int32_t num_successful;
+  int32_t num_unsuccessful;
+  int32_t n_trace;
+  int64_t n_evals;
+  double x[7];       // current accepted iterate
+  double x_eval[7];  // point the next evaluation pass must use
+  double x_out[7];   // Ceres' `parameters_`: lowest-cost accepted iterate
+  double x_norm, x_cost, minimum_cost, initial_cost, min_iter_cost;
+  double g[6], H[21];  // gradient / Gauss-Newton matrix at x (unscaled, robustified)
+  double scale[6];     // Jacobi column scaling, fixed at iteration 0
+  double diag[6];      // clamp(diag(J_s^T J_s)) used for the LM damping
+  double radius, decrease_factor;
+  double step[6];      // trust-region step in the scaled space
+  double model_cost_change;
+  double gmax;
+};
+
+// Temporaries of the controller (LDS on the device, stack in the host shim).
+struct LmScratch {
+  double Hs[36], A[36], L[36];
+  double gs[6], y[6], z[6], ng[6], delta[6];
+  double proj[7];
+};
+
+CLC_HD void lm_init(LmState& s, const clc_options& o, const double* pose0) {
+  s.status = CLC_RUNNING;
+  s.phase = 0;
+  s.iteration = 0;
+  s.n_invalid = 0;
+  s.reuse_diagonal = 0;
+  s.num_successful = 0;
+  s.num_unsuccessful = 0;
+  s.n_trace = 0;
+  s.n_evals = 0;
+  CLC_ROLLED for (int i = 0; i < 7; ++i) s.x[i] = s.x_eval[i] = s.x_out[i] = pose0[i];
+  s.x_norm = norm7(pose0);
+  s.x_cost = 0.0;
+  s.minimum_cost = 1.7976931348623157e308;
+  s.initial_cost = 0.0;
+  s.min_iter_cost = 0.0;
+  CLC_ROLLED for (int i = 0; i < 6; ++i) { s.g[i] = 0.0; s.scale[i] = 1.0; s.diag[i] = 0.0; s.step[i] = 0.0; }
+  CLC_ROLLED for (int i = 0; i < 21; ++i) s.H[i] = 0.0;
+  s.radius = o.initial_trust_region_radius;
+  s.decrease_factor = 2.0;
+  s.model_cost_change = 0.0;
+  s.gmax = 0.0;
+}
+
+// ||x - Plus(x, -g)||_inf in the ambient 7-space (Ceres' projected-gradient norm).
+CLC_HD double gradient_max_norm(const double* x, const double* g, LmScratch& w) {
+  CLC_ROLLED for (int i = 0; i < 6; ++i) w.ng[i] = -g[i];
+  pose_plus(x, w.ng, w.proj);
+  double m = 0.0;
+  CLC_ROLLED for (int i = 0; i < 7; ++i) {
+    const double a = fabs(x[i] - w.proj[i]);
+    m = a > m ? a : m;
+  }
+  return m;
+}
+
+// LevenbergMarquardtStrategy::ComputeStep + the model-cost test of ComputeTrustRegionStep.
+CLC_HD bool lm_compute_step(LmState& s, const clc_options& o, LmScratch& w) {
+  int idx = 0;
+  CLC_ROLLED for (int a = 0; a < 6; ++a)
+    CLC_ROLLED for (int b = a; b < 6; ++b) {
+      const double v = s.H[idx++] * s.scale[a] * s.scale[b];
+      w.Hs[6 * a + b] = v;
+      w.Hs[6 * b + a] = v;
+    }
+  CLC_ROLLED for (int a = 0; a < 6; ++a) w.gs[a] = s.g[a] * s.scale[a];
+  if (!s.reuse_diagonal) {
+    CLC_ROLLED for (int c = 0; c < 6; ++c) {
+      double d = w.Hs[6 * c + c];
+      d = d > o.min_lm_diagonal ? d : o.min_lm_diagonal;
+      d = d < o.max_lm_diagonal ? d : o.max_lm_diagonal;
+      s.diag[c] = d;
+    }
+  }
+  CLC_ROLLED for (int i = 0; i < 36; ++i) w.A[i] = w.Hs[i];
+  CLC_ROLLED for (int c = 0; c < 6; ++c) {
+    const double d = sqrt(s.diag[c] / s.radius);  // lm_diagonal = sqrt(diag / radius)
+    w.A[6 * c + c] += d * d;
+  }
+  bool ok = chol6_solve(w.A, w.gs, w.y, w.L, w.z);
+  s.reuse_diagonal = 1;
+  if (ok) {
+    CLC_ROLLED for (int c = 0; c < 6; ++c)
+      if (!(fabs(w.y[c]) <= 1.7976931348623157e308)) ok = false;  // NaN/Inf check
+  }
+  if (!ok) return false;
+  double sg = 0.0, shs = 0.0;
+  CLC_ROLLED for (int a = 0; a < 6; ++a) s.step[a] = -w.y[a];
+  CLC_ROLLED for (int a = 0; a < 6; ++a) {
+    sg += s.step[a] * w.gs[a];
+    double row = 0.0;
+    CLC_ROLLED for (int b = 0; b < 6; ++b) row += w.Hs[6 * a + b] * s.step[b];
+    shs += s.step[a] * row;
+  }
+  // model_cost_change = -(J step)^T (r + J step / 2)
+  s.model_cost_change = -(sg + 0.5 * shs);
+  return s.model_cost_change > 0.0;
+}
+
+CLC_HD void lm_record(LmState& s, clc_iteration* trace, int trace_cap, const clc_iteration& it) {
+  if (trace && s.n_trace < trace_cap) trace[s.n_trace] = it;
+  s.n_trace++;
+  s.min_iter_cost = it.cost < s.min_iter_cost ? it.cost : s.min_iter_cost;
+}
+
+// Consume one evaluation {cost, g[6], H[21]} taken at s.x_eval and advance to the next
+// evaluation request or to termination.
+CLC_HD void lm_advance(LmState& s, LmScratch& w, const clc_options& o, clc_iteration* trace,
+                       int trace_cap, double cost_e, const double* g_e, const double* H_e) {
+  if (s.status != CLC_RUNNING) return;
+  s.n_evals++;
+  clc_iteration it;
+  it.iteration = 0; it.step_is_valid = 0; it.step_is_successful = 0; it.pad_ = 0;
+  it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0;
+  it.relative_decrease = 0.0; it.trust_region_radius = 0.0;
+
+  const bool finite_eval = fabs(cost_e) <= 1.7976931348623157e308;  // false for NaN/Inf
+  if (s.phase == 0) {
+    // ---- IterationZero ----
+    if (!finite_eval) { s.status = CLC_FAILURE; return; }
+    s.x_cost = cost_e;
+    CLC_ROLLED for (int i = 0; i < 6; ++i) s.g[i] = g_e[i];
+    CLC_ROLLED for (int i = 0; i < 21; ++i) s.H[i] = H_e[i];
+    if (o.jacobi_scaling)
+      CLC_ROLLED for (int c = 0; c < 6; ++c) s.scale[c] = 1.0 / (1.0 + sqrt(s.H[tri6(c, c)]));
+    s.gmax = gradient_max_norm(s.x, s.g, w);
+    s.initial_cost = s.x_cost;
+    s.min_iter_cost = s.x_cost;
+    it.iteration = 0;
+    it.cost = s.x_cost;
+    it.gradient_max_norm = s.gmax;
+    it.step_is_valid = 1;
+    it.step_is_successful = 1;
+  } else {
+    it.iteration = s.iteration;
+    it.step_is_valid = 1;
+    // Ceres maps a failed candidate evaluation to cost = DBL_MAX (step gets rejected).
+    const double candidate_cost = finite_eval ? cost_e : 1.7976931348623157e308;
+    // ---- ParameterToleranceReached ----
+    double sn = 0.0;
+    CLC_ROLLED for (int i = 0; i < 7; ++i) sn += (s.x[i] - s.x_eval[i]) * (s.x[i] - s.x_eval[i]);
+    it.step_norm = sqrt(sn);
+    if (it.step_norm <= o.parameter_tolerance * (s.x_norm + o.parameter_tolerance)) {
+      s.status = CLC_CONVERGENCE_PARAMETER;
+      return;
+    }
+    // ---- FunctionToleranceReached ----
+    it.cost_change = s.x_cost - candidate_cost;
+    if (fabs(it.cost_change) <= o.function_tolerance * s.x_cost) {
+      s.status = CLC_CONVERGENCE_FUNCTION;
+      return;
+    }
+    // ---- IsStepSuccessful (monotonic step evaluator) ----
+    it.relative_decrease = it.cost_change / s.model_cost_change;
+    if (it.relative_decrease > o.min_relative_decrease) {
+      // ---- HandleSuccessfulStep: the fused pass already produced g,H at the candidate ----
+      CLC_ROLLED for (int i = 0; i < 7; ++i) s.x[i] = s.x_eval[i];
+      s.x_norm = norm7(s.x);
+      s.x_cost = candidate_cost;
+      CLC_ROLLED for (int i = 0; i < 6; ++i) s.g[i] = g_e[i];
+      CLC_ROLLED for (int i = 0; i < 21; ++i) s.H[i] = H_e[i];
+      s.gmax = gradient_max_norm(s.x, s.g, w);
+      it.cost = s.x_cost;
+      it.gradient_max_norm = s.gmax;
+      it.step_is_successful = 1;
+      const double q = 2.0 * it.relative_decrease - 1.0;  // StepAccepted
+      double den = 1.0 - q * q * q;
+      den = den > (1.0 / 3.0) ? den : (1.0 / 3.0);
+      s.radius = s.radius / den;
+      s.radius = s.radius < o.max_trust_region_radius ? s.radius : o.max_trust_region_radius;
+      s.decrease_factor = 2.0;
+      s.reuse_diagonal = 0;
+    } else {
+      // ---- HandleUnsuccessfulStep ----
+      it.step_is_successful = 0;
+      s.radius = s.radius / s.decrease_factor;  // StepRejected
+      s.decrease_factor *= 2.0;
+      s.reuse_diagonal = 1;
+      it.cost = candidate_cost;
+      it.gradient_max_norm = s.gmax;
+    }
+  }
+
+  for (;;) {
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
+    if (it.step_is_successful) {
+      s.num_successful++;
+      if (s.x_cost < s.minimum_cost) {
+        s.minimum_cost = s.x_cost;
+        CLC_ROLLED for (int i = 0; i < 7; ++i) s.x_out[i] = s.x[i];
+      }
+    } else {
+      s.num_unsuccessful++;
+    }
+    it.trust_region_radius = s.radius;
+    lm_record(s, trace, trace_cap, it);
+    if (it.iteration >= o.max_num_iterations) { s.status = CLC_NO_CONVERGENCE; return; }
+    if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) {
+      s.status = CLC_CONVERGENCE_GRADIENT;
+      return;
+    }
+    if (it.trust_region_radius <= o.min_trust_region_radius) {
+      s.status = CLC_CONVERGENCE_RADIUS;
+      return;
+    }
+    // ---- next iteration: ComputeTrustRegionStep ----
+    const int next = it.iteration + 1;
+    it.iteration = next; it.step_is_valid = 0; it.step_is_successful = 0;
+    it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0;
+    it.relative_decrease = 0.0; it.trust_region_radius = 0.0;
+    if (lm_compute_step(s, o, w)) {
+      s.n_invalid = 0;
+      CLC_ROLLED for (int c = 0; c < 6; ++c) w.delta[c] = s.step[c] * s.scale[c];  // undo column scaling
+      pose_plus(s.x, w.delta, s.x_eval);  // candidate
+      s.phase = 1;
+      s.iteration = next;
+      return;  // request an evaluation at x_eval
+    }
+    // ---- HandleInvalidStep ----
+    if (++s.n_invalid >= o.max_num_consecutive_invalid_steps) { s.status = CLC_FAILURE; return; }
+    s.radius = s.radius / s.decrease_factor;  // StepIsInvalid == StepRejected(0)
+    s.decrease_factor *= 2.0;
+    s.reuse_diagonal = 1;
+    it.cost = s.x_cost;
+    it.gradient_max_norm = s.gmax;
+  }
+}
+
+CLC_HD void lm_fill_summary(const LmState& s, clc_summary& out) {
+  out.termination = s.status;
+  out.num_iterations = s.n_trace - 1;
+  out.num_successful_steps = s.num_successful;
+  out.num_unsuccessful_steps = s.num_unsuccessful;
+  out.num_evaluations = s.n_evals;
+  out.initial_cost = s.initial_cost;
+  out.final_cost = s.initial_cost < s.min_iter_cost ? s.initial_cost : s.min_iter_cost;
+}
+
+}  // namespace clc

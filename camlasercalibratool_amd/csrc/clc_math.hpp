@@ -1,0 +1,93 @@
+// clc_math.hpp — scalar FP64 building blocks of the point-to-plane path, written once for
+// device code (hipcc) and for the host-side unit shim (g++, tests only).
+//
+//   quat_to_rot      Eigen::Quaterniond::toRotationMatrix  (src/LaseCamCalCeres.cpp:47,57,313)
+//   pose_plus        PoseLocalParameterization::Plus       (src/pose_local_parameterization.cpp:15-31)
+//   chol6_solve      the 6x6 damped normal-equation solve that replaces Ceres' DENSE_QR of [J;D]
+//   jacobi_eig_sym   symmetric eigen-solver standing in for Eigen::JacobiSVD on SPD input
+//                    (src/LaseCamCalCeres.cpp:162,366)
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CLC_HD __host__ __device__ __forceinline__
+#define CLC_ROLLED _Pragma("unroll 1")
+#else
+#define CLC_HD inline
+#define CLC_ROLLED
+#endif
+
+namespace clc {
+
+// q = (x,y,z,w) as stored in the 7-vector (src/LaseCamCalCeres.cpp:219); R row-major.
+// No normalisation, like Eigen.
+CLC_HD void quat_to_rot(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+// p+ = p + dp ; q+ = normalize(q (x) [1, dtheta/2])  — right-multiplicative, dq not normalised.
+CLC_HD void pose_plus(const double* x, const double* delta, double* out) {
+  out[0] = x[0] + delta[0];
+  out[1] = x[1] + delta[1];
+  out[2] = x[2] + delta[2];
+  const double bx = delta[3] / 2.0, by = delta[4] / 2.0, bz = delta[5] / 2.0;
+  const double ax = x[3], ay = x[4], az = x[5], aw = x[6];
+  const double w = aw - ax * bx - ay * by - az * bz;
+  const double qx = aw * bx + ax + ay * bz - az * by;
+  const double qy = aw * by + ay + az * bx - ax * bz;
+  const double qz = aw * bz + az + ax * by - ay * bx;
+  const double n = sqrt(qx * qx + qy * qy + qz * qz + w * w);
+  out[3] = qx / n;
+  out[4] = qy / n;
+  out[5] = qz / n;
+  out[6] = w / n;
+}
+
+CLC_HD double norm7(const double* x) {
+  double s = 0.0;
+  CLC_ROLLED for (int i = 0; i < 7; ++i) s += x[i] * x[i];
+  return sqrt(s);
+}
+
+// index of (a,b), a<=b, in the packed upper triangle (row-major: 00 01 .. 05 11 ..)
+CLC_HD int tri6(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
+
+// Solve A y = b for symmetric positive definite 6x6 A (row-major). false if a pivot <= 0.
+// L (36) and z (6) are caller-provided scratch (LDS on the device): the loops stay rolled so
+// the controller costs few registers next to the streaming loop it shares a kernel with.
+CLC_HD bool chol6_solve(const double* A, const double* b, double* y, double* L, double* z) {
+  CLC_ROLLED for (int i = 0; i < 36; ++i) L[i] = 0.0;
+  CLC_ROLLED for (int j = 0; j < 6; ++j) {
+    double d = A[6 * j + j];
+    CLC_ROLLED for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+    if (!(d > 0.0)) return false;
+    const double ljj = sqrt(d);
+    L[6 * j + j] = ljj;
+    CLC_ROLLED for (int i = j + 1; i < 6; ++i) {
+      double s = A[6 * i + j];
+      CLC_ROLLED for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = s / ljj;
+    }
+  }
+  CLC_ROLLED for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    CLC_ROLLED for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
+    z[i] = s / L[6 * i + i];
+  }
+  CLC_ROLLED for (int i = 5; i >= 0; --i) {
+    double s = z[i];
+    CLC_ROLLED for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
+    y[i] = s / L[6 * i + i];
+  }
+  return true;
+}
+
+}  // namespace clc

@@ -1,0 +1,175 @@
+"""Solver: thin object wrapper over one clc_handle (include/clc.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import Iteration, Options, Summary, TERMINATION, check, default_options, dptr, iptr
+
+
+@dataclass
+class SolveResult:
+    pose: np.ndarray  # [tx,ty,tz,qx,qy,qz,qw]
+    summary: Summary
+    trace: List[Iteration]
+
+    @property
+    def termination(self) -> str:
+        return TERMINATION.get(self.summary.termination, "?")
+
+
+def flatten_observations(obs_set, use_linefitting_data: bool = True, use_boundary_constraint: bool = False) -> np.ndarray:
+    """Residual-block construction of CamLaserCalibration (src/LaseCamCalCeres.cpp:222-295)
+    -> records [N,8] = {n(3), d, p(3), scale}.  Host-side; does not need a GPU."""
+    L = _capi.lib()
+    n = C.c_int64()
+    args = (C.c_int(obs_set.n_poses), dptr(np.ascontiguousarray(obs_set.tag_q, dtype=np.float64)),
+            dptr(np.ascontiguousarray(obs_set.tag_t, dtype=np.float64)), iptr(obs_set.pts_off), dptr(obs_set.pts),
+            iptr(obs_set.ptl_off), dptr(obs_set.ptl), C.c_int(int(use_linefitting_data)),
+            C.c_int(int(use_boundary_constraint)))
+    check(L.clc_flatten_observations(*args, None, C.byref(n)), "clc_flatten_observations")
+    rec = np.empty((n.value, 8))
+    check(L.clc_flatten_observations(*args, dptr(rec), C.byref(n)), "clc_flatten_observations")
+    return rec
+
+
+class Solver:
+    """One solver context on one GPU (one HIP stream).  Not thread-safe per instance."""
+
+    def __init__(self, device: int = 0):
+        self._L = _capi.lib()
+        self._h = C.c_void_p()
+        check(self._L.clc_create(C.byref(self._h), C.c_int(device)), "clc_create")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.clc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- configuration ----
+    def set_stream(self, hip_stream: Optional[int]):
+        check(self._L.clc_set_stream(self._h, C.c_void_p(hip_stream or 0)), "clc_set_stream")
+
+    def set_launch(self, grid_blocks: int = 0, reduce_mode: int = 0):
+        check(self._L.clc_set_launch(self._h, C.c_int(grid_blocks), C.c_int(reduce_mode)), "clc_set_launch")
+
+    def device_info(self) -> Tuple[str, int]:
+        buf = C.create_string_buffer(256)
+        n = C.c_int()
+        check(self._L.clc_device_info(self._h, buf, C.c_int(256), C.byref(n)), "clc_device_info")
+        return buf.value.decode(), n.value
+
+    # ---- data ----
+    def upload(self, records: np.ndarray):
+        records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 8)
+        check(self._L.clc_upload(self._h, dptr(records), C.c_size_t(records.shape[0])), "clc_upload")
+
+    def upload_device(self, device_ptr: int, n: int):
+        """records already in HBM as an [n,8] float64 AoS array (e.g. torch tensor .data_ptr())."""
+        check(self._L.clc_upload_device(self._h, C.c_void_p(device_ptr), C.c_size_t(n)), "clc_upload_device")
+
+    @property
+    def num_observations(self) -> int:
+        return int(self._L.clc_num_observations(self._h))
+
+    # ---- plug-in level ----
+    def factor_evaluate(self, pose: np.ndarray, want_jacobian: bool = True):
+        n = self.num_observations
+        r = np.empty(n)
+        j = np.empty((n, 7)) if want_jacobian else None
+        check(self._L.clc_factor_evaluate(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), dptr(r), dptr(j)),
+              "clc_factor_evaluate")
+        return r, j
+
+    def pose_plus(self, x: np.ndarray, delta: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 7)
+        delta = np.ascontiguousarray(delta, dtype=np.float64).reshape(-1, 6)
+        out = np.empty_like(x)
+        check(self._L.clc_pose_plus(self._h, dptr(x), dptr(delta), dptr(out), C.c_size_t(x.shape[0])), "clc_pose_plus")
+        return out
+
+    # ---- evaluation / solve ----
+    def eval(self, pose: np.ndarray, with_loss: bool = True, loss_scale_factor: float = 0.05, want_jacobian: bool = True):
+        """-> (cost, g[6], H[21])  (g, H None for a cost-only pass)."""
+        cost = C.c_double()
+        g = np.empty(6) if want_jacobian else None
+        H = np.empty(21) if want_jacobian else None
+        check(self._L.clc_eval(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(int(with_loss)),
+                               C.c_double(loss_scale_factor), C.byref(cost), dptr(g), dptr(H)), "clc_eval")
+        return cost.value, g, H
+
+    def solve(self, pose0: np.ndarray, options: Optional[Options] = None, trace_cap: int = 256) -> SolveResult:
+        pose = np.array(pose0, dtype=np.float64).copy()
+        s = Summary()
+        tr = (Iteration * max(trace_cap, 1))()
+        o = options or default_options()
+        check(self._L.clc_solve(self._h, C.byref(o), dptr(pose), C.byref(s), tr, C.c_int(trace_cap)), "clc_solve")
+        n = max(0, min(trace_cap, s.num_iterations + 1))
+        return SolveResult(pose, s, [tr[i] for i in range(n)])
+
+    def information(self, pose: np.ndarray):
+        """Analysis pass (src/LaseCamCalCeres.cpp:316-381) -> (H[6,6], b[6], chi2, sv[6], V[6,6], n_null)."""
+        H = np.empty(36); b = np.empty(6); chi = C.c_double(); sv = np.empty(6); V = np.empty(36); nn = C.c_int()
+        check(self._L.clc_information(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), dptr(H), dptr(b),
+                                      C.byref(chi), dptr(sv), dptr(V), C.byref(nn)), "clc_information")
+        return H.reshape(6, 6), b, chi.value, sv, V.reshape(6, 6), nn.value
+
+    def closed_form(self):
+        """CamLaserCalClosedSolution on the uploaded records -> (Tlc[4,4], unobservable, sv9)."""
+        T = np.empty(16); un = C.c_int(); sv = np.empty(9)
+        check(self._L.clc_closed_form(self._h, dptr(T), C.byref(un), dptr(sv)), "clc_closed_form")
+        return T.reshape(4, 4), bool(un.value), sv
+
+    # ---- batched ----
+    def upload_batched(self, records: np.ndarray, offsets: np.ndarray):
+        records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        check(self._L.clc_upload_batched(self._h, dptr(records), iptr(offsets), C.c_size_t(len(offsets) - 1)),
+              "clc_upload_batched")
+
+    @property
+    def num_problems(self) -> int:
+        return int(self._L.clc_num_problems(self._h))
+
+    def solve_batched(self, poses0: np.ndarray, options: Optional[Options] = None):
+        """-> (poses[P,7], summaries[P])"""
+        P = self.num_problems
+        poses = np.ascontiguousarray(np.array(poses0, dtype=np.float64).reshape(P, 7)).copy()
+        sm = (Summary * P)()
+        o = options or default_options()
+        check(self._L.clc_solve_batched(self._h, C.byref(o), dptr(poses), sm), "clc_solve_batched")
+        return poses, sm
+
+    # ---- test / profiling hooks ----
+    def debug_wave_reduce(self, lanes: np.ndarray, reduce_mode: int) -> np.ndarray:
+        lanes = np.ascontiguousarray(lanes, dtype=np.float64).reshape(64, 28)
+        out = np.empty(28)
+        check(self._L.clc_debug_wave_reduce(self._h, dptr(lanes), dptr(out), C.c_int(reduce_mode)), "clc_debug_wave_reduce")
+        return out
+
+    def time_eval(self, pose: np.ndarray, reps: int = 20, with_loss: bool = True, loss_scale_factor: float = 0.05,
+                  with_jacobian: bool = True) -> float:
+        """Mean duration [ms] of `reps` back-to-back evaluation-kernel launches (HIP events on the
+        handle's stream)."""
+        ms = C.c_double()
+        check(self._L.clc_time_eval(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(int(with_loss)),
+                                    C.c_double(loss_scale_factor), C.c_int(int(with_jacobian)), C.c_int(reps), C.byref(ms)),
+              "clc_time_eval")
+        return ms.value

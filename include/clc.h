@@ -1,0 +1,209 @@
+/* =====================================================================================
+ * clc.h — C-ABI of the MI355X-native point-to-plane extrinsic solver ("clc" = Cam-Laser
+ * Calibration).  This is the drop-in boundary: host code (the C++ adapter in
+ * include/LaseCamCalCeres.h, the Python mirror in camlasercalibratool_amd/) calls these
+ * entry points; everything behind them is hand-written HIP for gfx950.
+ *
+ * Plain pointers and sizes only; no exceptions cross this boundary; every function returns
+ * an int status (CLC_OK == 0, negative on error — the reference itself has no error
+ * codes).  All arithmetic is IEEE FP64.  Host pointers unless a parameter
+ * says "device".  Calls on one handle are blocking and must not overlap; different
+ * handles are independent (one HIP stream per handle).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference root, MegviiRobot/CamLaserCalibraTool).
+ * ===================================================================================== */
+#ifndef CLC_H_
+#define CLC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLC_VERSION 100
+
+/* status codes */
+#define CLC_OK 0
+#define CLC_ERR_INVALID_ARG (-1)
+#define CLC_ERR_HIP (-2)        /* HIP runtime / launch failure: see clc_last_error()        */
+#define CLC_ERR_NONFINITE (-3)  /* non-finite input pose or evaluation                      */
+#define CLC_ERR_EMPTY_SCAN (-4) /* boundary mode on an empty `points` (reference throws
+                                   std::out_of_range at src/LaseCamCalCeres.cpp:278)         */
+#define CLC_ERR_NO_DATA (-5)    /* solve/eval before upload                                 */
+#define CLC_ERR_LINALG (-6)     /* 9x9 closed-form solve failed (rank deficient)             */
+#define CLC_ERR_NO_DEVICE (-7)  /* no gfx950 device / HIP runtime unavailable                */
+
+/* termination codes of clc_summary.termination (ceres::TerminationType + which test) */
+#define CLC_RUNNING 0
+#define CLC_CONVERGENCE_GRADIENT 1
+#define CLC_CONVERGENCE_PARAMETER 2
+#define CLC_CONVERGENCE_FUNCTION 3
+#define CLC_CONVERGENCE_RADIUS 4
+#define CLC_NO_CONVERGENCE 5
+#define CLC_FAILURE 6
+
+typedef struct clc_handle clc_handle;
+
+/* One residual block, exactly the state a PointInPlaneFactor + its CauchyLoss hold
+ * (src/LaseCamCalCeres.cpp:19-21,249): 8 doubles = 64 bytes, the unit of algorithmic
+ * traffic.  The observation array handed to clc_upload is an array of
+ * these. */
+typedef struct clc_observation {
+  double n[3];  /* plane normal in the camera frame (planar_.head(3))                        */
+  double d;     /* plane offset (planar_[3])                                                */
+  double p[3];  /* laser point in the laser frame (point_)                                  */
+  double scale; /* 1/sqrt(points in this scan) (scale_, :239-240); loss a = 0.05*scale       */
+} clc_observation;
+
+/* Solver options.  Defaults (clc_options_default) = what the reference runs:
+ * src/LaseCamCalCeres.cpp:302-304 (DENSE_QR, 100 iterations) + Ceres defaults + the
+ * hard-coded Cauchy loss of :212,:249. */
+typedef struct clc_options {
+  int32_t max_num_iterations;                /* 100                                          */
+  int32_t max_num_consecutive_invalid_steps; /* 5                                            */
+  int32_t jacobi_scaling;                    /* 1                                            */
+  int32_t use_loss;                          /* 1  (#define LOSSFUNCTION)                    */
+  double loss_scale_factor;                  /* 0.05  -> CauchyLoss(0.05*scale)              */
+  double initial_trust_region_radius;        /* 1e4                                          */
+  double max_trust_region_radius;            /* 1e16                                         */
+  double min_trust_region_radius;            /* 1e-32                                        */
+  double min_relative_decrease;              /* 1e-3                                         */
+  double min_lm_diagonal;                    /* 1e-6                                         */
+  double max_lm_diagonal;                    /* 1e32                                         */
+  double function_tolerance;                 /* 1e-6                                         */
+  double gradient_tolerance;                 /* 1e-10                                        */
+  double parameter_tolerance;                /* 1e-8                                         */
+  /* execution knobs (no effect on results beyond reduction order) */
+  int32_t sync_interval;  /* LM iterations enqueued between host checks of the device-side
+                             termination flag; 0 = library default                           */
+  int32_t profile_events; /* 1: bracket every evaluation-kernel launch with HIP events on the
+                             handle's stream and report them in clc_summary                  */
+} clc_options;
+
+/* ceres::IterationSummary subset, one per recorded iteration (iteration 0 = initial
+ * evaluation).  Replaces summary.FullReport() (src/LaseCamCalCeres.cpp:309). */
+typedef struct clc_iteration {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t pad_;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+} clc_iteration;
+
+typedef struct clc_summary {
+  int32_t termination;            /* CLC_CONVERGENCE_* / CLC_NO_CONVERGENCE / CLC_FAILURE    */
+  int32_t num_iterations;         /* recorded iterations - 1                                 */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int64_t num_evaluations;        /* fused residual+Jacobian passes over the observations    */
+  double initial_cost;
+  double final_cost;
+  double solve_ms;                /* host wall time of the call                              */
+  double eval_kernel_ms;          /* sum of evaluation-kernel durations (profile_events=1)   */
+  int64_t eval_kernel_launches;   /* number of launches summed in eval_kernel_ms             */
+} clc_summary;
+
+/* ---- library ------------------------------------------------------------------------ */
+int clc_version(void);
+/* Last error text of the calling thread ("" if none). */
+const char* clc_last_error(void);
+void clc_options_default(clc_options* opt);
+
+/* ---- handle ------------------------------------------------------------------------- */
+/* Creates a solver context on HIP device `device` (one stream, scratch buffers). */
+int clc_create(clc_handle** out, int device);
+void clc_destroy(clc_handle* h);
+/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the handle's own stream. */
+int clc_set_stream(clc_handle* h, void* hip_stream);
+/* Geometry of the evaluation launch (blocks of 256 threads); 0 = library default. */
+int clc_set_launch(clc_handle* h, int grid_blocks, int reduce_mode);
+
+/* ---- problem assembly (host) --------------------------------------------------------
+ * Replaces the residual-block construction loop of CamLaserCalibration,
+ * src/LaseCamCalCeres.cpp:222-295 (plane per pose :227-231, scale :239-240, board-edge
+ * terms :258-294 with pi_from_ppp src/utilities.cpp:267-272).  Input is the flattened
+ * std::vector<Oberserve> (include/LaseCamCalCeres.h:11-24): tag_q[n_poses*4] as (w,x,y,z),
+ * tag_t[n_poses*3], CSR offsets/points for `points` and `points_on_line`.
+ * records == NULL only counts.  *n_records receives N. */
+int clc_flatten_observations(int n_poses, const double* tag_q_wxyz, const double* tag_t,
+                             const int64_t* pts_off, const double* pts,
+                             const int64_t* ptl_off, const double* ptl,
+                             int use_linefitting_data, int use_boundary_constraint,
+                             clc_observation* records, int64_t* n_records);
+
+/* ---- observation array --------------------------------------------------------------
+ * Copies N records to the device and re-tiles them for coalesced 16-byte loads.  Stays
+ * resident until the next upload/destroy.  `clc_upload_device` takes a DEVICE pointer to
+ * the same AoS layout (e.g. a torch tensor's data_ptr()). */
+int clc_upload(clc_handle* h, const clc_observation* records, size_t n);
+int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t n);
+size_t clc_num_observations(const clc_handle* h);
+
+/* ---- plug-in level math (element-wise parity) ---------------------------------------
+ * PointInPlaneFactor::Evaluate for every uploaded record at `pose` (src/LaseCamCalCeres.cpp
+ * :43-66): residuals[N] (raw, before the loss) and, if non-NULL, jacobians[N*7] row-major
+ * 1x7 rows exactly as the factor writes them (7th column zero, :60). */
+int clc_factor_evaluate(clc_handle* h, const double pose[7], double* residuals,
+                        double* jacobians);
+/* PoseLocalParameterization::Plus, batched on the device
+ * (src/pose_local_parameterization.cpp:15-31): x[n*7], delta[n*6] -> x_plus_delta[n*7]. */
+int clc_pose_plus(clc_handle* h, const double* x, const double* delta, double* x_plus_delta,
+                  size_t n);
+/* PoseLocalParameterization::ComputeJacobian: 7x6 row-major [I6;0] (cpp:33-40). */
+int clc_pose_plus_jacobian(const double x[7], double jacobian[42]);
+
+/* ---- one evaluation pass --------------------------------------------------------------
+ * What Ceres' evaluator + loss corrector produce per evaluation, reduced to the normal
+ * equation: cost = 1/2 sum rho, g[6] = J~^T r~, H[21] = upper triangle of J~^T J~
+ * (row-major: 00 01 .. 05 11 ..).  with_loss=0 drops the Cauchy loss (analysis pass,
+ * src/LaseCamCalCeres.cpp:316-362).  g/H may be NULL (cost-only pass). */
+int clc_eval(clc_handle* h, const double pose[7], int with_loss, double loss_scale_factor,
+             double* cost, double g[6], double H[21]);
+
+/* ---- the solve ------------------------------------------------------------------------
+ * Replaces ceres::Solve on the problem built by CamLaserCalibration
+ * (src/LaseCamCalCeres.cpp:299-307): Levenberg-Marquardt trust region with Jacobi scaling
+ * on the uploaded observations, SE(3) local parameterisation, Cauchy loss; runs entirely
+ * on the device.  pose is in/out = [tx,ty,tz,qx,qy,qz,qw] (:219, :311-314).
+ * trace (nullable) receives up to trace_cap iteration records. */
+int clc_solve(clc_handle* h, const clc_options* opt, double pose[7], clc_summary* summary,
+              clc_iteration* trace, int trace_cap);
+
+/* ---- post-solve analysis ---------------------------------------------------------------
+ * src/LaseCamCalCeres.cpp:316-381: un-robustified H = sum J^T J (6x6 row-major),
+ * b = -sum J^T r, chi2 = sum r^2, singular values of H (descending), V (columns), and the
+ * count of singular values < 1e-8 (null-space dimension).  The caller uploads the point
+ * residuals only (the reference skips the board-edge terms here). */
+int clc_information(clc_handle* h, const double pose[7], double H[36], double b[6],
+                    double* chi2, double sv[6], double V[36], int* n_null);
+
+/* ---- closed-form initialiser ------------------------------------------------------------
+ * CamLaserCalClosedSolution, src/LaseCamCalCeres.cpp:112-203, on the uploaded
+ * points_on_line records (uses n, d, p.x, p.y only, :147): device reduction of the 9x9
+ * normal equation, host 9x9 solve + nearest-rotation projection.  Tlc[16] row-major 4x4;
+ * *unobservable = 1 if any singular value of A^T A < 1e-10 (:164-171); sv9 nullable. */
+int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9[9]);
+
+/* ---- batched independent problems ---------------------------------------------------------
+ * P independent T_cl problems (own observations, own pose, own LM state), problem k owning
+ * records [offsets[k], offsets[k+1]).  One workgroup per problem runs the whole LM loop on
+ * the device.  poses[P*7] in/out, summaries[P]. */
+int clc_upload_batched(clc_handle* h, const clc_observation* records, const int64_t* offsets,
+                       size_t n_problems);
+int clc_solve_batched(clc_handle* h, const clc_options* opt, double* poses,
+                      clc_summary* summaries);
+size_t clc_num_problems(const clc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLC_H_ */

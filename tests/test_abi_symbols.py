@@ -1,0 +1,66 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/clc.h declares, and
+refuses to compute without a device (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import camlasercalibratool_amd as clc
+from camlasercalibratool_amd import _build, _capi, simdata as sd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "clc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(clc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_capi.EXPORTED)
+    L = _capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/clc.h but not exported"
+    assert L.clc_version() == 100
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(_capi.Options) == 4 * 4 + 10 * 8 + 2 * 4
+    assert C.sizeof(_capi.Iteration) == 16 + 6 * 8
+    assert C.sizeof(_capi.Summary) == 16 + 8 + 4 * 8 + 8
+
+
+def test_host_side_flatten_needs_no_gpu_and_matches_oracle(oracle_mod):
+    S = sd.sim_board_edges(3, 5, 12)
+    for lf, bd in [(False, False), (True, False), (True, True)]:
+        assert np.array_equal(clc.flatten_observations(S, lf, bd), oracle_mod.flatten(S, lf, bd))
+    S.pts_off[:] = 0
+    with pytest.raises(clc.ClcError) as e:
+        clc.flatten_observations(S, True, True)
+    assert e.value.code == -4  # reference: std::out_of_range at LaseCamCalCeres.cpp:278
+
+
+def test_pose_plus_jacobian_constant():
+    import ctypes as C
+    J = np.empty(42)
+    assert _capi.lib().clc_pose_plus_jacobian(None, _capi.dptr(J)) == 0
+    assert np.array_equal(J.reshape(7, 6), np.vstack([np.eye(6), np.zeros((1, 6))]))
+
+
+def test_no_cpu_fallback():
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(clc.ClcError) as e:
+        clc.Solver()
+    assert e.value.code == -7
+
+
+def test_extension_is_in_tree_and_current():
+    assert os.path.dirname(_build.LIB_PATH).endswith(os.path.join("camlasercalibratool_amd", "csrc"))
+    assert os.path.exists(_build.LIB_PATH)

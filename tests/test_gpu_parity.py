@@ -1,0 +1,308 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI,
+against the CPU oracle on identical seeded inputs.
+
+Tolerances (BASELINE.json north_star): recovered T_cl within 1e-6 max-abs on the 4x4, final
+cost within 1e-8, both against the oracle's DENSE_QR Ceres restatement.  Reductions are
+compared at 1e-11 relative (FP64 sums of up to 1e6 terms in a different association order)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import camlasercalibratool_amd as clc
+from camlasercalibratool_amd import _capi, simdata as sd
+
+pytestmark = pytest.mark.gpu
+
+X0 = sd.pose7_from_T(np.eye(4))  # calibr_simulation.cpp:126-129
+T_TOL = 1e-6
+COST_TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def sv():
+    s = clc.Solver(0)
+    yield s
+    s.close()
+
+
+def _rand_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return np.concatenate([rng.normal(size=3), q])
+
+
+def _mirror(oracle_mod, o):
+    oo = oracle_mod.default_options()
+    for f, _ in oo._fields_:
+        setattr(oo, f, getattr(o, f))
+    return oo
+
+
+def _dT(a, b):
+    return np.abs(sd.T_from_pose7(a) - sd.T_from_pose7(b)).max()
+
+
+# ---------------------------------------------------------------------------------------
+def test_extension_loaded_is_the_in_tree_hip_library(sv):
+    name, cus = sv.device_info()
+    assert "gfx950" in name, name
+    assert cus >= 64
+    maps = open("/proc/self/maps").read()
+    assert "camlasercalibratool_amd/csrc/libclc_hip.so" in maps
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_wave_reduction_exact_on_integers(sv, mode):
+    """Butterfly (permlane32/16 swap + DPP) and shuffle reductions are exact on integer-valued
+    data, whatever the association order."""
+    rng = np.random.default_rng(0)
+    lanes = rng.integers(-1000, 1000, size=(64, 28)).astype(np.float64)
+    lanes[5, 3] = 2.0 ** 40  # asymmetric spike: catches a lane/column permutation
+    out = sv.debug_wave_reduce(lanes, mode)
+    assert np.array_equal(out, lanes.sum(axis=0))
+
+
+def test_factor_evaluate_elementwise(sv, oracle_mod):
+    """PointInPlaneFactor::Evaluate, record by record (LaseCamCalCeres.cpp:43-66)."""
+    rng = np.random.default_rng(1)
+    S = sd.GenerateSimData(2, n_poses=12, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    for _ in range(3):
+        pose = _rand_pose(rng)
+        r, J = sv.factor_evaluate(pose)
+        r0, J0 = oracle_mod.factor_evaluate_batch(rec, pose)
+        assert np.abs(r - r0).max() <= 1e-14 * max(1.0, np.abs(r0).max())
+        assert np.abs(J - J0).max() <= 1e-14 * max(1.0, np.abs(J0).max())
+        assert np.all(J[:, 6] == 0.0)
+    r, J = sv.factor_evaluate(pose, want_jacobian=False)
+    assert J is None and np.abs(r - r0).max() < 1e-13
+
+
+def test_pose_plus_on_device(sv, oracle_mod):
+    rng = np.random.default_rng(2)
+    x = np.stack([_rand_pose(rng) for _ in range(300)])
+    d = rng.normal(size=(300, 6)) * 0.3
+    d[0] = 0.0
+    out = sv.pose_plus(x, d)
+    ref = np.stack([oracle_mod.pose_plus(x[i], d[i]) for i in range(300)])
+    assert np.abs(out - ref).max() < 4e-16
+    assert np.allclose(np.linalg.norm(out[:, 3:], axis=1), 1.0, atol=1e-15)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 127, 128, 129, 1000, 5317, 65536 + 77])
+@pytest.mark.parametrize("with_loss", [True, False])
+def test_eval_reduction_matches_oracle_ragged_sizes(sv, oracle_mod, n, with_loss):
+    """cost, g, H of one pass for ragged N (partial tiles, fewer tiles than waves)."""
+    rng = np.random.default_rng(n)
+    S = sd.sim_fixed_count(n % 97, n_poses=max(1, (n + 499) // 500), pts_per_pose=500, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)[:n].copy()
+    sv.upload(rec)
+    assert sv.num_observations == n
+    pose = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)) if n % 2 else X0
+    pose = oracle_mod.pose_plus(pose, rng.normal(size=6) * 0.05)
+    for mode in (0, 1):
+        sv.set_launch(0, mode)
+        c, g, H = sv.eval(pose, with_loss=with_loss)
+        c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
+        assert abs(c - c0) <= 1e-11 * abs(c0) + 1e-300
+        assert np.abs(g - g0).max() <= 1e-11 * np.abs(g0).max() + 1e-18
+        assert np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
+    sv.set_launch(0, 0)
+    c1, _, _ = sv.eval(pose, with_loss=with_loss, want_jacobian=False)  # cost-only variant
+    assert abs(c1 - c0) <= 1e-11 * abs(c0) + 1e-300
+
+
+def test_eval_is_bitwise_reproducible_and_grid_invariant_to_rounding(sv, oracle_mod):
+    S = sd.sim_fixed_count(5, 200, 500, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    a = sv.eval(X0)
+    b = sv.eval(X0)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])  # fixed-shape reduction
+    sv.set_launch(64, 0)
+    c = sv.eval(X0)
+    sv.set_launch(0, 0)
+    assert abs(c[0] - a[0]) <= 1e-12 * abs(a[0]) and np.allclose(c[2], a[2], rtol=1e-12)
+
+
+def test_eval_empty_and_errors(sv):
+    with pytest.raises(clc.ClcError) as e:
+        sv.eval(np.array([0, 0, 0, 0, 0, 0, np.nan]))
+    assert e.value.code == -3
+    sv.upload(np.zeros((0, 8)))
+    c, g, H = sv.eval(X0)
+    assert c == 0.0 and not g.any() and not H.any()
+    fresh = clc.Solver(0)
+    with pytest.raises(clc.ClcError) as e:
+        fresh.eval(X0)
+    assert e.value.code == -5
+    fresh.close()
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(4))
+def test_c1_noise_free_sim_recovers_ground_truth(sv, oracle_mod, seed):
+    """configs[0]: simulation_lasercamcal_node default, Tcl = I start, (linefit=false)."""
+    S = sd.GenerateSimData(seed)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    res = sv.solve(X0)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    Tlc = np.linalg.inv(sd.T_from_pose7(res.pose))
+    assert np.abs(Tlc[:3, :3] - sd.GT_RLC).max() < 1e-7 and np.abs(Tlc[:3, 3] - sd.GT_TLC).max() < 1e-7
+    assert _dT(res.pose, ref.pose) <= T_TOL
+    assert abs(res.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert res.summary.termination in (1, 2, 3)
+
+
+@pytest.mark.parametrize("noise,seed", [(0.01, 1), (0.01, 7), (0.03, 2), (0.03, 9)])
+def test_c1_noisy_solve_matches_oracle_trace(sv, oracle_mod, noise, seed):
+    S = sd.GenerateSimData(seed, noise_sigma=noise)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    res = sv.solve(X0)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    assert _dT(res.pose, ref.pose) <= T_TOL
+    assert abs(res.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert res.summary.termination == ref.summary.termination
+    assert res.summary.num_iterations == ref.summary.num_iterations
+    assert len(res.trace) == len(ref.trace)
+    for a, b in zip(res.trace, ref.trace):
+        assert a.iteration == b.iteration and a.step_is_successful == b.step_is_successful
+        assert a.cost == pytest.approx(b.cost, rel=1e-9, abs=1e-14)
+        assert a.trust_region_radius == pytest.approx(b.trust_region_radius, rel=1e-7)
+    # in/out semantics: restarting from the answer stays there
+    again = sv.solve(res.pose)
+    assert again.summary.num_iterations <= 2 and _dT(again.pose, res.pose) < 1e-5
+
+
+def test_solver_options_are_honoured(sv, oracle_mod):
+    S = sd.GenerateSimData(3, noise_sigma=0.02)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    for kw in [dict(max_num_iterations=3), dict(use_loss=0), dict(jacobi_scaling=0),
+               dict(initial_trust_region_radius=1e12, max_num_iterations=40), dict(sync_interval=1),
+               dict(sync_interval=7), dict(function_tolerance=1e-12, parameter_tolerance=1e-12)]:
+        o = clc.default_options()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        res = sv.solve(X0, o)
+        ref = oracle_mod.solve(rec, X0, options=_mirror(oracle_mod, o), linear_solver="qr")
+        assert res.summary.termination == ref.summary.termination, kw
+        assert res.summary.num_iterations == ref.summary.num_iterations, kw
+        assert _dT(res.pose, ref.pose) <= T_TOL and abs(res.summary.final_cost - ref.summary.final_cost) <= COST_TOL, kw
+    o = clc.default_options()
+    o.profile_events = 1
+    res = sv.solve(X0, o)
+    assert res.summary.eval_kernel_launches == res.summary.num_evaluations and res.summary.eval_kernel_ms > 0
+
+
+def test_c5_boundary_constraint_mixed_terms(sv, oracle_mod):
+    """configs[4] (reduced): board-edge residuals (LaseCamCalCeres.cpp:258-294) mixed with the
+    point residuals, same record type, same kernel."""
+    S = sd.sim_board_edges(11, n_poses=60, pts_per_pose=40, noise_sigma=0.002)
+    rec = clc.flatten_observations(S, True, True)
+    assert rec.shape[0] == 60 * 42
+    sv.upload(rec)
+    Tcl_gt = sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)
+    x0 = oracle_mod.pose_plus(sd.pose7_from_T(Tcl_gt), np.array([0.05, -0.04, 0.03, 0.05, -0.06, 0.04]))
+    res = sv.solve(x0)
+    ref = oracle_mod.solve(rec, x0, linear_solver="qr")
+    assert _dT(res.pose, ref.pose) <= T_TOL
+    assert abs(res.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert res.summary.num_iterations == ref.summary.num_iterations
+    assert _dT(res.pose, sd.pose7_from_T(Tcl_gt)) < 5e-2
+
+
+def test_information_and_closed_form(sv, oracle_mod):
+    S = sd.GenerateSimData(4, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, True)
+    sv.upload(rec)
+    T, unobs, sv9 = sv.closed_form()
+    T0, unobs0, sv90 = oracle_mod.closed_form(rec)
+    assert unobs == unobs0 and np.abs(T - T0).max() < 1e-9 and np.allclose(sv9, sv90, rtol=1e-9)
+    pose = sd.pose7_from_T(np.linalg.inv(T))
+    H, b, chi2, s6, V, nn = sv.information(pose)
+    H0, b0, chi0, s60, V0, nn0 = oracle_mod.information(rec, pose)
+    assert np.allclose(H, H0, rtol=1e-11) and np.allclose(b, b0, rtol=1e-9, atol=1e-14)
+    assert abs(chi2 - chi0) <= 1e-11 * chi0 and np.allclose(s6, s60, rtol=1e-9) and nn == nn0 == 0
+    # noise-free closed form is exact
+    rec = clc.flatten_observations(sd.GenerateSimData(4), True)
+    sv.upload(rec)
+    T, unobs, _ = sv.closed_form()
+    assert not unobs and np.abs(T[:3, :3] - sd.GT_RLC).max() < 1e-9 and np.abs(T[:3, 3] - sd.GT_TLC).max() < 1e-9
+
+
+def test_reference_call_surface_end_to_end(oracle_mod, capsys):
+    """calibr_offline.cpp:166-170 flow: closed form -> invert -> CamLaserCalibration(obs,Tcl,false)."""
+    obs = sd.GenerateSimData(8, noise_sigma=0.01).to_list()  # std::vector<Oberserve>
+    Tlc = np.eye(4)
+    clc.CamLaserCalClosedSolution(obs, Tlc)
+    Tcl = np.linalg.inv(Tlc)
+    rep = clc.CamLaserCalibration(obs, Tcl, False)
+    out = capsys.readouterr().out
+    assert "Closed-form solution Tlc" in out and "H singular values" in out and "recover chi2" in out
+    S = sd.ObservationSet.from_list(obs)
+    rec = oracle_mod.flatten(S, False, False)
+    ref = oracle_mod.solve(rec, sd.pose7_from_T(np.linalg.inv(oracle_mod.closed_form(oracle_mod.flatten(S, True, False))[0])))
+    assert np.abs(Tcl - sd.T_from_pose7(ref.pose)).max() <= T_TOL
+    assert abs(rep.result.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert rep.null_space.shape == (6, 0)
+    Tlc_est = np.linalg.inv(Tcl)
+    assert np.abs(Tlc_est[:3, 3] - sd.GT_TLC).max() < 0.02
+
+
+# ---------------------------------------------------------------------------------------
+def test_c3_batched_problems_match_oracle(sv, oracle_mod):
+    """configs[2] (reduced): independent T_cl problems, each with its own ground truth."""
+    probs, gts = sd.sim_batch(21, n_problems=24, n_poses=12, pts_per_pose=97, noise_sigma=0.01)
+    recs = [clc.flatten_observations(p, False) for p in probs]
+    recs[3] = recs[3][:130]   # ragged sizes
+    recs[7] = recs[7][:1]
+    off = np.zeros(len(recs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([r.shape[0] for r in recs])
+    sv.upload_batched(np.concatenate(recs), off)
+    assert sv.num_problems == 24
+    x0 = np.stack([oracle_mod.pose_plus(sd.pose7_from_T(g), np.array([0.1, -0.1, 0.1, 0.1, -0.1, 0.05])) for g in gts])
+    poses, sms = sv.solve_batched(x0)
+    for k in range(24):
+        ref = oracle_mod.solve(recs[k], x0[k], linear_solver="qr")
+        assert sms[k].termination == ref.summary.termination, k
+        assert sms[k].num_iterations == ref.summary.num_iterations, k
+        assert _dT(poses[k], ref.pose) <= T_TOL, k
+        assert abs(sms[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
+        if k not in (3, 7):
+            assert _dT(poses[k], sd.pose7_from_T(gts[k])) < 0.05
+
+
+def test_c2_full_size_properties_and_parity(sv, oracle_mod):
+    """configs[1]: single T_cl, 10^6 observations (2000 poses x 500 points)."""
+    S = sd.sim_fixed_count(2024, 2000, 500, noise_sigma=0.0)
+    rec = clc.flatten_observations(S, False)
+    assert rec.shape == (1_000_000, 8)
+    sv.upload(rec)
+    # linearity of the reduction: eval(all) == eval(first half) + eval(second half)
+    c, g, H = sv.eval(X0)
+    sv.upload(rec[:500_000]); c1, g1, H1 = sv.eval(X0)
+    sv.upload(rec[500_000:]); c2, g2, H2 = sv.eval(X0)
+    assert abs(c - (c1 + c2)) <= 1e-12 * c and np.allclose(H, H1 + H2, rtol=1e-12) and np.allclose(g, g1 + g2, rtol=1e-10, atol=1e-12)
+    # noise-free: unique zero-cost minimum at the ground truth (the reference's known answer)
+    sv.upload(rec)
+    res = sv.solve(X0)
+    Tlc = np.linalg.inv(sd.T_from_pose7(res.pose))
+    assert np.abs(Tlc[:3, :3] - sd.GT_RLC).max() < 1e-7 and np.abs(Tlc[:3, 3] - sd.GT_TLC).max() < 1e-7
+    assert res.summary.final_cost < 1e-10
+    # noisy: parity with the oracle's DENSE_QR solve at full size
+    S = sd.sim_fixed_count(2025, 2000, 500, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    res = sv.solve(X0)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    assert _dT(res.pose, ref.pose) <= T_TOL
+    assert abs(res.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert res.summary.num_iterations == ref.summary.num_iterations
+    # idempotence: solving again from the solution does not move it
+    again = sv.solve(res.pose)
+    assert _dT(again.pose, res.pose) < 1e-5

@@ -1,0 +1,135 @@
+"""The product's LM controller (csrc/clc_lm.hpp — the code lm_kernel runs on the GPU) compiled
+for the host and driven with oracle evaluations: its iteration trace must reproduce the
+oracle's Ceres restatement.  Host-logic test; runs without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from camlasercalibratool_amd import _capi, simdata as sd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+X0 = sd.pose7_from_T(np.eye(4))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    src = os.path.join(HERE, "shim", "lm_shim.cpp")
+    out = os.path.join(HERE, "shim", "liblm_shim.so")
+    deps = [src] + [os.path.join(HERE, "..", "camlasercalibratool_amd", "csrc", f) for f in ("clc_lm.hpp", "clc_math.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", out])
+    return C.CDLL(out)
+
+
+EVAL_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def _solve_with_controller(shim, oracle_mod, rec, opt, x0, cap=300):
+    calls = []
+
+    def ev(pose, cost, g, H):
+        p = np.array([pose[i] for i in range(7)])
+        c, gg, HH = oracle_mod.evaluate_ne(rec, p, with_loss=bool(opt.use_loss), loss_factor=opt.loss_scale_factor)
+        calls.append(p)
+        cost[0] = c
+        for i in range(6):
+            g[i] = gg[i]
+        for i in range(21):
+            H[i] = HH[i]
+
+    pose = np.array(x0, dtype=np.float64).copy()
+    sm = _capi.Summary()
+    tr = (_capi.Iteration * cap)()
+    shim.shim_lm_solve(C.byref(opt), pose.ctypes.data_as(C.POINTER(C.c_double)), C.byref(sm), tr, C.c_int(cap), EVAL_FN(ev))
+    return pose, sm, [tr[i] for i in range(min(cap, sm.num_iterations + 1))], calls
+
+
+def _mirror_opts(oracle_mod, o):
+    oo = oracle_mod.default_options()
+    for f, _ in oo._fields_:
+        setattr(oo, f, getattr(o, f))
+    return oo
+
+
+def test_controller_options_default_match_reference():
+    o = _capi.default_options()
+    assert o.max_num_iterations == 100  # LaseCamCalCeres.cpp:304
+    assert o.loss_scale_factor == 0.05 and o.use_loss == 1  # :212,:249
+    assert (o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius) == (1e4, 1e16, 1e-32)
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+    assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
+    assert o.jacobi_scaling == 1 and o.max_num_consecutive_invalid_steps == 5
+
+
+@pytest.mark.parametrize("noise,seed", [(0.01, 1), (0.03, 2), (0.0, 3)])
+def test_controller_trace_matches_oracle(shim, oracle_mod, noise, seed):
+    rec = oracle_mod.flatten(sd.GenerateSimData(seed, noise_sigma=noise), False, False)
+    opt = _capi.default_options()
+    pose, sm, tr, calls = _solve_with_controller(shim, oracle_mod, rec, opt, X0)
+    ref = oracle_mod.solve(rec, X0, options=_mirror_opts(oracle_mod, opt), linear_solver="qr")
+    assert np.abs(sd.T_from_pose7(pose) - sd.T_from_pose7(ref.pose)).max() < 1e-9
+    assert abs(sm.final_cost - ref.summary.final_cost) < 1e-12
+    assert sm.initial_cost == pytest.approx(ref.summary.initial_cost, rel=1e-14)
+    if noise > 0:
+        assert sm.termination == ref.summary.termination
+        assert sm.num_iterations == ref.summary.num_iterations
+        assert sm.num_successful_steps == ref.summary.num_successful_steps
+        assert sm.num_unsuccessful_steps == ref.summary.num_unsuccessful_steps
+        for a, b in zip(tr, ref.trace):
+            assert a.iteration == b.iteration
+            assert a.step_is_successful == b.step_is_successful and a.step_is_valid == b.step_is_valid
+            assert a.cost == pytest.approx(b.cost, rel=1e-10, abs=1e-15)
+            assert a.trust_region_radius == pytest.approx(b.trust_region_radius, rel=1e-9)
+            assert a.step_norm == pytest.approx(b.step_norm, rel=1e-7, abs=1e-14)
+            assert a.relative_decrease == pytest.approx(b.relative_decrease, rel=1e-6, abs=1e-12)
+            assert a.gradient_max_norm == pytest.approx(b.gradient_max_norm, rel=1e-7, abs=1e-14)
+        # fused evaluation: one pass per iteration (oracle: one cost pass + one Jacobian pass per accept)
+        assert sm.num_evaluations == len(calls) == ref.summary.num_residual_evaluations - ref.summary.num_jacobian_evaluations + 1
+
+
+def test_controller_rejected_steps_and_iteration_cap(shim, oracle_mod):
+    """Small initial radius bound + low max_iterations + a start far away exercise the
+    unsuccessful-step branch and NO_CONVERGENCE."""
+    rec = oracle_mod.flatten(sd.GenerateSimData(5, noise_sigma=0.02), False, False)
+    opt = _capi.default_options()
+    opt.initial_trust_region_radius = 1e12  # huge first step -> rejections
+    opt.max_num_iterations = 40
+    far = sd.pose7_from_T(sd.tlc_to_tcl(sd.rot_zyx(2.0, -1.0, 2.5)[0], np.array([3.0, -2.0, 1.0])))
+    pose, sm, tr, _ = _solve_with_controller(shim, oracle_mod, rec, opt, far)
+    ref = oracle_mod.solve(rec, far, options=_mirror_opts(oracle_mod, opt), linear_solver="qr")
+    assert sm.termination == ref.summary.termination
+    assert sm.num_iterations == ref.summary.num_iterations
+    assert sm.num_unsuccessful_steps == ref.summary.num_unsuccessful_steps
+    assert [t.step_is_successful for t in tr] == [t.step_is_successful for t in ref.trace]
+    assert np.abs(pose - ref.pose).max() < 1e-8
+    opt.max_num_iterations = 3
+    pose, sm, tr, _ = _solve_with_controller(shim, oracle_mod, rec, opt, X0)
+    assert sm.termination == 5 and sm.num_iterations == 3
+
+
+def test_controller_no_loss_and_no_scaling(shim, oracle_mod):
+    rec = oracle_mod.flatten(sd.GenerateSimData(6, noise_sigma=0.01), False, False)
+    opt = _capi.default_options()
+    opt.use_loss = 0
+    opt.jacobi_scaling = 0
+    pose, sm, tr, _ = _solve_with_controller(shim, oracle_mod, rec, opt, X0)
+    ref = oracle_mod.solve(rec, X0, options=_mirror_opts(oracle_mod, opt), linear_solver="qr")
+    assert sm.num_iterations == ref.summary.num_iterations
+    assert np.abs(pose - ref.pose).max() < 1e-9
+    assert abs(sm.final_cost - ref.summary.final_cost) < 1e-12
+
+
+def test_shared_math_matches_oracle(shim, oracle_mod):
+    rng = np.random.default_rng(0)
+    dp = C.POINTER(C.c_double)
+    for _ in range(20):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        x = np.concatenate([rng.normal(size=3), q]); d = rng.normal(size=6) * 0.2
+        out = np.empty(7); R = np.empty(9)
+        shim.shim_pose_plus(x.ctypes.data_as(dp), d.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        assert np.abs(out - oracle_mod.pose_plus(x, d)).max() < 1e-15
+        shim.shim_quat_to_rot(x[3:].copy().ctypes.data_as(dp), R.ctypes.data_as(dp))
+        assert np.array_equal(R.reshape(3, 3), oracle_mod.quat_to_rot(x[3:]))
