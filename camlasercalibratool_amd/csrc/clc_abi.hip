@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC clc_abi.hip -o libclc_hip.so
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -41,7 +42,10 @@ bool all_finite(const double* p, int n) {
   return true;
 }
 
-constexpr int kDefaultSyncInterval = 4;
+constexpr int kDefaultSyncInterval = 4;  // batched solver: iterations between host checks
+constexpr int kDefaultLookahead = 2;
+constexpr int kDefaultLaunchFlags = 6;   // prefetch + non-temporal loads (clc::FLAG_*), tuned on MI355X
+constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
 constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
 
 }  // namespace
@@ -57,7 +61,7 @@ struct clc_handle {
   size_t n_obs = 0;
   // launch geometry
   int grid_override = 0;
-  int reduce_mode = 0;
+  int launch_flags = kDefaultLaunchFlags;
   double* d_partials = nullptr;
   int partials_cap_blocks = 0;
   // LM state
@@ -67,6 +71,8 @@ struct clc_handle {
   // scratch
   double* d_small = nullptr;
   double* h_small = nullptr;  // pinned
+  clc::HostMailbox* h_mailbox = nullptr;  // pinned, device-visible
+  clc::HostMailbox* d_mailbox = nullptr;  // device address of the same memory
   std::vector<hipEvent_t> ev;
   // batched problems
   double* d_btiles = nullptr;
@@ -89,7 +95,7 @@ namespace {
 int eval_grid(const clc_handle* h, size_t n) {
   const long long tiles = (long long)((n + clc::TILE - 1) / clc::TILE);
   long long want = (tiles + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64);  // one tile per wave
-  long long cap = h->grid_override > 0 ? h->grid_override : 2LL * h->num_cus;
+  long long cap = h->grid_override > 0 ? h->grid_override : (long long)kDefaultBlocksPerCU * h->num_cus;
   if (want < 1) want = 1;
   return (int)(want < cap ? want : cap);
 }
@@ -121,17 +127,25 @@ int ensure_events(clc_handle* h, size_t n) {
   return CLC_OK;
 }
 
+template <bool WITH_LOSS, bool WITH_JAC>
+void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t* d_status, double lf) {
+  const int fl = h->launch_flags;
+#define CLC_LAUNCH(PF, NT)                                                                              \
+  hipLaunchKernelGGL((clc::eval_kernel<WITH_LOSS, WITH_JAC, PF, NT>), dim3(grid), dim3(clc::BLOCK), 0,   \
+                     h->stream, h->d_tiles, (long long)h->n_obs, d_pose, d_status, lf, fl, h->d_partials)
+  const bool pf = (fl & clc::FLAG_PREFETCH) != 0, nt = (fl & clc::FLAG_NONTEMPORAL) != 0;
+  if (pf && nt) CLC_LAUNCH(true, true);
+  else if (pf) CLC_LAUNCH(true, false);
+  else if (nt) CLC_LAUNCH(false, true);
+  else CLC_LAUNCH(false, false);
+#undef CLC_LAUNCH
+}
+
 template <bool WITH_JAC>
 void launch_eval(clc_handle* h, int grid, bool with_loss, const double* d_pose,
                  const int32_t* d_status, double lf) {
-  if (with_loss)
-    hipLaunchKernelGGL((clc::eval_kernel<true, WITH_JAC>), dim3(grid), dim3(clc::BLOCK), 0, h->stream,
-                       h->d_tiles, (long long)h->n_obs, d_pose, d_status, lf, h->reduce_mode,
-                       h->d_partials);
-  else
-    hipLaunchKernelGGL((clc::eval_kernel<false, WITH_JAC>), dim3(grid), dim3(clc::BLOCK), 0, h->stream,
-                       h->d_tiles, (long long)h->n_obs, d_pose, d_status, lf, h->reduce_mode,
-                       h->d_partials);
+  if (with_loss) launch_eval_v<true, WITH_JAC>(h, grid, d_pose, d_status, lf);
+  else launch_eval_v<false, WITH_JAC>(h, grid, d_pose, d_status, lf);
 }
 
 int retile_into(clc_handle* h, const double* d_aos, size_t n, double** d_tiles, size_t* cap_bytes) {
@@ -202,6 +216,9 @@ int clc_create(clc_handle** out, int device) {
   CLC_HIP(hipMalloc(&h->d_small, sizeof(double) * kSmallDoubles));
   CLC_HIP(hipHostMalloc(&h->h_small, sizeof(double) * kSmallDoubles, hipHostMallocDefault));
   CLC_HIP(hipMalloc(&h->d_queue, sizeof(unsigned int)));
+  CLC_HIP(hipHostMalloc(&h->h_mailbox, sizeof(clc::HostMailbox), hipHostMallocCoherent | hipHostMallocMapped));
+  CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mailbox), h->h_mailbox, 0));
+  std::memset(h->h_mailbox, 0, sizeof(clc::HostMailbox));
   *out = h;
   return CLC_OK;
 }
@@ -217,6 +234,7 @@ void clc_destroy(clc_handle* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->h_mailbox) (void)hipHostFree(h->h_mailbox);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -227,11 +245,11 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
   return CLC_OK;
 }
 
-int clc_set_launch(clc_handle* h, int grid_blocks, int reduce_mode) {
-  if (!h || grid_blocks < 0 || reduce_mode < 0 || reduce_mode > 1)
+int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 7)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
-  h->reduce_mode = reduce_mode;
+  h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
   return CLC_OK;
 }
 
@@ -338,6 +356,7 @@ int clc_eval(clc_handle* h, const double pose[7], int with_loss, double loss_sca
   if (!h || !pose || !cost) return fail(CLC_ERR_INVALID_ARG, "clc_eval: bad argument");
   if (!h->d_tiles) return fail(CLC_ERR_NO_DATA, "clc_eval: no observations uploaded");
   if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_eval: non-finite pose");
+  if (with_loss && !(loss_scale_factor > 0.0)) return fail(CLC_ERR_INVALID_ARG, "clc_eval: loss_scale_factor must be > 0");
   CLC_HIP(hipSetDevice(h->device));
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
@@ -351,7 +370,7 @@ int clc_eval(clc_handle* h, const double pose[7], int with_loss, double loss_sca
     launch_eval<false>(h, grid, with_loss != 0, h->d_small, nullptr, loss_scale_factor);
   CLC_HIP(hipGetLastError());
   hipLaunchKernelGGL(clc::reduce_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
-                     h->d_small + 16);
+                     with_loss, loss_scale_factor, h->d_small + 16);
   CLC_HIP(hipGetLastError());
   CLC_HIP(hipMemcpyAsync(h->h_small + 16, h->d_small + 16, clc::NACC * sizeof(double), hipMemcpyDeviceToHost,
                          h->stream));
@@ -371,6 +390,8 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   clc_options opt;
   if (opt_in) opt = *opt_in; else clc_options_default(&opt);
   if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve: max_num_iterations < 0");
+  if (opt.use_loss && !(opt.loss_scale_factor > 0.0))
+    return fail(CLC_ERR_INVALID_ARG, "clc_solve: loss_scale_factor must be > 0");
   CLC_HIP(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
 
@@ -378,58 +399,83 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
   const int max_evals = opt.max_num_iterations + 1;
-  const int dev_trace_cap = opt.max_num_iterations + 8;
-  rc = ensure_trace(h, dev_trace_cap);
-  if (rc != CLC_OK) return rc;
+  const bool want_trace = trace != nullptr && trace_cap > 0;
+  if (want_trace) {
+    rc = ensure_trace(h, opt.max_num_iterations + 8);
+    if (rc != CLC_OK) return rc;
+  }
   if (opt.profile_events) {
     rc = ensure_events(h, 2 * (size_t)max_evals);
     if (rc != CLC_OK) return rc;
   }
-  const int sync_interval = opt.sync_interval > 0 ? opt.sync_interval : kDefaultSyncInterval;
+  // Launch-ahead depth: the host keeps this many LM iterations queued beyond the last one the
+  // device has reported done (pinned mailbox), so the stream never drains and the host never
+  // blocks; at most `lookahead` already-queued iterations turn into no-ops after termination.
+  const int lookahead = opt.sync_interval > 0 ? opt.sync_interval : kDefaultLookahead;
 
-  std::memcpy(h->h_small, pose, 7 * sizeof(double));
-  CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, h->d_small);
+  clc::HostMailbox* mb = h->h_mailbox;
+  mb->n_done = 0;
+  mb->status = CLC_RUNNING;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+
+  clc::Pose7 p0;
+  for (int i = 0; i < 7; ++i) p0.v[i] = pose[i];
+  hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, p0);
   CLC_HIP(hipGetLastError());
 
   const double* d_x_eval = reinterpret_cast<const double*>(
       reinterpret_cast<const char*>(h->d_state) + offsetof(clc::LmState, x_eval));
   const int32_t* d_status = reinterpret_cast<const int32_t*>(
       reinterpret_cast<const char*>(h->d_state) + offsetof(clc::LmState, status));
-  int32_t* h_status = reinterpret_cast<int32_t*>(h->h_small + 48);
+  clc_iteration* d_trace = want_trace ? h->d_trace : nullptr;
+  const int d_trace_cap = want_trace ? h->trace_cap : 0;
 
   int launched = 0;
-  bool done = false;
-  while (!done && launched < max_evals) {
-    if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
-    launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor);
-    if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
-    hipLaunchKernelGGL(clc::lm_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
-                       h->d_state, opt, h->d_trace, h->trace_cap);
-    ++launched;
-    if (launched % sync_interval == 0 || launched == max_evals) {
-      CLC_HIP(hipGetLastError());
-      CLC_HIP(hipMemcpyAsync(h_status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-      CLC_HIP(hipStreamSynchronize(h->stream));
-      if (*h_status != CLC_RUNNING) done = true;
+  int status = CLC_RUNNING;
+  long long spins = 0;
+  auto t_last_progress = std::chrono::steady_clock::now();
+  int last_done = 0;
+  for (;;) {
+    status = __atomic_load_n(&mb->status, __ATOMIC_ACQUIRE);
+    if (status != CLC_RUNNING) break;
+    const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
+    if (launched < max_evals && launched - done < lookahead) {
+      if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
+      launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor);
+      if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
+      hipLaunchKernelGGL(clc::lm_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
+                         h->d_state, opt, d_trace, d_trace_cap, h->d_mailbox);
+      ++launched;
+      continue;
+    }
+    // nothing to launch: wait for the device (bounded: a wedged queue must not hang the caller)
+    if (done != last_done) { last_done = done; t_last_progress = std::chrono::steady_clock::now(); spins = 0; }
+    if ((++spins & 0xFFFF) == 0) {
+      hipError_t e = hipStreamQuery(h->stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(CLC_ERR_HIP, "clc_solve: stream error", e);
+      if (e == hipSuccess) {  // queue drained: the mailbox must be final now
+        status = __atomic_load_n(&mb->status, __ATOMIC_ACQUIRE);
+        if (status != CLC_RUNNING) break;
+        if (launched >= max_evals && __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE) >= launched)
+          return fail(CLC_ERR_HIP, "clc_solve: controller did not terminate");
+      }
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last_progress).count();
+      if (waited > 30.0) return fail(CLC_ERR_HIP, "clc_solve: no progress from the device for 30 s");
     }
   }
-  // final read-back of the controller state and trace
-  clc::LmState* h_state = reinterpret_cast<clc::LmState*>(h->h_small + 256);
-  static_assert(sizeof(clc::LmState) <= (kSmallDoubles - 256) * sizeof(double), "pinned scratch too small");
-  CLC_HIP(hipMemcpyAsync(h_state, h->d_state, sizeof(clc::LmState), hipMemcpyDeviceToHost, h->stream));
-  CLC_HIP(hipStreamSynchronize(h->stream));
-  clc::lm_fill_summary(*h_state, *summary);
-  if (summary->termination == CLC_RUNNING) summary->termination = CLC_FAILURE;  // cannot happen
-  for (int i = 0; i < 7; ++i) pose[i] = h_state->x_out[i];
-  if (trace && trace_cap > 0) {
-    const int n = std::min(std::min(h_state->n_trace, trace_cap), h->trace_cap);
-    if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
-  }
+  CLC_HIP(hipGetLastError());
+  std::atomic_thread_fence(std::memory_order_acquire);
+  *summary = mb->summary;
+  for (int i = 0; i < 7; ++i) pose[i] = mb->pose[i];
   summary->eval_kernel_ms = 0.0;
   summary->eval_kernel_launches = 0;
+  if (want_trace || opt.profile_events) CLC_HIP(hipStreamSynchronize(h->stream));
+  if (want_trace) {
+    const int n = std::min(std::min(summary->num_iterations + 1, trace_cap), h->trace_cap);
+    if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
+  }
   if (opt.profile_events) {
-    const int n_real = (int)std::min<int64_t>(h_state->n_evals, launched);
+    const int n_real = (int)std::min<int64_t>(summary->num_evaluations, launched);
     double tot = 0.0;
     for (int i = 0; i < n_real; ++i) {
       float ms = 0.f;
@@ -572,6 +618,8 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   clc_options opt;
   if (opt_in) opt = *opt_in; else clc_options_default(&opt);
   if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: max_num_iterations < 0");
+  if (opt.use_loss && !(opt.loss_scale_factor > 0.0))
+    return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: loss_scale_factor must be > 0");
   const size_t P = h->n_problems;
   for (size_t i = 0; i < 7 * P; ++i)
     if (!std::isfinite(poses[i])) return fail(CLC_ERR_NONFINITE, "clc_solve_batched: non-finite initial pose");

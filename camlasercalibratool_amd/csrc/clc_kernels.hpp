@@ -63,13 +63,49 @@ __device__ __forceinline__ void load_pose(const double* __restrict__ pose, PoseU
   for (int i = 0; i < 3; ++i) P.t[i] = make_uniform(x[i]);
 }
 
-// One observation: residual r = s (n.(R p + t) + d)            (LaseCamCalCeres.cpp:47-48)
-//                  J_t = s n, J_theta = s (p x R^T n)            (:56-57, tangent space of Plus)
-//                  Cauchy a = lf*s: rho0 = b log(1 + r^2/b), rho1 = 1/(1 + r^2/b)   (:249)
-// Corrector (rho'' <= 0 branch): J~ = sqrt(rho1) J, r~ = sqrt(rho1) r, so
-//   H += rho1 J^T J, g += rho1 J^T r, cost += rho0 (halved at the end).
+// Reciprocal to ~1 ulp: v_rcp_f64 seed + two Newton steps (no IEEE corner cases needed: the
+// argument is a finite number >= 1).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
+// log(x) for finite x >= 1 (the Cauchy argument 1 + r^2/a^2): fdlibm-style reduction
+// x = 2^e * m, m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f/(2+f),
+// log(m) = f - s*(f - R(s^2)) with the 7-term minimax R, log(x) = e*ln2 + log(m).  < 1 ulp.
+__device__ __forceinline__ double log_ge1(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f * fast_rcp(2.0 + f);
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  // log(x) = dk*ln2_hi - ((hfsq - (s*(hfsq+R) + dk*ln2_lo)) - f)
+  return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
+// One observation (record {n,d,p,s}), pose (R,t):
+//   r0 = n.(R p + t) + d, residual r = s r0                          (LaseCamCalCeres.cpp:47-48)
+//   u  = [n, p x R^T n]  : Jacobian row J = s u (tangent space of Plus)            (:56-57)
+//   Cauchy a = lf*s (:249): rho0 = a^2 log(1 + r^2/a^2), rho1 = 1/(1 + r^2/a^2).  The scale
+//   cancels inside the loss argument: r^2/a^2 = r0^2/lf^2, so sum = 1 + r0^2/lf^2 needs no
+//   per-observation division.
+//   Corrector (rho'' <= 0 branch): J~ = sqrt(rho1) J, r~ = sqrt(rho1) r, hence
+//     H += k u u^T, g += k r0 u  with k = rho1 s^2 ;  cost += s^2 log(sum)  (x lf^2/2 at the end)
+//   Without loss: k = s^2, cost += s^2 r0^2 (x 1/2 at the end).
+// acc[27] therefore holds sum s^2*log(sum) (or sum r^2); finalize_cost() applies the factor.
 template <bool WITH_LOSS, bool WITH_JAC>
-__device__ __forceinline__ void accumulate_observation(const PoseU& P, const double lf,
+__device__ __forceinline__ void accumulate_observation(const PoseU& P, const double inv_lf2,
                                                        const double nx, const double ny,
                                                        const double nz, const double d,
                                                        const double px, const double py,
@@ -81,39 +117,42 @@ __device__ __forceinline__ void accumulate_observation(const PoseU& P, const dou
   const double mz = fma(P.R[8], nz, fma(P.R[5], ny, P.R[2] * nx));
   // n.(R p + t) + d = m.p + (n.t + d)
   const double c0 = fma(P.t[2], nz, fma(P.t[1], ny, fma(P.t[0], nx, d)));
-  const double r = s * fma(mz, pz, fma(my, py, fma(mx, px, c0)));
-  double w = 1.0;
+  const double r0 = fma(mz, pz, fma(my, py, fma(mx, px, c0)));
+  const double s2 = s * s;
+  double k = s2;
   if (WITH_LOSS) {
-    const double a = lf * s;
-    const double b = a * a;
-    const double c = 1.0 / b;
-    const double sum = fma(r * r, c, 1.0);
-    acc[27] = fma(b, log(sum), acc[27]);
-    w = fmax(2.2250738585072014e-308, 1.0 / sum);
+    const double sum = fma(r0 * r0, inv_lf2, 1.0);
+    acc[27] = fma(s2, log_ge1(sum), acc[27]);
+    k = s2 * fmax(2.2250738585072014e-308, fast_rcp(sum));
   } else {
-    acc[27] = fma(r, r, acc[27]);
+    acc[27] = fma(s2 * r0, r0, acc[27]);
   }
   if (WITH_JAC) {
-    double J[6], wJ[6];
-    J[0] = s * nx;
-    J[1] = s * ny;
-    J[2] = s * nz;
-    J[3] = s * fma(py, mz, -(pz * my));
-    J[4] = s * fma(pz, mx, -(px * mz));
-    J[5] = s * fma(px, my, -(py * mx));
+    double u[6], ku[6];
+    u[0] = nx;
+    u[1] = ny;
+    u[2] = nz;
+    u[3] = fma(py, mz, -(pz * my));
+    u[4] = fma(pz, mx, -(px * mz));
+    u[5] = fma(px, my, -(py * mx));
 #pragma unroll
-    for (int a = 0; a < 6; ++a) wJ[a] = WITH_LOSS ? w * J[a] : J[a];
+    for (int a = 0; a < 6; ++a) ku[a] = k * u[a];
     int idx = 0;
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = a; b < 6; ++b) {
-        acc[idx] = fma(wJ[a], J[b], acc[idx]);
+        acc[idx] = fma(ku[a], u[b], acc[idx]);
         ++idx;
       }
 #pragma unroll
-    for (int a = 0; a < 6; ++a) acc[21 + a] = fma(wJ[a], r, acc[21 + a]);
+    for (int a = 0; a < 6; ++a) acc[21 + a] = fma(ku[a], r0, acc[21 + a]);
   }
+}
+
+// cost = 1/2 sum rho: acc[27] holds sum s^2 log(sum) (loss) or sum r^2 (no loss).
+__device__ __forceinline__ double finalize_cost(double acc27, bool with_loss, double lf) {
+  return with_loss ? 0.5 * (lf * lf) * acc27 : 0.5 * acc27;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -197,7 +236,7 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], int redu
   __shared__ double wsum[NWAVES][NACC];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  if (reduce_mode == 0)
+  if ((reduce_mode & 1) == 0)
     wave_reduce_butterfly(acc, wsum[wave], lane);
   else
     wave_reduce_shuffle(acc, wsum[wave], lane);
@@ -267,7 +306,39 @@ __global__ void retile_batched_kernel(const double* __restrict__ aos,
 // status (nullable): device-side termination flag of the LM controller; a finished solve
 // turns the remaining enqueued launches into no-ops.
 // ---------------------------------------------------------------------------------------
+// launch flags (clc_set_launch)
+constexpr int FLAG_REDUCE_SHUFFLE = 1;  // reference wave reduction instead of the butterfly
+constexpr int FLAG_PREFETCH = 2;        // software-pipelined tile loads (next tile in flight while computing)
+constexpr int FLAG_NONTEMPORAL = 4;     // nt loads for the streamed tiles
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ void load_tile(const double* __restrict__ tiles, long long tile, int lane,
+                                          double2 (&f)[8]) {
+  const v2d* base = reinterpret_cast<const v2d*>(tiles + tile * TILE_DOUBLES) + lane;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v2d v;
+    if (NT)
+      v = __builtin_nontemporal_load(base + k * 64);
+    else
+      v = base[k * 64];
+    f[k].x = v[0];
+    f[k].y = v[1];
+  }
+}
+
 template <bool WITH_LOSS, bool WITH_JAC>
+__device__ __forceinline__ void accumulate_tile(const PoseU& P, double inv_lf2, const double2 (&f)[8],
+                                                double (&acc)[NACC]) {
+  accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x,
+                                              f[5].x, f[6].x, f[7].x, acc);
+  accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
+                                              f[5].y, f[6].y, f[7].y, acc);
+}
+
+template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT>
 __global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ tiles,
                                                      const long long n,
                                                      const double* __restrict__ pose,
@@ -277,6 +348,7 @@ __global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ 
   if (status != nullptr && *status != CLC_RUNNING) return;
   PoseU P;
   load_pose(pose, P);
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
@@ -286,53 +358,76 @@ __global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ 
   const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
   const long long n_full = n / TILE;
 
-  for (long long tile = wave_global; tile < n_full; tile += n_waves) {
-    const double2* base = reinterpret_cast<const double2*>(tiles + tile * TILE_DOUBLES) + lane;
-    double2 f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
-    accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x,
-                                                f[5].x, f[6].x, f[7].x, acc);
-    accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
-                                                f[5].y, f[6].y, f[7].y, acc);
+  if (PREFETCH) {
+    // two register buffers; the loads of tile t+n_waves are in flight while tile t is consumed
+    double2 fa[8], fb[8];
+    long long tile = wave_global;
+    if (tile < n_full) load_tile<NT>(tiles, tile, lane, fa);
+    while (tile < n_full) {
+      const long long t1 = tile + n_waves;
+      if (t1 < n_full) load_tile<NT>(tiles, t1, lane, fb);
+      accumulate_tile<WITH_LOSS, WITH_JAC>(P, inv_lf2, fa, acc);
+      if (t1 >= n_full) break;
+      const long long t2 = t1 + n_waves;
+      if (t2 < n_full) load_tile<NT>(tiles, t2, lane, fa);
+      accumulate_tile<WITH_LOSS, WITH_JAC>(P, inv_lf2, fb, acc);
+      tile = t2;
+    }
+  } else {
+    for (long long tile = wave_global; tile < n_full; tile += n_waves) {
+      double2 f[8];
+      load_tile<NT>(tiles, tile, lane, f);
+      accumulate_tile<WITH_LOSS, WITH_JAC>(P, inv_lf2, f, acc);
+    }
   }
   const int rem = (int)(n % TILE);
   if (rem != 0 && wave_global == (n_full % n_waves)) {  // ragged last tile: masked lanes
-    const double2* base = reinterpret_cast<const double2*>(tiles + n_full * TILE_DOUBLES) + lane;
     double2 f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
+    load_tile<false>(tiles, n_full, lane, f);
     if (2 * lane < rem)
-      accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x,
+      accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x,
                                                   f[5].x, f[6].x, f[7].x, acc);
     if (2 * lane + 1 < rem)
-      accumulate_observation<WITH_LOSS, WITH_JAC>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
+      accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
                                                   f[5].y, f[6].y, f[7].y, acc);
   }
   block_reduce_store<BLOCK / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 
-// Fixed-order sum of the block partials: thread (c, rg) sums rows rg, rg+8, ... of column c,
-// then column c is finished in row-group order.  Result in tot[28] of thread 0's caller via LDS.
+// Fixed-order sum of the block partials: thread (c, rg) sums rows rg, rg+8, ... of column c
+// (16 independent loads in flight per round — a dependent load chain here costs more than
+// the whole evaluation kernel), then the 8 row groups are combined in order.
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int n_blocks,
                                                 double (*red)[32]) {
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  constexpr int RG = BLOCK / 32, UNROLL = 16;
   double s = 0.0;
-  if (c < NACC)
-    for (int b = rg; b < n_blocks; b += BLOCK / 32) s += partials[(size_t)b * NACC + c];
+  if (c < NACC) {
+    for (int b0 = rg; b0 < n_blocks; b0 += RG * UNROLL) {
+      double v[UNROLL];
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) {
+        const int b = b0 + RG * j;
+        v[j] = (b < n_blocks) ? partials[(size_t)b * NACC + c] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) s += v[j];
+    }
+  }
   red[rg][c] = s;
   __syncthreads();
 }
 
 __global__ __launch_bounds__(BLOCK) void reduce_kernel(const double* __restrict__ partials,
-                                                       int n_blocks, double* __restrict__ out28) {
+                                                       int n_blocks, int with_loss, double lf,
+                                                       double* __restrict__ out28) {
   __shared__ double red[BLOCK / 32][32];
   reduce_partials(partials, n_blocks, red);
   if (threadIdx.x < NACC) {
     double s = 0.0;
 #pragma unroll
     for (int rg = 0; rg < BLOCK / 32; ++rg) s += red[rg][threadIdx.x];
-    out28[threadIdx.x] = (threadIdx.x == 27) ? 0.5 * s : s;
+    out28[threadIdx.x] = (threadIdx.x == 27) ? finalize_cost(s, with_loss != 0, lf) : s;
   }
 }
 
@@ -341,14 +436,23 @@ __global__ __launch_bounds__(BLOCK) void reduce_kernel(const double* __restrict_
 // ---------------------------------------------------------------------------------------
 constexpr int LM_STATE_WORDS = (int)((sizeof(LmState) + 7) / 8);
 
+// Host-visible completion record in pinned (fine-grained) host memory.  lm_kernel publishes
+// the number of evaluation passes consumed after every LM step and, at termination, the
+// result — so the host can keep the launch queue primed without ever blocking on the stream.
+struct HostMailbox {
+  int32_t status;  // CLC_RUNNING until the controller terminates
+  int32_t n_done;  // evaluation passes consumed so far
+  clc_summary summary;
+  double pose[7];
+};
+
 __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ partials,
                                                    int n_blocks, LmState* __restrict__ state,
                                                    const clc_options opt,
                                                    clc_iteration* __restrict__ trace,
-                                                   int trace_cap) {
+                                                   int trace_cap, HostMailbox* mailbox) {
   __shared__ double red[BLOCK / 32][32];
   __shared__ double sh_state[LM_STATE_WORDS];
-  __shared__ LmScratch scratch;
   if (state->status != CLC_RUNNING) return;
   for (int i = threadIdx.x; i < LM_STATE_WORDS; i += BLOCK)
     sh_state[i] = reinterpret_cast<const double*>(state)[i];
@@ -362,21 +466,40 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
       for (int rg = 0; rg < BLOCK / 32; ++rg) s += red[rg][c];
       tot[c] = s;
     }
-    LmState& st = *reinterpret_cast<LmState*>(sh_state);
-    lm_advance(st, scratch, opt, trace, trace_cap, 0.5 * tot[27], tot + 21, tot);
+    LmState st = *reinterpret_cast<LmState*>(sh_state);
+    LmScratch scratch;
+    lm_advance(st, scratch, opt, trace, trace_cap,
+               finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
+    *reinterpret_cast<LmState*>(sh_state) = st;
+    if (mailbox != nullptr) {
+      if (st.status != CLC_RUNNING) {
+        clc_summary sm;
+        lm_fill_summary(st, sm);
+        sm.solve_ms = 0.0;
+        sm.eval_kernel_ms = 0.0;
+        sm.eval_kernel_launches = 0;
+        mailbox->summary = sm;
+        for (int i = 0; i < 7; ++i) mailbox->pose[i] = st.x_out[i];
+        __threadfence_system();
+      }
+      __hip_atomic_store(&mailbox->n_done, (int32_t)st.n_evals, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (st.status != CLC_RUNNING)
+        __hip_atomic_store(&mailbox->status, st.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < LM_STATE_WORDS; i += BLOCK)
     reinterpret_cast<double*>(state)[i] = sh_state[i];
 }
 
-__global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt,
-                               const double* __restrict__ pose0) {
+struct Pose7 {
+  double v[7];
+};
+
+__global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double p[7];
-    for (int i = 0; i < 7; ++i) p[i] = pose0[i];
     LmState s;
-    lm_init(s, opt, p);
+    lm_init(s, opt, pose0.v);
     *state = s;
   }
 }
@@ -541,6 +664,7 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
   if (st->status != CLC_RUNNING) return;
   PoseU P;
   load_pose(st->x_eval, P);
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
@@ -555,9 +679,9 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
     double2 f[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
-    accumulate_observation<WITH_LOSS, true>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
+    accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
                                             f[6].x, f[7].x, acc);
-    accumulate_observation<WITH_LOSS, true>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
+    accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
                                             f[6].y, f[7].y, acc);
   }
   const int rem = (int)(n % TILE);
@@ -567,10 +691,10 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
     if (2 * lane < rem)
-      accumulate_observation<WITH_LOSS, true>(P, lf, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
+      accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
                                               f[6].x, f[7].x, acc);
     if (2 * lane + 1 < rem)
-      accumulate_observation<WITH_LOSS, true>(P, lf, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
+      accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
                                               f[6].y, f[7].y, acc);
   }
   block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
@@ -603,7 +727,7 @@ __global__ void batched_lm_kernel(const double* __restrict__ partials, const int
   }
   LmState s = states[p];
   LmScratch w;
-  lm_advance(s, w, opt, nullptr, 0, 0.5 * tot[27], tot + 21, tot);
+  lm_advance(s, w, opt, nullptr, 0, finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
   states[p] = s;
   if (s.status == CLC_RUNNING) atomicAdd(active, 1u);
 }

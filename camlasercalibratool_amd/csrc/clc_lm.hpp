@@ -79,7 +79,7 @@ CLC_HD void lm_init(LmState& s, const clc_options& o, const double* pose0) {
 // ||x - Plus(x, -g)||_inf in the ambient 7-space (Ceres' projected-gradient norm).
 CLC_HD double gradient_max_norm(const double* x, const double* g, LmScratch& w) {
   CLC_ROLLED for (int i = 0; i < 6; ++i) w.ng[i] = -g[i];
-  pose_plus(x, w.ng, w.proj);
+  pose_plus_rcp(x, w.ng, w.proj);
   double m = 0.0;
   CLC_ROLLED for (int i = 0; i < 7; ++i) {
     const double a = fabs(x[i] - w.proj[i]);
@@ -107,10 +107,10 @@ CLC_HD bool lm_compute_step(LmState& s, const clc_options& o, LmScratch& w) {
     }
   }
   CLC_ROLLED for (int i = 0; i < 36; ++i) w.A[i] = w.Hs[i];
-  CLC_ROLLED for (int c = 0; c < 6; ++c) {
-    const double d = sqrt(s.diag[c] / s.radius);  // lm_diagonal = sqrt(diag / radius)
-    w.A[6 * c + c] += d * d;
-  }
+  // Ceres appends lm_diagonal = sqrt(diag / radius) as rows of [J; D]; in the normal
+  // equations that is + D^2 = diag / radius on the diagonal.
+  const double inv_radius = 1.0 / s.radius;
+  CLC_ROLLED for (int c = 0; c < 6; ++c) w.A[6 * c + c] += s.diag[c] * inv_radius;
   bool ok = chol6_solve(w.A, w.gs, w.y, w.L, w.z);
   s.reuse_diagonal = 1;
   if (ok) {
@@ -245,7 +245,7 @@ CLC_HD void lm_advance(LmState& s, LmScratch& w, const clc_options& o, clc_itera
     if (lm_compute_step(s, o, w)) {
       s.n_invalid = 0;
       CLC_ROLLED for (int c = 0; c < 6; ++c) w.delta[c] = s.step[c] * s.scale[c];  // undo column scaling
-      pose_plus(s.x, w.delta, s.x_eval);  // candidate
+      pose_plus_rcp(s.x, w.delta, s.x_eval);  // candidate
       s.phase = 1;
       s.iteration = next;
       return;  // request an evaluation at x_eval

@@ -12,7 +12,7 @@
 
 #if defined(__HIPCC__)
 #define CLC_HD __host__ __device__ __forceinline__
-#define CLC_ROLLED _Pragma("unroll 1")
+#define CLC_ROLLED
 #else
 #define CLC_HD inline
 #define CLC_ROLLED
@@ -51,6 +51,25 @@ CLC_HD void pose_plus(const double* x, const double* delta, double* out) {
   out[6] = w / n;
 }
 
+// Same update with one reciprocal instead of four divisions (<= 1 ulp from pose_plus): used
+// by the LM controller, where the serial division latency is what the GPU pays for.
+CLC_HD void pose_plus_rcp(const double* x, const double* delta, double* out) {
+  out[0] = x[0] + delta[0];
+  out[1] = x[1] + delta[1];
+  out[2] = x[2] + delta[2];
+  const double bx = delta[3] * 0.5, by = delta[4] * 0.5, bz = delta[5] * 0.5;
+  const double ax = x[3], ay = x[4], az = x[5], aw = x[6];
+  const double w = aw - ax * bx - ay * by - az * bz;
+  const double qx = aw * bx + ax + ay * bz - az * by;
+  const double qy = aw * by + ay + az * bx - ax * bz;
+  const double qz = aw * bz + az + ax * by - ay * bx;
+  const double inv = 1.0 / sqrt(qx * qx + qy * qy + qz * qz + w * w);
+  out[3] = qx * inv;
+  out[4] = qy * inv;
+  out[5] = qz * inv;
+  out[6] = w * inv;
+}
+
 CLC_HD double norm7(const double* x) {
   double s = 0.0;
   CLC_ROLLED for (int i = 0; i < 7; ++i) s += x[i] * x[i];
@@ -61,31 +80,30 @@ CLC_HD double norm7(const double* x) {
 CLC_HD int tri6(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
 
 // Solve A y = b for symmetric positive definite 6x6 A (row-major). false if a pivot <= 0.
-// L (36) and z (6) are caller-provided scratch (LDS on the device): the loops stay rolled so
-// the controller costs few registers next to the streaming loop it shares a kernel with.
+// One reciprocal square root per column (the serial controller is division-latency bound on
+// the GPU); L holds the factor with the INVERSE diagonal on its diagonal.  L (36), z (6) scratch.
 CLC_HD bool chol6_solve(const double* A, const double* b, double* y, double* L, double* z) {
-  CLC_ROLLED for (int i = 0; i < 36; ++i) L[i] = 0.0;
   CLC_ROLLED for (int j = 0; j < 6; ++j) {
     double d = A[6 * j + j];
     CLC_ROLLED for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
     if (!(d > 0.0)) return false;
-    const double ljj = sqrt(d);
-    L[6 * j + j] = ljj;
+    const double inv = 1.0 / sqrt(d);
+    L[6 * j + j] = inv;
     CLC_ROLLED for (int i = j + 1; i < 6; ++i) {
       double s = A[6 * i + j];
       CLC_ROLLED for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
-      L[6 * i + j] = s / ljj;
+      L[6 * i + j] = s * inv;
     }
   }
   CLC_ROLLED for (int i = 0; i < 6; ++i) {
     double s = b[i];
     CLC_ROLLED for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
-    z[i] = s / L[6 * i + i];
+    z[i] = s * L[6 * i + i];
   }
   CLC_ROLLED for (int i = 5; i >= 0; --i) {
     double s = z[i];
     CLC_ROLLED for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
-    y[i] = s / L[6 * i + i];
+    y[i] = s * L[6 * i + i];
   }
   return true;
 }

@@ -67,8 +67,8 @@ class Solver:
     def set_stream(self, hip_stream: Optional[int]):
         check(self._L.clc_set_stream(self._h, C.c_void_p(hip_stream or 0)), "clc_set_stream")
 
-    def set_launch(self, grid_blocks: int = 0, reduce_mode: int = 0):
-        check(self._L.clc_set_launch(self._h, C.c_int(grid_blocks), C.c_int(reduce_mode)), "clc_set_launch")
+    def set_launch(self, grid_blocks: int = 0, flags: int = 0):
+        check(self._L.clc_set_launch(self._h, C.c_int(grid_blocks), C.c_int(flags)), "clc_set_launch")
 
     def device_info(self) -> Tuple[str, int]:
         buf = C.create_string_buffer(256)

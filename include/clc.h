@@ -77,8 +77,9 @@ typedef struct clc_options {
   double gradient_tolerance;                 /* 1e-10                                        */
   double parameter_tolerance;                /* 1e-8                                         */
   /* execution knobs (no effect on results beyond reduction order) */
-  int32_t sync_interval;  /* LM iterations enqueued between host checks of the device-side
-                             termination flag; 0 = library default                           */
+  int32_t sync_interval;  /* clc_solve: launch-ahead depth (LM iterations kept queued beyond the
+                             last one the device reported done); clc_solve_batched: iterations
+                             between host checks of the active-problem count; 0 = default    */
   int32_t profile_events; /* 1: bracket every evaluation-kernel launch with HIP events on the
                              handle's stream and report them in clc_summary                  */
 } clc_options;
@@ -124,8 +125,11 @@ void clc_destroy(clc_handle* h);
 /* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
  * NULL restores the handle's own stream. */
 int clc_set_stream(clc_handle* h, void* hip_stream);
-/* Geometry of the evaluation launch (blocks of 256 threads); 0 = library default. */
-int clc_set_launch(clc_handle* h, int grid_blocks, int reduce_mode);
+/* Tuning of the evaluation launch: grid_blocks = number of 256-thread workgroups (0 = library
+ * default); flags: 1 = reference shuffle reduction instead of the butterfly, 2 = software
+ * prefetch of the next tile, 4 = non-temporal loads; -1 = library default.  Results change
+ * only in summation order. */
+int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 
 /* ---- problem assembly (host) --------------------------------------------------------
  * Replaces the residual-block construction loop of CamLaserCalibration,

@@ -102,14 +102,14 @@ def test_eval_reduction_matches_oracle_ragged_sizes(sv, oracle_mod, n, with_loss
     assert sv.num_observations == n
     pose = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)) if n % 2 else X0
     pose = oracle_mod.pose_plus(pose, rng.normal(size=6) * 0.05)
-    for mode in (0, 1):
-        sv.set_launch(0, mode)
+    for flags in (0, 1, 2, 4, 6, 7):  # every kernel variant: reduction x prefetch x non-temporal
+        sv.set_launch(0, flags)
         c, g, H = sv.eval(pose, with_loss=with_loss)
         c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
         assert abs(c - c0) <= 1e-11 * abs(c0) + 1e-300
         assert np.abs(g - g0).max() <= 1e-11 * np.abs(g0).max() + 1e-18
         assert np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
-    sv.set_launch(0, 0)
+    sv.set_launch(0, -1)  # library default
     c1, _, _ = sv.eval(pose, with_loss=with_loss, want_jacobian=False)  # cost-only variant
     assert abs(c1 - c0) <= 1e-11 * abs(c0) + 1e-300
 
@@ -121,9 +121,9 @@ def test_eval_is_bitwise_reproducible_and_grid_invariant_to_rounding(sv, oracle_
     a = sv.eval(X0)
     b = sv.eval(X0)
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])  # fixed-shape reduction
-    sv.set_launch(64, 0)
+    sv.set_launch(64, -1)
     c = sv.eval(X0)
-    sv.set_launch(0, 0)
+    sv.set_launch(0, -1)
     assert abs(c[0] - a[0]) <= 1e-12 * abs(a[0]) and np.allclose(c[2], a[2], rtol=1e-12)
 
 
