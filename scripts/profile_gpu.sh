@@ -1,19 +1,25 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of the bench command.
-# Outputs under gpurun_out/prof_<tag>/ ; summaries are copied into profiles/ by hand.
+# Outputs under gpurun_out/prof_<tag>/ ; scripts/summarize_profile.py turns them into profiles/.
 TAG=${1:-r01}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --large-obs 8000000"
+# the default bench command, minus the CPU baseline (pure host work) ...
+CMD="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace_bench.log 2>&1
+# 1) kernel trace + stats of the C2 workload only (no >L3 pass, so the per-kernel averages are clean)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD --large-obs 0 > $OUT/trace_bench.log 2>&1
 echo "trace rc=$?"
+# 2) PMC passes (own runs, --kernel-trace only): HBM read / write bytes per dispatch, incl. the 8e6-obs pass
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch_bench.log 2>&1
 echo "pmc fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write_bench.log 2>&1
 echo "pmc write rc=$?"
+# 3) plain run of the same command for the bench line that goes with these profiles
+$CMD > $OUT/bench_plain.log 2>&1
+echo "plain rc=$?"
 cd $REPO
-find $OUT -type f | head -50
+grep -h '^{' $OUT/bench_plain.log | tail -1 | cut -c1-400
 du -sh $OUT
