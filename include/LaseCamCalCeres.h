@@ -1,0 +1,206 @@
+// include/LaseCamCalCeres.h — drop-in replacement of the reference header of the same name
+// (MegviiRobot/CamLaserCalibraTool, include/LaseCamCalCeres.h:11-29).
+//
+// Same public surface — `struct Oberserve` (sic) and the four free functions with identical
+// signatures and default arguments — so main/calibr_offline.cpp:166-170 and
+// main/calibr_simulation.cpp:130 compile unchanged.  The two functions on the hot path,
+//     CamLaserCalClosedSolution()   (reference body: src/LaseCamCalCeres.cpp:112-203)
+//     CamLaserCalibration()         (reference body: src/LaseCamCalCeres.cpp:213-383)
+// are defined here as thin host adapters: flatten std::vector<Oberserve> -> C-ABI (clc.h) ->
+// hand-written HIP kernels on the MI355X.  LineFittingCeres() and
+// CalibrationTool_SavePlanePoints() are out of scope (per-scan front-end fit / debug dump) and
+// stay declared only: they keep coming from the reference's own translation unit.
+// Link with libclc_hip.so; see INTEGRATION.md.
+//
+// Conventions kept from the reference: `obs` by value; `Tlc` / `Tcl` are in/out 4x4 matrices
+// (initial guess in, result out; :215-219, :311-314); no return value, no exceptions by design,
+// diagnostics on stdout (closed-form Tlc :202, solver summary :309, singular values / null
+// space / "recover chi2" :365-381).  An error from the GPU library (e.g. no device) is
+// reported on stderr and leaves the output matrix untouched.
+#ifndef PROJECT_LASECAMCALCERES_H
+#define PROJECT_LASECAMCALCERES_H
+
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "clc.h"
+
+struct Oberserve
+{
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+    Oberserve()
+    {
+        tagPose_Qca = Eigen::Quaterniond(1,0,0,0);
+        tagPose_tca = Eigen::Vector3d::Zero();
+    }
+
+    Eigen::Quaterniond tagPose_Qca;    // tag orientation in the camera frame at this instant
+    Eigen::Vector3d tagPose_tca;
+    std::vector<Eigen::Vector3d> points;           // laser points on the board in this scan
+    std::vector<Eigen::Vector3d> points_on_line;   // the (two) points on the fitted scan line
+};
+
+// unchanged, CPU, provided by the reference's own src/LaseCamCalCeres.cpp
+void LineFittingCeres(const std::vector<Eigen::Vector3d> Points, Eigen::Vector2d & Line);
+void CalibrationTool_SavePlanePoints(const std::vector<Oberserve> obs, const Eigen::Matrix4d Tcl, const std::string path);
+
+namespace clc_adapter {
+
+struct Flat {  // pose-major CSR form of std::vector<Oberserve>
+    std::vector<double> tag_q, tag_t, pts, ptl;
+    std::vector<int64_t> pts_off, ptl_off;
+};
+
+inline Flat flatten(const std::vector<Oberserve>& obs)
+{
+    Flat f;
+    const size_t P = obs.size();
+    f.tag_q.reserve(4 * P); f.tag_t.reserve(3 * P);
+    f.pts_off.assign(1, 0); f.ptl_off.assign(1, 0);
+    for (size_t i = 0; i < P; ++i) {
+        const Oberserve& o = obs[i];
+        f.tag_q.push_back(o.tagPose_Qca.w()); f.tag_q.push_back(o.tagPose_Qca.x());
+        f.tag_q.push_back(o.tagPose_Qca.y()); f.tag_q.push_back(o.tagPose_Qca.z());
+        for (int k = 0; k < 3; ++k) f.tag_t.push_back(o.tagPose_tca(k));
+        for (size_t j = 0; j < o.points.size(); ++j)
+            for (int k = 0; k < 3; ++k) f.pts.push_back(o.points[j](k));
+        for (size_t j = 0; j < o.points_on_line.size(); ++j)
+            for (int k = 0; k < 3; ++k) f.ptl.push_back(o.points_on_line[j](k));
+        f.pts_off.push_back((int64_t)(f.pts.size() / 3));
+        f.ptl_off.push_back((int64_t)(f.ptl.size() / 3));
+    }
+    return f;
+}
+
+inline bool records(const Flat& f, bool linefit, bool boundary, std::vector<clc_observation>& rec)
+{
+    int64_t n = 0;
+    const int P = (int)(f.pts_off.size() - 1);
+    int rc = clc_flatten_observations(P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts.data(),
+                                      f.ptl_off.data(), f.ptl.data(), linefit, boundary, NULL, &n);
+    if (rc != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; return false; }
+    rec.resize((size_t)n);
+    rc = clc_flatten_observations(P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts.data(),
+                                  f.ptl_off.data(), f.ptl.data(), linefit, boundary, rec.data(), &n);
+    return rc == CLC_OK;
+}
+
+// Eigen::Quaterniond(Matrix3d) on plain doubles (the conversion the reference does at :215).
+inline void rot_to_quat_xyzw(const double m[9], double q[4])
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+
+inline int device_index()
+{
+    const char* e = std::getenv("CLC_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+
+struct Handle {  // RAII around clc_handle
+    clc_handle* h;
+    Handle() : h(NULL) {
+        if (clc_create(&h, device_index()) != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; h = NULL; }
+    }
+    ~Handle() { if (h) clc_destroy(h); }
+};
+
+}  // namespace clc_adapter
+
+// Closed-form initial guess of Tlc (camera -> laser).  Reference: src/LaseCamCalCeres.cpp:112-203.
+inline void CamLaserCalClosedSolution(const std::vector<Oberserve> obs, Eigen::Matrix4d &Tlc)
+{
+    std::vector<clc_observation> rec;
+    if (!clc_adapter::records(clc_adapter::flatten(obs), /*linefit=*/true, /*boundary=*/false, rec)) return;  // :143
+    clc_adapter::Handle H;
+    if (!H.h) return;
+    double T[16]; int unobservable = 0;
+    if (clc_upload(H.h, rec.data(), rec.size()) != CLC_OK || clc_closed_form(H.h, T, &unobservable, NULL) != CLC_OK) {
+        std::cerr << "[clc] " << clc_last_error() << std::endl;
+        return;
+    }
+    if (unobservable) {  // :173-178
+        std::cout <<std::endl<< "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl;
+        std::cout << " Notice Notice Notice: system unobservable !!!!!!!" << std::endl;
+        std::cout << "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl<<std::endl;
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tlc(i, j) = T[4 * i + j];  // :198-200
+    std::cout <<"------- Closed-form solution Tlc: -------\n" << Tlc <<std::endl;      // :202
+}
+
+// Nonlinear refinement of Tcl (laser -> camera).  Reference: src/LaseCamCalCeres.cpp:213-383.
+inline void CamLaserCalibration(const std::vector<Oberserve> obs, Eigen::Matrix4d &Tcl, bool use_linefitting_data = true, bool use_boundary_constraint = false)
+{
+    const clc_adapter::Flat flat = clc_adapter::flatten(obs);
+    std::vector<clc_observation> rec;
+    if (!clc_adapter::records(flat, use_linefitting_data, use_boundary_constraint, rec)) return;
+    double R[9], pose[7];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = Tcl(i, j);
+    clc_adapter::rot_to_quat_xyzw(R, pose + 3);                       // :215
+    pose[0] = Tcl(0, 3); pose[1] = Tcl(1, 3); pose[2] = Tcl(2, 3);    // :219
+
+    clc_adapter::Handle H;
+    if (!H.h) return;
+    clc_options opt; clc_options_default(&opt);                       // DENSE_QR-equivalent, 100 iterations, :302-304
+    clc_summary sum;
+    if (clc_upload(H.h, rec.data(), rec.size()) != CLC_OK || clc_solve(H.h, &opt, pose, &sum, NULL, 0) != CLC_OK) {
+        std::cerr << "[clc] " << clc_last_error() << std::endl;
+        return;
+    }
+    static const char* term[] = {"RUNNING", "CONVERGENCE (gradient)", "CONVERGENCE (parameter)", "CONVERGENCE (function)",
+                                 "CONVERGENCE (radius)", "NO_CONVERGENCE", "FAILURE"};
+    std::cout << "Solver Summary (MI355X HIP backend)\n  Residuals            " << rec.size()
+              << "\n  Initial cost         " << sum.initial_cost << "\n  Final cost           " << sum.final_cost
+              << "\n  Iterations           " << sum.num_iterations << " (successful " << sum.num_successful_steps - 1
+              << ", unsuccessful " << sum.num_unsuccessful_steps << ")\n  Evaluation passes    " << sum.num_evaluations
+              << "\n  Time (ms)            " << sum.solve_ms << "\n  Termination          " << term[sum.termination] << std::endl;  // :309
+
+    // write-back, :311-314 (Quaterniond::toRotationMatrix on the unit quaternion)
+    {
+        const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];
+        const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+        const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+        Tcl(0, 0) = 1 - (tyy + tzz); Tcl(0, 1) = txy - twz;       Tcl(0, 2) = txz + twy;
+        Tcl(1, 0) = txy + twz;       Tcl(1, 1) = 1 - (txx + tzz); Tcl(1, 2) = tyz - twx;
+        Tcl(2, 0) = txz - twy;       Tcl(2, 1) = tyz + twx;       Tcl(2, 2) = 1 - (txx + tyy);
+        Tcl(0, 3) = pose[0]; Tcl(1, 3) = pose[1]; Tcl(2, 3) = pose[2];
+    }
+
+    /// =============================  analysis code (:316-381) ==============================
+    // second pass without loss and without the board-edge terms
+    if (use_boundary_constraint && use_linefitting_data) {
+        if (!clc_adapter::records(flat, use_linefitting_data, false, rec) || clc_upload(H.h, rec.data(), rec.size()) != CLC_OK) return;
+    }
+    double Hm[36], b[6], chi, sv[6], V[36]; int n = 0;
+    if (clc_information(H.h, pose, Hm, b, &chi, sv, V, &n) != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; return; }
+    std::cout << "----- H singular values--------:\n";
+    for (int i = 0; i < 6; ++i) std::cout << sv[i] << "\n";
+    if (n > 0) {
+        std::cout << "====== null space basis, it's means the unobservable direction for Tcl ======" <<std::endl;
+        std::cout << "       please note the unobservable direction is for Tcl, not for Tlc        " <<std::endl;
+        for (int r = 0; r < 6; ++r) { for (int c = 6 - n; c < 6; ++c) std::cout << V[6 * r + c] << " "; std::cout << "\n"; }
+    }
+    std::cout <<"\nrecover chi2: " <<chi / 2. << std::endl;
+}
+#endif //PROJECT_LASECAMCALCERES_H

@@ -1,0 +1,75 @@
+// tests/dropin/sim_main.cpp — TEST ONLY.  A ROS-free port of the flow of
+// main/calibr_simulation.cpp:110-143 (GenerateSimData with a fixed seed -> Tcl = I ->
+// CamLaserCalibration(obs, Tcl, false) -> print Tlc) and of main/calibr_offline.cpp:166-170
+// (closed form -> invert -> refine), written against the drop-in header exactly as the
+// reference's nodes use it.  Prints "RESULT tlc_err R_err" for the test to parse.
+#include <cstdio>
+#include <random>
+
+#include "LaseCamCalCeres.h"
+
+static Eigen::Matrix3d rot(double a, int axis) {
+    Eigen::Matrix3d R = Eigen::Matrix3d::Identity();
+    const double c = std::cos(a), s = std::sin(a);
+    const int i = (axis + 1) % 3, j = (axis + 2) % 3;
+    R(i, i) = c; R(i, j) = -s; R(j, i) = s; R(j, j) = c;
+    return R;
+}
+
+static Eigen::Matrix4d invert(const Eigen::Matrix4d& T) {
+    Eigen::Matrix4d I = Eigen::Matrix4d::Identity();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) I(i, j) = T(j, i);
+    for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += T(k, i) * T(k, 3); I(i, 3) = -s; }
+    return I;
+}
+
+static void GenerateSimData(std::vector<Oberserve>& obs, unsigned seed, double sigma) {
+    Eigen::Matrix3d Rlc;  // calibr_simulation.cpp:15-20
+    Rlc(0, 2) = 1; Rlc(1, 0) = -1; Rlc(2, 1) = -1;
+    Eigen::Vector3d tlc(0.1, 0.2, 0.3);
+    std::mt19937 generator(seed);
+    std::uniform_real_distribution<double> rpy_rand(-M_PI / 6., M_PI / 6.), xy_rand(-3, 3.0), z_rand(1., 5.);
+    std::normal_distribution<double> noise(0.0, 1.0);
+    for (size_t i = 0; i < 50; i++) {
+        Eigen::Matrix3d Rca = rot(rpy_rand(generator), 2) * rot(rpy_rand(generator), 1) * rot(rpy_rand(generator), 0);
+        Eigen::Vector3d tca(xy_rand(generator), xy_rand(generator), z_rand(generator));
+        Eigen::Matrix3d Rla = Rlc * Rca;
+        Eigen::Vector3d tla = Eigen::Vector3d(Rlc * tca) + tlc;
+        Eigen::Vector3d n(Rla(0, 2), Rla(1, 2), Rla(2, 2));
+        const double d = -n.dot(tla);
+        std::vector<Eigen::Vector3d> points;
+        for (size_t j = 0; j < 180; j++) {
+            const double theta = -M_PI_2 + j * M_PI / 180;
+            Eigen::Vector3d ray(cos(theta), sin(theta), 0);
+            double depth = -d / (ray.dot(n));
+            if (std::isnan(depth) || depth < 0) continue;
+            depth += sigma * noise(generator);
+            Eigen::Vector3d p = depth * ray;
+            if (std::fabs(p.x()) < 5 && std::fabs(p.y()) < 5) points.push_back(p);
+        }
+        Oberserve ob;
+        ob.tagPose_Qca = Eigen::Quaterniond(Rca);
+        ob.tagPose_tca = tca;
+        ob.points = points;
+        ob.points_on_line = points;
+        obs.push_back(ob);
+    }
+}
+
+int main(int argc, char** argv) {
+    const bool offline_flow = argc > 1 && std::string(argv[1]) == "offline";
+    std::vector<Oberserve> obs;
+    GenerateSimData(obs, 7u, offline_flow ? 0.01 : 0.0);
+    std::cout << "obs size: " << obs.size() << std::endl;
+    Eigen::Matrix4d Tlc_initial = Eigen::Matrix4d::Identity();
+    if (offline_flow) CamLaserCalClosedSolution(obs, Tlc_initial);      // calibr_offline.cpp:167
+    Eigen::Matrix4d Tcl = invert(Tlc_initial);
+    CamLaserCalibration(obs, Tcl, false);                               // calibr_simulation.cpp:130 / calibr_offline.cpp:170
+    Eigen::Matrix4d Tlc = invert(Tcl);
+    std::cout << "\n----- Transform from Camera to Laser Tlc is: -----\n" << std::endl << Tlc << std::endl;
+    const double Rgt[3][3] = {{0, 0, 1}, {-1, 0, 0}, {0, -1, 0}}, tgt[3] = {0.1, 0.2, 0.3};
+    double eR = 0, et = 0;
+    for (int i = 0; i < 3; ++i) { et = std::fmax(et, std::fabs(Tlc(i, 3) - tgt[i])); for (int j = 0; j < 3; ++j) eR = std::fmax(eR, std::fabs(Tlc(i, j) - Rgt[i][j])); }
+    std::printf("RESULT %.3e %.3e\n", et, eR);
+    return 0;
+}
