@@ -700,6 +700,15 @@ int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int redu
   return CLC_OK;
 }
 
+// Shader-clock stamps of the last lm_kernel launch: [0] kernel entry, [1] after state load +
+// partial reduction, [2] after the LM controller, [3] after publishing to the host mailbox.
+int clc_debug_lm_profile(clc_handle* h, long long out[4]) {
+  if (!h || !out) return fail(CLC_ERR_INVALID_ARG, "clc_debug_lm_profile: bad argument");
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 4; ++i) out[i] = h->h_mailbox->prof[i];
+  return CLC_OK;
+}
+
 // Times `reps` back-to-back launches of the evaluation kernel (K1 only) with HIP events on
 // the handle's stream; *avg_ms = mean kernel-to-kernel period.
 int clc_time_eval(clc_handle* h, const double pose[7], int with_loss, double lf, int with_jac, int reps,

@@ -444,6 +444,7 @@ struct HostMailbox {
   int32_t n_done;  // evaluation passes consumed so far
   clc_summary summary;
   double pose[7];
+  long long prof[8];  // shader-clock stamps of the last lm_kernel launch (debug/profiling)
 };
 
 __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ partials,
@@ -453,26 +454,57 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
                                                    int trace_cap, HostMailbox* mailbox) {
   __shared__ double red[BLOCK / 32][32];
   __shared__ double sh_state[LM_STATE_WORDS];
-  if (state->status != CLC_RUNNING) return;
-  for (int i = threadIdx.x; i < LM_STATE_WORDS; i += BLOCK)
-    sh_state[i] = reinterpret_cast<const double*>(state)[i];
-  reduce_partials(partials, n_blocks, red);
+  static_assert(LM_STATE_WORDS <= BLOCK, "one state word per thread");
+  const long long c0 = clock64();
+  // Issue every global load of this kernel before the first use: termination flag, the
+  // thread's word of the LM state and its share of the block partials (fixed order: thread
+  // (c, rg) owns rows rg, rg+8, ... of column c).  One memory latency instead of four.
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  constexpr int RG = BLOCK / 32, UNROLL = 32;
+  const int32_t status = state->status;
+  const double my_word = threadIdx.x < LM_STATE_WORDS ? reinterpret_cast<const double*>(state)[threadIdx.x] : 0.0;
+  double v[UNROLL];
+#pragma unroll
+  for (int j = 0; j < UNROLL; ++j) {
+    const int b = rg + RG * j;
+    v[j] = (c < NACC && b < n_blocks) ? partials[(size_t)b * NACC + c] : 0.0;
+  }
+  if (status != CLC_RUNNING) return;
+  if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = my_word;
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < UNROLL; ++j) s += v[j];
+  for (int b0 = rg + RG * UNROLL; b0 < n_blocks; b0 += RG * UNROLL) {  // grids beyond 256 workgroups
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) {
+      const int b = b0 + RG * j;
+      v[j] = (c < NACC && b < n_blocks) ? partials[(size_t)b * NACC + c] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < UNROLL; ++j) s += v[j];
+  }
+  red[rg][c] = s;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    const long long c1 = clock64();
     double tot[NACC];
 #pragma unroll
-    for (int c = 0; c < NACC; ++c) {
-      double s = 0.0;
+    for (int cc = 0; cc < NACC; ++cc) {
+      double t = 0.0;
 #pragma unroll
-      for (int rg = 0; rg < BLOCK / 32; ++rg) s += red[rg][c];
-      tot[c] = s;
+      for (int g = 0; g < RG; ++g) t += red[g][cc];
+      tot[cc] = t;
     }
     LmState st = *reinterpret_cast<LmState*>(sh_state);
     LmScratch scratch;
     lm_advance(st, scratch, opt, trace, trace_cap,
                finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
     *reinterpret_cast<LmState*>(sh_state) = st;
+    const long long c2 = clock64();
     if (mailbox != nullptr) {
+      mailbox->prof[0] = c0; mailbox->prof[1] = c1; mailbox->prof[2] = c2;
       if (st.status != CLC_RUNNING) {
+        // termination: payload first, then ONE system-scope release, then the flags
         clc_summary sm;
         lm_fill_summary(st, sm);
         sm.solve_ms = 0.0;
@@ -480,16 +512,17 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
         sm.eval_kernel_launches = 0;
         mailbox->summary = sm;
         for (int i = 0; i < 7; ++i) mailbox->pose[i] = st.x_out[i];
-        __threadfence_system();
-      }
-      __hip_atomic_store(&mailbox->n_done, (int32_t)st.n_evals, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (st.status != CLC_RUNNING)
+        __hip_atomic_store(&mailbox->n_done, (int32_t)st.n_evals, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&mailbox->status, st.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        // progress only: nothing to order it against, a relaxed uncached store is enough
+        __hip_atomic_store(&mailbox->n_done, (int32_t)st.n_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      mailbox->prof[3] = clock64();
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < LM_STATE_WORDS; i += BLOCK)
-    reinterpret_cast<double*>(state)[i] = sh_state[i];
+  if (threadIdx.x < LM_STATE_WORDS) reinterpret_cast<double*>(state)[threadIdx.x] = sh_state[threadIdx.x];
 }
 
 struct Pose7 {

@@ -1,0 +1,13 @@
+import os, sys, ctypes as C, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import camlasercalibratool_amd as clc
+from camlasercalibratool_amd import simdata as sd, _capi
+S = sd.sim_fixed_count(1000, 2000, 500, noise_sigma=0.01)
+rec = clc.flatten_observations(S, False); x0 = sd.pose7_from_T(np.eye(4))
+sv = clc.Solver(0); sv.upload(rec)
+o = clc.default_options(); o.max_num_iterations = 5   # stop mid-way: the last lm_kernel ran a regular step
+for _ in range(5):
+    r = sv.solve(x0, o)
+    p = (C.c_longlong * 4)()
+    _capi.lib().clc_debug_lm_profile(sv._h, p)
+    print("cycles: load+reduce %d, controller %d, mailbox %d (termination %s)" % (p[1]-p[0], p[2]-p[1], p[3]-p[2], r.termination))
