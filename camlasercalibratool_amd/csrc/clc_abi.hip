@@ -42,7 +42,6 @@ bool all_finite(const double* p, int n) {
   return true;
 }
 
-constexpr int kDefaultSyncInterval = 4;  // batched solver: iterations between host checks
 constexpr int kDefaultLookahead = 2;
 constexpr int kDefaultLaunchFlags = 6;   // prefetch + non-temporal loads (clc::FLAG_*), tuned on MI355X
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
@@ -82,6 +81,7 @@ struct clc_handle {
   double* d_poses = nullptr;
   clc_summary* d_summaries = nullptr;
   unsigned int* d_queue = nullptr;  // small device counter (active problems)
+  unsigned int* d_ticket = nullptr; // arrival counter of the fused evaluation+controller launch
   clc::LmState* d_states = nullptr;
   double* d_bpartials = nullptr;
   size_t bpartials_cap_blocks = 0;
@@ -216,6 +216,8 @@ int clc_create(clc_handle** out, int device) {
   CLC_HIP(hipMalloc(&h->d_small, sizeof(double) * kSmallDoubles));
   CLC_HIP(hipHostMalloc(&h->h_small, sizeof(double) * kSmallDoubles, hipHostMallocDefault));
   CLC_HIP(hipMalloc(&h->d_queue, sizeof(unsigned int)));
+  CLC_HIP(hipMalloc(&h->d_ticket, sizeof(unsigned int)));
+  CLC_HIP(hipMemset(h->d_ticket, 0, sizeof(unsigned int)));
   CLC_HIP(hipHostMalloc(&h->h_mailbox, sizeof(clc::HostMailbox), hipHostMallocCoherent | hipHostMallocMapped));
   CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mailbox), h->h_mailbox, 0));
   std::memset(h->h_mailbox, 0, sizeof(clc::HostMailbox));
@@ -230,7 +232,7 @@ void clc_destroy(clc_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_state, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_poses, h->d_summaries, h->d_queue, h->d_states,
-                  h->d_bpartials};
+                  h->d_bpartials, h->d_ticket};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -246,7 +248,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 7)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 15)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
@@ -412,6 +414,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // device has reported done (pinned mailbox), so the stream never drains and the host never
   // blocks; at most `lookahead` already-queued iterations turn into no-ops after termination.
   const int lookahead = opt.sync_interval > 0 ? opt.sync_interval : kDefaultLookahead;
+  const bool fused = (h->launch_flags & clc::FLAG_FUSED_LM) != 0;
 
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
@@ -420,7 +423,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 
   clc::Pose7 p0;
   for (int i = 0; i < 7; ++i) p0.v[i] = pose[i];
-  hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, p0);
+  hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, p0, h->d_ticket);
   CLC_HIP(hipGetLastError());
 
   const double* d_x_eval = reinterpret_cast<const double*>(
@@ -441,10 +444,22 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
     const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
     if (launched < max_evals && launched - done < lookahead) {
       if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
-      launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor);
-      if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
-      hipLaunchKernelGGL(clc::lm_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
-                         h->d_state, opt, d_trace, d_trace_cap, h->d_mailbox);
+      if (fused) {
+        const bool nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;
+#define CLC_LAUNCH_FUSED(LOSS, NT)                                                                        \
+  hipLaunchKernelGGL((clc::eval_lm_kernel<LOSS, NT>), dim3(grid), dim3(clc::BLOCK), 0, h->stream,         \
+                     h->d_tiles, (long long)h->n_obs, h->d_state, opt, h->d_partials, h->d_ticket, d_trace, \
+                     d_trace_cap, h->d_mailbox)
+        if (opt.use_loss) { if (nt) CLC_LAUNCH_FUSED(true, true); else CLC_LAUNCH_FUSED(true, false); }
+        else { if (nt) CLC_LAUNCH_FUSED(false, true); else CLC_LAUNCH_FUSED(false, false); }
+#undef CLC_LAUNCH_FUSED
+        if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
+      } else {
+        launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor);
+        if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
+        hipLaunchKernelGGL(clc::lm_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
+                           h->d_state, opt, d_trace, d_trace_cap, h->d_mailbox);
+      }
       ++launched;
       continue;
     }
@@ -643,32 +658,46 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   hipLaunchKernelGGL(clc::batched_init_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
                      opt, h->d_poses, (int)P);
   CLC_HIP(hipGetLastError());
-  const int sync_interval = opt.sync_interval > 0 ? opt.sync_interval : kDefaultSyncInterval;
+  const int lookahead = opt.sync_interval > 0 ? opt.sync_interval : kDefaultLookahead;
   const int max_evals = opt.max_num_iterations + 1;
-  unsigned int* h_active = reinterpret_cast<unsigned int*>(h->h_small + 48);
+  clc::HostMailbox* mb = h->h_mailbox;
+  mb->n_done = 0;
+  mb->status = CLC_RUNNING;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  CLC_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), h->stream));
+  CLC_HIP(hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned int), h->stream));
   int launched = 0;
-  bool done = false;
-  while (!done && launched < max_evals) {
-    const bool check = ((launched + 1) % sync_interval == 0) || (launched + 1 == max_evals);
-    if (check) CLC_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), h->stream));
-    if (opt.use_loss)
-      hipLaunchKernelGGL((clc::batched_eval_kernel<true>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
-                         h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
-                         opt.loss_scale_factor, h->d_bpartials);
-    else
-      hipLaunchKernelGGL((clc::batched_eval_kernel<false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
-                         h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
-                         opt.loss_scale_factor, h->d_bpartials);
-    hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
-                       h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue);
-    ++launched;
-    if (check) {
-      CLC_HIP(hipGetLastError());
-      CLC_HIP(hipMemcpyAsync(h_active, h->d_queue, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
-      CLC_HIP(hipStreamSynchronize(h->stream));
-      if (*h_active == 0) done = true;
+  long long spins = 0;
+  int last_done = 0;
+  auto t_last_progress = std::chrono::steady_clock::now();
+  for (;;) {
+    if (__atomic_load_n(&mb->status, __ATOMIC_ACQUIRE) != CLC_RUNNING) break;
+    const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
+    if (launched < max_evals && launched - done < lookahead) {
+      if (opt.use_loss)
+        hipLaunchKernelGGL((clc::batched_eval_kernel<true>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
+                           h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
+                           opt.loss_scale_factor, h->d_bpartials);
+      else
+        hipLaunchKernelGGL((clc::batched_eval_kernel<false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
+                           h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
+                           opt.loss_scale_factor, h->d_bpartials);
+      hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
+                         h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue, h->d_ticket, launched,
+                         h->d_mailbox);
+      ++launched;
+      continue;
+    }
+    if (launched >= max_evals && done >= launched) break;  // iteration cap reached for the stragglers
+    if (done != last_done) { last_done = done; t_last_progress = std::chrono::steady_clock::now(); spins = 0; }
+    if ((++spins & 0xFFFF) == 0) {
+      hipError_t e = hipStreamQuery(h->stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(CLC_ERR_HIP, "clc_solve_batched: stream error", e);
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last_progress).count();
+      if (waited > 60.0) return fail(CLC_ERR_HIP, "clc_solve_batched: no progress from the device for 60 s");
     }
   }
+  CLC_HIP(hipGetLastError());
   hipLaunchKernelGGL(clc::batched_finish_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
                      (int)P, h->d_poses, h->d_summaries);
   CLC_HIP(hipGetLastError());

@@ -310,6 +310,7 @@ __global__ void retile_batched_kernel(const double* __restrict__ aos,
 constexpr int FLAG_REDUCE_SHUFFLE = 1;  // reference wave reduction instead of the butterfly
 constexpr int FLAG_PREFETCH = 2;        // software-pipelined tile loads (next tile in flight while computing)
 constexpr int FLAG_NONTEMPORAL = 4;     // nt loads for the streamed tiles
+constexpr int FLAG_FUSED_LM = 8;        // clc_solve: controller in the tail of the evaluation launch
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -338,26 +339,15 @@ __device__ __forceinline__ void accumulate_tile(const PoseU& P, double inv_lf2, 
                                               f[5].y, f[6].y, f[7].y, acc);
 }
 
+// The streaming loop shared by every evaluation kernel: wave `wave_global` of `n_waves`
+// consumes tiles wave_global, wave_global + n_waves, ... of an array of n records (whole tiles
+// + one ragged, zero-padded tile that is masked by index).
 template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT>
-__global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ tiles,
-                                                     const long long n,
-                                                     const double* __restrict__ pose,
-                                                     const int32_t* __restrict__ status,
-                                                     const double lf, const int reduce_mode,
-                                                     double* __restrict__ partials) {
-  if (status != nullptr && *status != CLC_RUNNING) return;
-  PoseU P;
-  load_pose(pose, P);
-  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
-  double acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-
-  const int lane = threadIdx.x & 63;
-  const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-  const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
+__device__ __forceinline__ void stream_tiles(const double* __restrict__ tiles, const long long n,
+                                             const long long wave_global, const long long n_waves,
+                                             const int lane, const PoseU& P, const double inv_lf2,
+                                             double (&acc)[NACC]) {
   const long long n_full = n / TILE;
-
   if (PREFETCH) {
     // two register buffers; the loads of tile t+n_waves are in flight while tile t is consumed
     double2 fa[8], fb[8];
@@ -391,6 +381,26 @@ __global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ 
       accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
                                                   f[5].y, f[6].y, f[7].y, acc);
   }
+}
+
+template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT>
+__global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ tiles,
+                                                     const long long n,
+                                                     const double* __restrict__ pose,
+                                                     const int32_t* __restrict__ status,
+                                                     const double lf, const int reduce_mode,
+                                                     double* __restrict__ partials) {
+  if (status != nullptr && *status != CLC_RUNNING) return;
+  PoseU P;
+  load_pose(pose, P);
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
+  stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wave_global, n_waves, lane, P, inv_lf2, acc);
   block_reduce_store<BLOCK / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 
@@ -447,29 +457,36 @@ struct HostMailbox {
   long long prof[8];  // shader-clock stamps of the last lm_kernel launch (debug/profiling)
 };
 
-__global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ partials,
-                                                   int n_blocks, LmState* __restrict__ state,
-                                                   const clc_options opt,
-                                                   clc_iteration* __restrict__ trace,
-                                                   int trace_cap, HostMailbox* mailbox) {
-  __shared__ double red[BLOCK / 32][32];
-  __shared__ double sh_state[LM_STATE_WORDS];
+// Tail shared by lm_kernel (own launch) and eval_lm_kernel (last-arriving workgroup of the
+// evaluation launch): fixed-order reduction of the block partials + LM controller + publish.
+// COHERENT: read partials with agent-scope (sc1) loads — required when they were produced by
+// other workgroups of the SAME launch.
+template <bool COHERENT>
+__device__ __forceinline__ double load_partial(const double* p) {
+  if (COHERENT)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int n_blocks,
+                                        LmState* __restrict__ state, const clc_options& opt,
+                                        clc_iteration* __restrict__ trace, int trace_cap,
+                                        HostMailbox* mailbox, double (*red)[32], double* sh_state,
+                                        const long long c0) {
   static_assert(LM_STATE_WORDS <= BLOCK, "one state word per thread");
-  const long long c0 = clock64();
-  // Issue every global load of this kernel before the first use: termination flag, the
-  // thread's word of the LM state and its share of the block partials (fixed order: thread
-  // (c, rg) owns rows rg, rg+8, ... of column c).  One memory latency instead of four.
+  // Issue every global load before the first use: the thread's word of the LM state and its
+  // share of the block partials (fixed order: thread (c, rg) owns rows rg, rg+8, ... of column
+  // c).  One memory latency instead of several.
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   constexpr int RG = BLOCK / 32, UNROLL = 32;
-  const int32_t status = state->status;
   const double my_word = threadIdx.x < LM_STATE_WORDS ? reinterpret_cast<const double*>(state)[threadIdx.x] : 0.0;
   double v[UNROLL];
 #pragma unroll
   for (int j = 0; j < UNROLL; ++j) {
     const int b = rg + RG * j;
-    v[j] = (c < NACC && b < n_blocks) ? partials[(size_t)b * NACC + c] : 0.0;
+    v[j] = (c < NACC && b < n_blocks) ? load_partial<COHERENT>(partials + (size_t)b * NACC + c) : 0.0;
   }
-  if (status != CLC_RUNNING) return;
   if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = my_word;
   double s = 0.0;
 #pragma unroll
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) {
       const int b = b0 + RG * j;
-      v[j] = (c < NACC && b < n_blocks) ? partials[(size_t)b * NACC + c] : 0.0;
+      v[j] = (c < NACC && b < n_blocks) ? load_partial<COHERENT>(partials + (size_t)b * NACC + c) : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) s += v[j];
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
     if (mailbox != nullptr) {
       mailbox->prof[0] = c0; mailbox->prof[1] = c1; mailbox->prof[2] = c2;
       if (st.status != CLC_RUNNING) {
-        // termination: payload first, then ONE system-scope release, then the flags
+        // termination: payload first, then system-scope release stores of the flags
         clc_summary sm;
         lm_fill_summary(st, sm);
         sm.solve_ms = 0.0;
@@ -525,12 +542,86 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
   if (threadIdx.x < LM_STATE_WORDS) reinterpret_cast<double*>(state)[threadIdx.x] = sh_state[threadIdx.x];
 }
 
+__global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ partials,
+                                                   int n_blocks, LmState* __restrict__ state,
+                                                   const clc_options opt,
+                                                   clc_iteration* __restrict__ trace,
+                                                   int trace_cap, HostMailbox* mailbox) {
+  __shared__ double red[BLOCK / 32][32];
+  __shared__ double sh_state[LM_STATE_WORDS];
+  const long long c0 = clock64();
+  if (state->status != CLC_RUNNING) return;
+  lm_tail<false>(partials, n_blocks, state, opt, trace, trace_cap, mailbox, red, sh_state, c0);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1+K2 fused — evaluation launch whose LAST-ARRIVING workgroup runs the reduction + LM
+// controller, so one LM iteration is ONE launch.  Inter-workgroup hand-off (placement
+// independent, MI355X per-XCD L2s are not coherent):
+//   producer: partial row stored write-through (agent-scope relaxed atomic stores = sc1),
+//             every storing wave drains vmcnt(0), workgroup barrier, ONE lane takes a ticket
+//             with a relaxed agent-scope fetch_add;
+//   consumer: the workgroup that draws ticket == gridDim-1 reads all rows with agent-scope
+//             (sc1) loads, which bypass its CU's L1 — no stale lines possible.
+// The ticket counter is reset by the last workgroup (all others have already arrived) and is
+// zeroed by lm_init_kernel before the first launch of a solve.
+// ---------------------------------------------------------------------------------------
+template <bool WITH_LOSS, bool NT>
+__global__ __launch_bounds__(BLOCK) void eval_lm_kernel(const double* __restrict__ tiles,
+                                                        const long long n, LmState* __restrict__ state,
+                                                        const clc_options opt,
+                                                        double* __restrict__ partials,
+                                                        unsigned int* __restrict__ ticket_counter,
+                                                        clc_iteration* __restrict__ trace, int trace_cap,
+                                                        HostMailbox* mailbox) {
+  __shared__ double red[BLOCK / 32][32];
+  __shared__ double sh_state[LM_STATE_WORDS];
+  __shared__ double wsum[BLOCK / 64][NACC];
+  __shared__ int sh_last;
+  if (state->status != CLC_RUNNING) return;
+  PoseU P;
+  load_pose(state->x_eval, P);
+  const double lf = opt.loss_scale_factor;
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + wave;
+  const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
+  stream_tiles<WITH_LOSS, true, true, NT>(tiles, n, wave_global, n_waves, lane, P, inv_lf2, acc);
+  wave_reduce_butterfly(acc, wsum[wave], lane);
+  __syncthreads();
+  // ---- publish this workgroup's partial row (write-through) and take a ticket ----
+  if (threadIdx.x < NACC) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) s += wsum[w][threadIdx.x];
+    __hip_atomic_store(partials + (size_t)blockIdx.x * NACC + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every (storing) wave: stores acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(ticket_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  // ---- last-arriving workgroup: every other row is complete and visible at agent scope ----
+  const long long c0 = clock64();
+  if (threadIdx.x == 0) __hip_atomic_store(ticket_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  lm_tail<true>(partials, (int)gridDim.x, state, opt, trace, trace_cap, mailbox, red, sh_state, c0);
+}
+
 struct Pose7 {
   double v[7];
 };
 
-__global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0) {
+__global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0,
+                               unsigned int* __restrict__ ticket_counter) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *ticket_counter = 0u;
     LmState s;
     lm_init(s, opt, pose0.v);
     *state = s;
@@ -704,36 +795,12 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
   const int lane = threadIdx.x & 63;
   const long long wave_global = (long long)j * (BLOCK / 64) + (threadIdx.x >> 6);
   const long long n_waves = (long long)blocks_per_problem * (BLOCK / 64);
-  const double* ptiles = tiles + tile_off[prob] * TILE_DOUBLES;
-  const long long n = n_obs[prob];
-  const long long n_full = n / TILE;
-  for (long long tile = wave_global; tile < n_full; tile += n_waves) {
-    const double2* base = reinterpret_cast<const double2*>(ptiles + tile * TILE_DOUBLES) + lane;
-    double2 f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
-    accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
-                                            f[6].x, f[7].x, acc);
-    accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
-                                            f[6].y, f[7].y, acc);
-  }
-  const int rem = (int)(n % TILE);
-  if (rem != 0 && wave_global == (n_full % n_waves)) {
-    const double2* base = reinterpret_cast<const double2*>(ptiles + n_full * TILE_DOUBLES) + lane;
-    double2 f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = base[k * 64];
-    if (2 * lane < rem)
-      accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].x, f[1].x, f[2].x, f[3].x, f[4].x, f[5].x,
-                                              f[6].x, f[7].x, acc);
-    if (2 * lane + 1 < rem)
-      accumulate_observation<WITH_LOSS, true>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y, f[5].y,
-                                              f[6].y, f[7].y, acc);
-  }
+  stream_tiles<WITH_LOSS, true, true, true>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wave_global,
+                                            n_waves, lane, P, inv_lf2, acc);
   block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
 }
 
-__global__ void batched_init_kernel(LmState* __restrict__ states, const clc_options opt,
+__global__ __launch_bounds__(64) void batched_init_kernel(LmState* __restrict__ states, const clc_options opt,
                                     const double* __restrict__ poses, int n_problems) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_problems) return;
@@ -745,24 +812,45 @@ __global__ void batched_init_kernel(LmState* __restrict__ states, const clc_opti
 }
 
 // One thread per problem: fixed-order sum of the problem's block partials, then the LM
-// controller.  *active counts the problems that still need another evaluation.
-__global__ void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
+// controller.  The workgroups count the problems that still need another evaluation; the
+// last-arriving workgroup (ticket pattern, agent-scope atomics) publishes that count and the
+// iteration index to the pinned host mailbox, so the host can run launch-ahead without
+// blocking (status flips to non-zero when no problem is left running).
+__global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
                                   LmState* __restrict__ states, const clc_options opt,
-                                  const int n_problems, unsigned int* __restrict__ active) {
+                                  const int n_problems, unsigned int* __restrict__ active,
+                                  unsigned int* __restrict__ ticket, const int launch_index,
+                                  HostMailbox* mailbox) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_problems) return;
-  if (states[p].status != CLC_RUNNING) return;
-  double tot[NACC];
-  for (int c = 0; c < NACC; ++c) tot[c] = 0.0;
-  for (int j = 0; j < blocks_per_problem; ++j) {
-    const double* pp = partials + ((size_t)p * blocks_per_problem + j) * NACC;
-    for (int c = 0; c < NACC; ++c) tot[c] += pp[c];
+  bool still_running = false;
+  if (p < n_problems && states[p].status == CLC_RUNNING) {
+    double tot[NACC];
+    for (int c = 0; c < NACC; ++c) tot[c] = 0.0;
+    for (int j = 0; j < blocks_per_problem; ++j) {
+      const double* pp = partials + ((size_t)p * blocks_per_problem + j) * NACC;
+      for (int c = 0; c < NACC; ++c) tot[c] += pp[c];
+    }
+    LmState s = states[p];
+    LmScratch w;
+    lm_advance(s, w, opt, nullptr, 0, finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
+    states[p] = s;
+    still_running = (s.status == CLC_RUNNING);
   }
-  LmState s = states[p];
-  LmScratch w;
-  lm_advance(s, w, opt, nullptr, 0, finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
-  states[p] = s;
-  if (s.status == CLC_RUNNING) atomicAdd(active, 1u);
+  if (still_running) __hip_atomic_fetch_add(active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {  // every other workgroup has added its count
+      const unsigned int a = __hip_atomic_load(active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(active, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mailbox != nullptr) {
+        __hip_atomic_store(&mailbox->n_done, (int32_t)(launch_index + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a == 0u) __hip_atomic_store(&mailbox->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 __global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_problems,

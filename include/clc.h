@@ -77,9 +77,9 @@ typedef struct clc_options {
   double gradient_tolerance;                 /* 1e-10                                        */
   double parameter_tolerance;                /* 1e-8                                         */
   /* execution knobs (no effect on results beyond reduction order) */
-  int32_t sync_interval;  /* clc_solve: launch-ahead depth (LM iterations kept queued beyond the
-                             last one the device reported done); clc_solve_batched: iterations
-                             between host checks of the active-problem count; 0 = default    */
+  int32_t sync_interval;  /* launch-ahead depth: LM iterations the host keeps queued beyond the
+                             last one the device reported done (pinned mailbox, no blocking
+                             sync); 0 = library default (2)                                  */
   int32_t profile_events; /* 1: bracket every evaluation-kernel launch with HIP events on the
                              handle's stream and report them in clc_summary                  */
 } clc_options;
@@ -127,7 +127,8 @@ void clc_destroy(clc_handle* h);
 int clc_set_stream(clc_handle* h, void* hip_stream);
 /* Tuning of the evaluation launch: grid_blocks = number of 256-thread workgroups (0 = library
  * default); flags: 1 = reference shuffle reduction instead of the butterfly, 2 = software
- * prefetch of the next tile, 4 = non-temporal loads; -1 = library default.  Results change
+ * prefetch of the next tile, 4 = non-temporal loads, 8 = clc_solve runs the LM controller in the
+ * tail of the evaluation launch (one launch per iteration); -1 = library default.  Results change
  * only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 

@@ -9,6 +9,8 @@ from camlasercalibratool_amd import simdata as sd
 S = sd.sim_fixed_count(1000, 2000, 500, noise_sigma=0.01)
 rec = clc.flatten_observations(S, False); x0 = sd.pose7_from_T(np.eye(4))
 sv = clc.Solver(0); sv.upload(rec)
+import os
+sv.set_launch(0, int(os.environ.get('CLC_FLAGS','-1')))
 for _ in range(6): r = sv.solve(x0)
 print(r.summary.num_evaluations, r.summary.solve_ms)
 PY

@@ -13,7 +13,7 @@ x0 = sd.pose7_from_T(np.eye(4))
 sv = clc.Solver(0)
 print(sv.device_info())
 res = {}
-for n_mult in (1, 8):
+for n_mult in ():
     big = np.ascontiguousarray(np.tile(rec, (n_mult, 1)))
     sv.upload(big)
     n = big.shape[0]
@@ -32,9 +32,9 @@ print("default  jac+loss %.2f us | cost-only %.2f us | no-loss %.2f us" % (
     1e3 * sv.time_eval(x0, reps=100), 1e3 * sv.time_eval(x0, reps=100, with_jacobian=False),
     1e3 * sv.time_eval(x0, reps=100, with_loss=False)))
 # solve loop: launch-ahead depth
-for flags, grid in ((0, 512), (2, 512), (0, 1024)):
+for flags, grid in ((6, 256), (14, 256), (14, 512), (6, 512)):
     sv.set_launch(grid, flags)
-    for la in (1, 2, 3, 4, 6):
+    for la in (1, 2, 3, 4):
         o = clc.default_options(); o.sync_interval = la
         for _ in range(5): sv.solve(x0, o)
         t = time.perf_counter()

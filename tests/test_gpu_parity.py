@@ -199,6 +199,31 @@ def test_solver_options_are_honoured(sv, oracle_mod):
     assert res.summary.eval_kernel_launches == res.summary.num_evaluations and res.summary.eval_kernel_ms > 0
 
 
+@pytest.mark.parametrize("grid", [0, 7, 256, 1000, 2048])
+def test_fused_controller_launch_matches_two_kernel_path(sv, oracle_mod, grid):
+    """flags bit 8: the LM controller runs in the tail of the evaluation launch (last-arriving
+    workgroup).  Must give the same solve for any grid (more or fewer workgroups than CUs, i.e.
+    any arrival order / placement), and be bitwise repeatable — a stale or torn inter-workgroup
+    hand-off would show up as run-to-run differences."""
+    S = sd.sim_fixed_count(77, 400, 500, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    sv.set_launch(grid, 6)
+    two = sv.solve(X0)
+    sv.set_launch(grid, 6 | 8)
+    first = sv.solve(X0)
+    for rep in range(60):
+        r = sv.solve(X0)
+        assert np.array_equal(r.pose, first.pose) and r.summary.final_cost == first.summary.final_cost, rep
+        assert r.summary.num_iterations == first.summary.num_iterations
+    sv.set_launch(0, -1)
+    assert np.array_equal(first.pose, two.pose) and first.summary.final_cost == two.summary.final_cost
+    assert len(first.trace) == len(two.trace) == len(ref.trace)
+    assert _dT(first.pose, ref.pose) <= T_TOL and abs(first.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert first.summary.num_iterations == ref.summary.num_iterations
+
+
 def test_c5_boundary_constraint_mixed_terms(sv, oracle_mod):
     """configs[4] (reduced): board-edge residuals (LaseCamCalCeres.cpp:258-294) mixed with the
     point residuals, same record type, same kernel."""
@@ -275,6 +300,39 @@ def test_c3_batched_problems_match_oracle(sv, oracle_mod):
         assert abs(sms[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
         if k not in (3, 7):
             assert _dT(poses[k], sd.pose7_from_T(gts[k])) < 0.05
+
+
+def test_c3_full_size_batch(sv, oracle_mod):
+    """configs[2] at full size: 1 024 independent T_cl problems x 10^4 observations (655 MB).
+    Size-independent properties on all problems (every problem terminates by convergence at a
+    cost no higher than where it started, recovers its own ground truth to the noise level, the
+    batch is permutation-equivariant) + oracle parity on a sample."""
+    P = 1024
+    probs, gts = sd.sim_batch(4242, P, 20, 500, noise_sigma=0.01)
+    recs = [clc.flatten_observations(p, False) for p in probs]
+    off = np.zeros(P + 1, dtype=np.int64)
+    off[1:] = np.cumsum([r.shape[0] for r in recs])
+    rng = np.random.default_rng(1)
+    x0 = sv.pose_plus(np.stack([sd.pose7_from_T(g) for g in gts]), rng.normal(size=(P, 6)) * 0.05)
+    sv.upload_batched(np.concatenate(recs), off)
+    poses, sms = sv.solve_batched(x0)
+    for k in range(P):
+        assert sms[k].termination in (1, 2, 3), k
+        assert sms[k].final_cost <= sms[k].initial_cost
+        assert np.abs(sd.T_from_pose7(poses[k]) - gts[k]).max() < 0.02, k
+        assert abs(np.linalg.norm(poses[k, 3:]) - 1) < 1e-14
+    for k in range(0, P, 97):
+        ref = oracle_mod.solve(recs[k], x0[k], linear_solver="qr")
+        assert sms[k].num_iterations == ref.summary.num_iterations
+        assert _dT(poses[k], ref.pose) <= T_TOL and abs(sms[k].final_cost - ref.summary.final_cost) <= COST_TOL
+    # permutation equivariance: reversing the problem order reverses the results bit for bit
+    perm = np.arange(P)[::-1]
+    off2 = np.zeros(P + 1, dtype=np.int64)
+    off2[1:] = np.cumsum([recs[i].shape[0] for i in perm])
+    sv.upload_batched(np.concatenate([recs[i] for i in perm]), off2)
+    poses2, sms2 = sv.solve_batched(x0[perm])
+    assert np.array_equal(poses2[::-1], poses)
+    assert [sms2[P - 1 - k].final_cost for k in range(P)] == [sms[k].final_cost for k in range(P)]
 
 
 def test_c2_full_size_properties_and_parity(sv, oracle_mod):
