@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--large-obs", type=int, default=8_000_000,
                     help="extra >Infinity-Cache evaluation-kernel measurement (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="testing only: map ranks onto the visible GPUs modulo their count (with --backend gloo)")
     return ap.parse_args()
 
 
@@ -64,14 +68,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    if args.oversubscribe:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    coll_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import camlasercalibratool_amd as clc
     from camlasercalibratool_amd import simdata as sd
@@ -95,8 +105,8 @@ def main():
 
     for _ in range(args.warmup):
         res = solver.solve(x0, opt)
-    result_rec = torch.zeros(12, dtype=torch.float64, device=f"cuda:{local_rank}")
-    gathered = torch.zeros(12 * world, dtype=torch.float64, device=f"cuda:{local_rank}") if dist is not None else None
+    result_rec = torch.zeros(12, dtype=torch.float64, device=coll_dev)
+    gathered = torch.zeros(12 * world, dtype=torch.float64, device=coll_dev) if dist is not None else None
     if dist is not None:
         dist.all_gather_into_tensor(gathered, result_rec)  # warm up the RCCL communicator
 
@@ -122,7 +132,7 @@ def main():
 
     # max time over ranks, summed work
     if dist is not None:
-        t = torch.tensor([elapsed, float(evals), float(iters)], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed, float(evals), float(iters)], dtype=torch.float64, device=coll_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -156,6 +166,7 @@ def main():
                 "device": dev_name,
                 "compute_units": n_cus,
             },
+            "gathered_result_records": (gathered.view(world, 12).cpu().tolist() if gathered is not None else None),
             "lm_iters_per_s": iters_total / elapsed_max,
             "lm_iterations_per_solve": res.summary.num_iterations,
             "evaluation_passes_per_solve": res.summary.num_evaluations,

@@ -364,3 +364,26 @@ def test_c2_full_size_properties_and_parity(sv, oracle_mod):
     # idempotence: solving again from the solution does not move it
     again = sv.solve(res.pose)
     assert _dT(again.pose, res.pose) < 1e-5
+
+
+def test_bench_two_rank_path_dry_run():
+    """bench.py's N>1 code path (per-rank problem, gather of result records, max-over-ranks
+    timing) with 2 ranks oversubscribing the one visible GPU and gloo standing in for RCCL."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+           "--backend", "gloo", "--oversubscribe", "--poses", "200", "--pts", "100"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    recs = d["gathered_result_records"]
+    assert len(recs) == 2 and [r[11] for r in recs] == [0.0, 1.0]
+    assert recs[0][:7] != recs[1][:7]  # two different problems
+    assert all(abs(sum(x * x for x in r[3:7]) - 1) < 1e-12 for r in recs)
