@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured achievable
 BYTES_PER_EVAL = 64     # one clc_observation record read once per evaluation
+COMPACT_BYTES_PER_EVAL = 28  # what the default (compact) layout actually streams: 24 B point + 4 B group id
 
 
 def parse():
@@ -181,10 +182,24 @@ def main():
         # solve add ~3 us of event/dispatch overhead per pair and are reported separately.
         b2b = min(solver.time_eval(x0, reps=200) for _ in range(3))
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "kernel": "clc::eval_kernel<true,true,true,true>", "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs,
+                "kernel": "clc::eval_kernel<loss=1,jac=1,prefetch=1,nt=0,compact=1>",
+                "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs,
                 "achieved": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9, "avg_kernel_ms": b2b,
                 "timing": "hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)"}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        # The default layout is a lossless re-encoding of the 64-byte records (28 B/obs): the bytes
+        # actually streamed are fewer than the algorithmic bytes the contract prices the kernel at.
+        roof["layout"] = "compact (24 B point + 4 B group id per observation; group table per scan)"
+        roof["streamed_bytes_per_launch"] = COMPACT_BYTES_PER_EVAL * n_obs
+        roof["achieved_streamed"] = COMPACT_BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9
+        roof["frac_streamed"] = roof["achieved_streamed"] / HBM_PEAK_GBS
+        # same kernel on the 64-byte tiles (clc_set_launch flags = prefetch + non-temporal)
+        solver.set_launch(0, 6)
+        b2b64 = min(solver.time_eval(x0, reps=200) for _ in range(3))
+        solver.set_launch(0, -1)
+        roof["tiled64"] = {"avg_kernel_ms": b2b64, "achieved": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9,
+                           "frac": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "note": "64-byte records streamed as stored: achieved == actual HBM rate"}
         # in-solve diagnostic: event pairs around every launch of a few extra solves
         opt_ev = clc.default_options()
         opt_ev.profile_events = 1
@@ -214,9 +229,15 @@ def main():
         solver.upload(big)
         ms = min(solver.time_eval(x0, reps=20) for _ in range(3))
         gbs = BYTES_PER_EVAL * big.shape[0] / (ms * 1e-3) / 1e9
+        solver.set_launch(0, 6)
+        ms64 = min(solver.time_eval(x0, reps=20) for _ in range(3))
+        solver.set_launch(0, -1)
         out["roofline_large"] = {"observations": int(big.shape[0]), "bytes": int(BYTES_PER_EVAL * big.shape[0]),
                                  "avg_kernel_ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": gbs / HBM_PEAK_GBS, "evals_per_s": big.shape[0] / (ms * 1e-3)}
+                                 "frac": gbs / HBM_PEAK_GBS, "evals_per_s": big.shape[0] / (ms * 1e-3),
+                                 "achieved_streamed": COMPACT_BYTES_PER_EVAL * big.shape[0] / (ms * 1e-3) / 1e9,
+                                 "tiled64": {"avg_kernel_ms": ms64, "achieved": BYTES_PER_EVAL * big.shape[0] / (ms64 * 1e-3) / 1e9,
+                                             "frac": BYTES_PER_EVAL * big.shape[0] / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         del big
         solver.upload(rec)
 

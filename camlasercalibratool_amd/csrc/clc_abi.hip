@@ -43,7 +43,7 @@ bool all_finite(const double* p, int n) {
 }
 
 constexpr int kDefaultLookahead = 2;
-constexpr int kDefaultLaunchFlags = 6;   // prefetch + non-temporal loads (clc::FLAG_*), tuned on MI355X
+constexpr int kDefaultLaunchFlags = 2 | 16;  // prefetch + compact layout (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py)
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
 constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
 
@@ -58,6 +58,13 @@ struct clc_handle {
   double* d_tiles = nullptr;
   size_t tiles_cap_bytes = 0;
   size_t n_obs = 0;
+  // compact copy of the same observations (28 B/obs), built at upload when they compress
+  double* d_ctiles = nullptr;
+  size_t ctiles_cap_bytes = 0;
+  double* d_groups = nullptr;
+  size_t groups_cap_bytes = 0;
+  long long n_groups = 0;
+  bool compact_ok = false;
   // launch geometry
   int grid_override = 0;
   int launch_flags = kDefaultLaunchFlags;
@@ -76,6 +83,12 @@ struct clc_handle {
   // batched problems
   double* d_btiles = nullptr;
   size_t btiles_cap_bytes = 0;
+  double* d_bctiles = nullptr;
+  size_t bctiles_cap_bytes = 0;
+  double* d_bgroups = nullptr;
+  size_t bgroups_cap_bytes = 0;
+  long long bn_groups = 0;
+  bool bcompact_ok = false;
   long long* d_tile_off = nullptr;
   long long* d_nobs = nullptr;
   double* d_poses = nullptr;
@@ -130,14 +143,17 @@ int ensure_events(clc_handle* h, size_t n) {
 template <bool WITH_LOSS, bool WITH_JAC>
 void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t* d_status, double lf) {
   const int fl = h->launch_flags;
-#define CLC_LAUNCH(PF, NT)                                                                              \
-  hipLaunchKernelGGL((clc::eval_kernel<WITH_LOSS, WITH_JAC, PF, NT>), dim3(grid), dim3(clc::BLOCK), 0,   \
-                     h->stream, h->d_tiles, (long long)h->n_obs, d_pose, d_status, lf, fl, h->d_partials)
+#define CLC_LAUNCH(PF, NT, CP)                                                                            \
+  hipLaunchKernelGGL((clc::eval_kernel<WITH_LOSS, WITH_JAC, PF, NT, CP>), dim3(grid), dim3(clc::BLOCK), 0, \
+                     h->stream, (CP) ? h->d_ctiles : h->d_tiles, h->d_groups, (long long)h->n_obs, d_pose, \
+                     d_status, lf, fl, h->d_partials)
   const bool pf = (fl & clc::FLAG_PREFETCH) != 0, nt = (fl & clc::FLAG_NONTEMPORAL) != 0;
-  if (pf && nt) CLC_LAUNCH(true, true);
-  else if (pf) CLC_LAUNCH(true, false);
-  else if (nt) CLC_LAUNCH(false, true);
-  else CLC_LAUNCH(false, false);
+  const bool cp = (fl & clc::FLAG_COMPACT) != 0 && h->compact_ok;
+  if (cp) { if (nt) CLC_LAUNCH(true, true, true); else CLC_LAUNCH(true, false, true); }
+  else if (pf && nt) CLC_LAUNCH(true, true, false);
+  else if (pf) CLC_LAUNCH(true, false, false);
+  else if (nt) CLC_LAUNCH(false, true, false);
+  else CLC_LAUNCH(false, false, false);
 #undef CLC_LAUNCH
 }
 
@@ -165,6 +181,81 @@ int retile_into(clc_handle* h, const double* d_aos, size_t n, double** d_tiles, 
                        *d_tiles, (long long)n, (long long)n_padded);
     CLC_HIP(hipGetLastError());
   }
+  return CLC_OK;
+}
+
+// Lossless compression of staged AoS records into the compact layout (clc_kernels.hpp): runs of
+// records with bit-identical (n, d, scale) become one group-table entry.  rec_off/tile_off
+// describe P problems (P = 1 for the single-problem array).  *ok = false (and nothing kept) when
+// the records do not compress at least 4:1 in groups, e.g. hand-made arrays without scan structure.
+int ensure_bytes(double** p, size_t* cap, size_t bytes) {
+  if (bytes <= *cap && *p) return CLC_OK;
+  if (*p) CLC_HIP(hipFree(*p));
+  *p = nullptr; *cap = 0;
+  CLC_HIP(hipMalloc(p, bytes));
+  *cap = bytes;
+  return CLC_OK;
+}
+
+int compress_records(clc_handle* h, const double* d_aos, size_t n_total, const std::vector<long long>& rec_off,
+                     const std::vector<long long>& tile_off, double** d_ct, size_t* ct_cap, double** d_gr,
+                     size_t* gr_cap, long long* n_groups_out, bool* ok) {
+  *ok = false;
+  *n_groups_out = 0;
+  const size_t P = rec_off.size() - 1;
+  if (n_total == 0 || P == 0) return CLC_OK;
+  unsigned char* d_flag = nullptr;
+  CLC_HIP(hipMalloc(&d_flag, n_total));
+  const int threads = 256;
+  hipLaunchKernelGGL(clc::group_flag_kernel, dim3((unsigned)((n_total + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, d_aos, (long long)n_total, d_flag);
+  std::vector<unsigned char> flag(n_total);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(flag.data(), d_flag, n_total, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d_flag);
+  if (e != hipSuccess) return fail(CLC_ERR_HIP, "compress_records: flags", e);
+  for (size_t k = 0; k < P; ++k)
+    if ((size_t)rec_off[k] < n_total) flag[(size_t)rec_off[k]] = 1;  // a problem never shares a group
+  std::vector<unsigned int> gid(n_total);
+  std::vector<long long> starts;
+  starts.reserve(n_total / 64 + 16);
+  for (size_t i = 0; i < n_total; ++i) {
+    if (flag[i]) starts.push_back((long long)i);
+    gid[i] = (unsigned int)(starts.size() - 1);
+  }
+  const size_t G = starts.size();
+  if (G * 4 > n_total || G > 0xFFFFFFF0ull) return CLC_OK;  // not worth it / does not fit u32
+  const size_t total_tiles = (size_t)tile_off[P];
+  int rc = ensure_bytes(d_ct, ct_cap, std::max<size_t>(total_tiles, 1) * clc::CTILE_DOUBLES * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  rc = ensure_bytes(d_gr, gr_cap, G * clc::GROUP_DOUBLES * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  unsigned int* d_gid = nullptr;
+  long long *d_starts = nullptr, *d_roff = nullptr, *d_toff = nullptr;
+  CLC_HIP(hipMalloc(&d_gid, n_total * sizeof(unsigned int)));
+  CLC_HIP(hipMalloc(&d_starts, G * sizeof(long long)));
+  CLC_HIP(hipMalloc(&d_roff, (P + 1) * sizeof(long long)));
+  CLC_HIP(hipMalloc(&d_toff, (P + 1) * sizeof(long long)));
+  e = hipMemcpy(d_gid, gid.data(), n_total * sizeof(unsigned int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_starts, starts.data(), G * sizeof(long long), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_roff, rec_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_toff, tile_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(clc::build_groups_kernel, dim3((unsigned)((G + threads - 1) / threads)), dim3(threads), 0,
+                       h->stream, d_aos, d_starts, (long long)G, *d_gr);
+    long long max_padded = 0;
+    for (size_t k = 0; k < P; ++k) max_padded = std::max(max_padded, (tile_off[k + 1] - tile_off[k]) * clc::TILE);
+    const unsigned ydim = (unsigned)std::min<long long>(4096, std::max<long long>(1, (max_padded + threads - 1) / threads));
+    hipLaunchKernelGGL(clc::build_ctiles_kernel, dim3((unsigned)P, ydim), dim3(threads), 0, h->stream, d_aos, d_gid,
+                       d_roff, d_toff, *d_ct);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
+  (void)hipFree(d_gid); (void)hipFree(d_starts); (void)hipFree(d_roff); (void)hipFree(d_toff);
+  if (e != hipSuccess) return fail(CLC_ERR_HIP, "compress_records: build", e);
+  *n_groups_out = (long long)G;
+  *ok = true;
   return CLC_OK;
 }
 
@@ -232,7 +323,7 @@ void clc_destroy(clc_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_state, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_poses, h->d_summaries, h->d_queue, h->d_states,
-                  h->d_bpartials, h->d_ticket};
+                  h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -248,7 +339,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 15)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 31)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
@@ -281,11 +372,16 @@ int clc_flatten_observations(int n_poses, const double* tag_q_wxyz, const double
 int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t n) {
   if (!h || (n > 0 && !records_dev)) return fail(CLC_ERR_INVALID_ARG, "clc_upload_device: bad argument");
   CLC_HIP(hipSetDevice(h->device));
+  h->compact_ok = false;
   int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
   if (rc != CLC_OK) return rc;
   CLC_HIP(hipStreamSynchronize(h->stream));
   h->n_obs = n;
-  return CLC_OK;
+  const std::vector<long long> rec_off = {0, (long long)n};
+  const std::vector<long long> tile_off = {0, (long long)((n + clc::TILE - 1) / clc::TILE)};
+  rc = compress_records(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, &h->d_ctiles,
+                        &h->ctiles_cap_bytes, &h->d_groups, &h->groups_cap_bytes, &h->n_groups, &h->compact_ok);
+  return rc;
 }
 
 int clc_upload(clc_handle* h, const clc_observation* records, size_t n) {
@@ -618,9 +714,15 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
                      h->d_tile_off, h->d_btiles);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  if (d_aos) (void)hipFree(d_aos);
   (void)hipFree(d_off);
+  int crc = CLC_OK;
+  h->bcompact_ok = false;
+  if (e == hipSuccess && d_aos)
+    crc = compress_records(h, d_aos, n_total, rel, tile_off, &h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups,
+                           &h->bgroups_cap_bytes, &h->bn_groups, &h->bcompact_ok);
+  if (d_aos) (void)hipFree(d_aos);
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
+  if (crc != CLC_OK) return crc;
   h->n_problems = P;
   return CLC_OK;
 }
@@ -641,7 +743,8 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   CLC_HIP(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
   // enough workgroups to fill the chip: >= 2 per CU in total, never more than one per 4 tiles
-  int bpp = (int)((2 * (size_t)h->num_cus + P - 1) / P);
+  const size_t target_blocks = h->grid_override > 0 ? (size_t)h->grid_override : 4 * (size_t)h->num_cus;
+  int bpp = (int)((target_blocks + P - 1) / P);
   const long long max_tiles = h->batch_max_tiles;
   const int bpp_cap = (int)std::max<long long>(1, max_tiles / 4);
   bpp = std::max(1, std::min(bpp, bpp_cap));
@@ -660,6 +763,8 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   CLC_HIP(hipGetLastError());
   const int lookahead = opt.sync_interval > 0 ? opt.sync_interval : kDefaultLookahead;
   const int max_evals = opt.max_num_iterations + 1;
+  const bool bcompact = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->bcompact_ok;
+  const bool bnt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
   mb->status = CLC_RUNNING;
@@ -674,14 +779,18 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     if (__atomic_load_n(&mb->status, __ATOMIC_ACQUIRE) != CLC_RUNNING) break;
     const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
     if (launched < max_evals && launched - done < lookahead) {
-      if (opt.use_loss)
-        hipLaunchKernelGGL((clc::batched_eval_kernel<true>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
-                           h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
-                           opt.loss_scale_factor, h->d_bpartials);
-      else
-        hipLaunchKernelGGL((clc::batched_eval_kernel<false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0,
-                           h->stream, h->d_btiles, h->d_tile_off, h->d_nobs, h->d_states, bpp,
-                           opt.loss_scale_factor, h->d_bpartials);
+#define CLC_LAUNCH_B(LOSS, CP, NT)                                                                          \
+  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, CP, NT>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
+                     h->stream, (CP) ? h->d_bctiles : h->d_btiles, h->d_bgroups, h->d_tile_off, h->d_nobs,    \
+                     h->d_states, bpp, opt.loss_scale_factor, h->d_bpartials)
+      if (bcompact) {
+        if (opt.use_loss) { if (bnt) CLC_LAUNCH_B(true, true, true); else CLC_LAUNCH_B(true, true, false); }
+        else { if (bnt) CLC_LAUNCH_B(false, true, true); else CLC_LAUNCH_B(false, true, false); }
+      } else {
+        if (opt.use_loss) { if (bnt) CLC_LAUNCH_B(true, false, true); else CLC_LAUNCH_B(true, false, false); }
+        else { if (bnt) CLC_LAUNCH_B(false, false, true); else CLC_LAUNCH_B(false, false, false); }
+      }
+#undef CLC_LAUNCH_B
       hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
                          h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue, h->d_ticket, launched,
                          h->d_mailbox);
@@ -726,6 +835,16 @@ int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int redu
   CLC_HIP(hipStreamSynchronize(h->stream));
   CLC_HIP(hipMemcpy(out, d + 64 * clc::NACC, sizeof(double) * clc::NACC, hipMemcpyDeviceToHost));
   (void)hipFree(d);
+  return CLC_OK;
+}
+
+// Layout report: compact[0/1] + group counts for the single-problem array and the batch.
+int clc_debug_layout(clc_handle* h, int* compact, long long* n_groups, int* bcompact, long long* bn_groups) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_layout: NULL handle");
+  if (compact) *compact = h->compact_ok ? 1 : 0;
+  if (n_groups) *n_groups = h->n_groups;
+  if (bcompact) *bcompact = h->bcompact_ok ? 1 : 0;
+  if (bn_groups) *bn_groups = h->bn_groups;
   return CLC_OK;
 }
 

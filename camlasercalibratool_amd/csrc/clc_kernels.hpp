@@ -22,6 +22,7 @@
 //   factor_kernel        per-record residual / 1x7 Jacobian rows (plug-in level parity)
 //   plus_kernel          batched PoseLocalParameterization::Plus
 //   normal9_kernel       K5: 9x9 normal equation of the closed-form initialiser
+//   group_flag/build_*   upload-time lossless compression into the compact (28 B/obs) layout
 //   batched_*_kernel     K4: independent problems in lockstep (eval + controller per iteration)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -383,8 +384,168 @@ __device__ __forceinline__ void stream_tiles(const double* __restrict__ tiles, c
   }
 }
 
-template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT>
+// ---------------------------------------------------------------------------------------
+// Compact layout.  Every record of one scan carries the same plane and
+// scale (src/LaseCamCalCeres.cpp:231,240,245), so the 64-byte records compress LOSSLESSLY into
+//   * a group table  groups[g] = {n.x, n.y, n.z, d, scale, 0}  (48 B, one entry per run of
+//     records with bit-identical (n, d, scale)), and
+//   * compact tiles of 128 points: x[128], y[128], z[128] (FP64) + gid[128] (u32) = 3 584 B,
+// i.e. 28 bytes of HBM traffic per observation instead of 64.  The arithmetic per observation
+// is unchanged (same operands, same order), so results are bitwise those of the 64-byte path.
+// ---------------------------------------------------------------------------------------
+constexpr int CTILE_DOUBLES = 3 * TILE + TILE / 2;  // 448 doubles = 3 584 B
+constexpr int GROUP_DOUBLES = 6;                    // 48 B, 16-B aligned
+constexpr int FLAG_COMPACT = 16;                    // stream the compact layout when it is available
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
+struct CTile {  // one lane's share of a compact tile: 2 points + their group ids
+  double2 p[3];
+  v2u g;
+};
+
+struct Planes2 {  // gathered group entries of the lane's 2 points
+  double nx[2], ny[2], nz[2], d[2], s[2];
+};
+
+template <bool NT>
+__device__ __forceinline__ void load_ctile(const double* __restrict__ ctiles, long long tile, int lane, CTile& c) {
+  const double* base = ctiles + tile * CTILE_DOUBLES;
+  const v2d* pb = reinterpret_cast<const v2d*>(base) + lane;
+  const v2u* gb = reinterpret_cast<const v2u*>(base + 3 * TILE) + lane;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v2d v;
+    if (NT) v = __builtin_nontemporal_load(pb + k * 64);
+    else v = pb[k * 64];
+    c.p[k].x = v[0];
+    c.p[k].y = v[1];
+  }
+  if (NT) c.g = __builtin_nontemporal_load(gb);
+  else c.g = *gb;
+}
+
+// Group-table gather: consecutive points belong to the same scan, so the 64 lanes of a wave
+// read one or two distinct 48-byte entries per instruction (broadcast out of L1/L2).
+__device__ __forceinline__ void gather_planes(const double* __restrict__ groups, const v2u g, Planes2& q) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const double* gp = groups + (size_t)g[o] * GROUP_DOUBLES;
+    const v2d a = *reinterpret_cast<const v2d*>(gp);
+    const v2d b = *reinterpret_cast<const v2d*>(gp + 2);
+    q.nx[o] = a[0]; q.ny[o] = a[1]; q.nz[o] = b[0]; q.d[o] = b[1];
+    q.s[o] = gp[4];
+  }
+}
+
+template <bool WITH_LOSS, bool WITH_JAC, int O>
+__device__ __forceinline__ void accumulate_cpoint(const PoseU& P, double inv_lf2, const CTile& c, const Planes2& q,
+                                                  double (&acc)[NACC]) {
+  accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, q.nx[O], q.ny[O], q.nz[O], q.d[O],
+                                              O == 0 ? c.p[0].x : c.p[0].y, O == 0 ? c.p[1].x : c.p[1].y,
+                                              O == 0 ? c.p[2].x : c.p[2].y, q.s[O], acc);
+}
+
+// Streaming loop over compact tiles, software-pipelined in two ways: the point/gid loads of the
+// wave's next tile are issued before the current tile is consumed, and the group gather of the
+// next tile is issued between the two observations of the current one (its gids have landed by
+// then, and the second observation's arithmetic hides the gather latency).
+template <bool WITH_LOSS, bool WITH_JAC, bool NT>
+__device__ __forceinline__ void stream_ctiles(const double* __restrict__ ctiles,
+                                              const double* __restrict__ groups, const long long n,
+                                              const long long wave_global, const long long n_waves,
+                                              const int lane, const PoseU& P, const double inv_lf2,
+                                              double (&acc)[NACC]) {
+  const long long n_full = n / TILE;
+  CTile A, B;
+  Planes2 PA, PB;
+  long long tile = wave_global;
+  bool have = tile < n_full;
+  if (have) {
+    load_ctile<NT>(ctiles, tile, lane, A);
+    gather_planes(groups, A.g, PA);
+  }
+  while (have) {
+    const long long t1 = tile + n_waves;
+    const bool has1 = t1 < n_full;
+    if (has1) load_ctile<NT>(ctiles, t1, lane, B);
+    accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, A, PA, acc);
+    if (has1) gather_planes(groups, B.g, PB);
+    accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, A, PA, acc);
+    if (!has1) break;
+    const long long t2 = t1 + n_waves;
+    const bool has2 = t2 < n_full;
+    if (has2) load_ctile<NT>(ctiles, t2, lane, A);
+    accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, B, PB, acc);
+    if (has2) gather_planes(groups, A.g, PA);
+    accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, B, PB, acc);
+    tile = t2;
+    have = has2;
+  }
+  const int rem = (int)(n % TILE);
+  if (rem != 0 && wave_global == (n_full % n_waves)) {  // ragged last tile (zero padded, gid 0)
+    load_ctile<false>(ctiles, n_full, lane, A);
+    gather_planes(groups, A.g, PA);
+    if (2 * lane < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, A, PA, acc);
+    if (2 * lane + 1 < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, A, PA, acc);
+  }
+}
+
+// upload-time helpers of the compact layout -------------------------------------------------
+// flag[k] = 1 when record k starts a new group: (n, d, scale) differ bitwise from record k-1.
+__global__ void group_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  bool nw = (k == 0);
+  if (!nw) {
+    const unsigned long long* a = reinterpret_cast<const unsigned long long*>(aos + 8 * k);
+    const unsigned long long* b = a - 8;
+    nw = (a[0] != b[0]) | (a[1] != b[1]) | (a[2] != b[2]) | (a[3] != b[3]) | (a[7] != b[7]);
+  }
+  flag[k] = nw ? 1 : 0;
+}
+
+__global__ void build_groups_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
+                                    long long n_groups, double* __restrict__ groups) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const double* r = aos + 8 * starts[g];
+  double* o = groups + g * GROUP_DOUBLES;
+  o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[7]; o[5] = 0.0;
+}
+
+// Records [rec_off[b], rec_off[b+1]) of "problem" b -> compact tiles starting at tile_off[b]
+// (single problem: one entry).  One workgroup per problem, grid-stride over y for long ones.
+__global__ void build_ctiles_kernel(const double* __restrict__ aos, const unsigned int* __restrict__ gid,
+                                    const long long* __restrict__ rec_off, const long long* __restrict__ tile_off,
+                                    double* __restrict__ ctiles) {
+  const int prob = blockIdx.x;
+  const long long r0 = rec_off[prob];
+  const long long n = rec_off[prob + 1] - r0;
+  const long long n_padded = (tile_off[prob + 1] - tile_off[prob]) * TILE;
+  double* tb = ctiles + tile_off[prob] * CTILE_DOUBLES;
+  for (long long k = (long long)blockIdx.y * blockDim.x + threadIdx.x; k < n_padded;
+       k += (long long)gridDim.y * blockDim.x) {
+    double x = 0.0, y = 0.0, z = 0.0;
+    unsigned int g = 0u;
+    if (k < n) {
+      const double* r = aos + 8 * (r0 + k);
+      x = r[4]; y = r[5]; z = r[6];
+      g = gid[r0 + k];
+    }
+    const long long t = k / TILE;
+    const int j = (int)(k % TILE);
+    double* base = tb + t * CTILE_DOUBLES;
+    base[j] = x;
+    base[TILE + j] = y;
+    base[2 * TILE + j] = z;
+    reinterpret_cast<unsigned int*>(base + 3 * TILE)[j] = g;
+  }
+}
+
+template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT, bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ tiles,
+                                                     const double* __restrict__ groups,
                                                      const long long n,
                                                      const double* __restrict__ pose,
                                                      const int32_t* __restrict__ status,
@@ -400,7 +561,10 @@ __global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ 
   const int lane = threadIdx.x & 63;
   const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
-  stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wave_global, n_waves, lane, P, inv_lf2, acc);
+  if (COMPACT)
+    stream_ctiles<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wave_global, n_waves, lane, P, inv_lf2, acc);
+  else
+    stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wave_global, n_waves, lane, P, inv_lf2, acc);
   block_reduce_store<BLOCK / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 
@@ -777,11 +941,12 @@ __global__ __launch_bounds__(BLOCK) void reduce9_kernel(const double* __restrict
 // owns tiles [tile_off[k], tile_off[k+1]) (padded to whole tiles) and n_obs[k] records; no
 // communication between problems.
 // ---------------------------------------------------------------------------------------
-template <bool WITH_LOSS>
+template <bool WITH_LOSS, bool COMPACT, bool NT>
 __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
-    const double* __restrict__ tiles, const long long* __restrict__ tile_off,
-    const long long* __restrict__ n_obs, const LmState* __restrict__ states,
-    const int blocks_per_problem, const double lf, double* __restrict__ partials) {
+    const double* __restrict__ tiles, const double* __restrict__ groups,
+    const long long* __restrict__ tile_off, const long long* __restrict__ n_obs,
+    const LmState* __restrict__ states, const int blocks_per_problem, const double lf,
+    double* __restrict__ partials) {
   const int prob = blockIdx.x / blocks_per_problem;
   const int j = blockIdx.x - prob * blocks_per_problem;
   const LmState* st = states + prob;
@@ -795,8 +960,12 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
   const int lane = threadIdx.x & 63;
   const long long wave_global = (long long)j * (BLOCK / 64) + (threadIdx.x >> 6);
   const long long n_waves = (long long)blocks_per_problem * (BLOCK / 64);
-  stream_tiles<WITH_LOSS, true, true, true>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wave_global,
-                                            n_waves, lane, P, inv_lf2, acc);
+  if (COMPACT)
+    stream_ctiles<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wave_global,
+                                         n_waves, lane, P, inv_lf2, acc);
+  else
+    stream_tiles<WITH_LOSS, true, true, NT>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wave_global,
+                                              n_waves, lane, P, inv_lf2, acc);
   block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
 }
 

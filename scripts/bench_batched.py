@@ -26,13 +26,18 @@ d = rng.normal(size=(P, 6)) * np.array([0.05, 0.05, 0.05, 0.05, 0.05, 0.05])
 x0 = sv.pose_plus(x0, d)
 sv.upload_batched(allrec, off)
 best = None
-for si in (1, 3, 2):
+import itertools
+for flags, grid, si in [(6, 1024, 2), (6, 4096, 2), (18, 1024, 2), (18, 2048, 2), (18, 4096, 2), (18, 8192, 2), (22, 4096, 2), (-1, 0, 2)]:
+    sv.set_launch(grid, flags)
     o = clc.default_options(); o.sync_interval = si
-    for rep in range(3):
-        t = time.perf_counter(); poses, sms = sv.solve_batched(x0, o); dt = time.perf_counter() - t
+    times = []
+    for rep in range(12):
+        t = time.perf_counter(); poses, sms = sv.solve_batched(x0, o); times.append(time.perf_counter() - t)
+    for rep in range(1):
+        dt = float(np.median(times))
         evals = sum(sms[k].num_evaluations * (off[k+1]-off[k]) for k in range(P))
         iters = [sms[k].num_iterations for k in range(P)]
-        line = dict(sync_interval=si, ms=dt*1e3, evals_per_s=evals/dt, problems_per_s=P/dt, iters_min=min(iters), iters_max=max(iters), iters_mean=float(np.mean(iters)),
+        line = dict(flags=flags, grid=grid, sync_interval=si, ms=dt*1e3, evals_per_s=evals/dt, problems_per_s=P/dt, iters_min=min(iters), iters_max=max(iters), iters_mean=float(np.mean(iters)),
                     GBps=64*evals/dt/1e9)
         if best is None or line["evals_per_s"] > best["evals_per_s"]: best = line
     print(json.dumps(line), flush=True)

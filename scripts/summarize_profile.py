@@ -49,7 +49,7 @@ for (k, cname), v in fetch.items():
         continue
     groups = collections.defaultdict(list)
     for x in v:
-        cls = "no-op" if x < 1000 else ("1e6 obs" if x < 100000 else "8e6 obs")
+        cls = "no-op" if x < 1000 else ("1e6 obs" if x < 60000 else "8e6 obs")
         groups[cls].append(x)
     wv = write.get((k, "WRITE_SIZE"), [0.0])
     for cls, g in groups.items():

@@ -17,7 +17,7 @@ for n_mult in ():
     big = np.ascontiguousarray(np.tile(rec, (n_mult, 1)))
     sv.upload(big)
     n = big.shape[0]
-    for flags in (0, 2, 4, 6):
+    for flags in (6, 22, 18):
         row = []
         for grid in (256, 512, 768, 1024, 1280, 1536, 2048, 4096):
             sv.set_launch(grid, flags)
@@ -32,9 +32,9 @@ print("default  jac+loss %.2f us | cost-only %.2f us | no-loss %.2f us" % (
     1e3 * sv.time_eval(x0, reps=100), 1e3 * sv.time_eval(x0, reps=100, with_jacobian=False),
     1e3 * sv.time_eval(x0, reps=100, with_loss=False)))
 # solve loop: launch-ahead depth
-for flags, grid in ((6, 256), (14, 256), (14, 512), (6, 512)):
+for flags, grid in ((6, 256), (18, 256), (18, 384), (18, 512), (22, 512)):
     sv.set_launch(grid, flags)
-    for la in (1, 2, 3, 4):
+    for la in (2, 3):
         o = clc.default_options(); o.sync_interval = la
         for _ in range(5): sv.solve(x0, o)
         t = time.perf_counter()

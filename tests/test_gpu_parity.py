@@ -102,7 +102,7 @@ def test_eval_reduction_matches_oracle_ragged_sizes(sv, oracle_mod, n, with_loss
     assert sv.num_observations == n
     pose = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)) if n % 2 else X0
     pose = oracle_mod.pose_plus(pose, rng.normal(size=6) * 0.05)
-    for flags in (0, 1, 2, 4, 6, 7):  # every kernel variant: reduction x prefetch x non-temporal
+    for flags in (0, 1, 2, 4, 6, 7, 16 | 2, 16 | 6, 16 | 7):  # reduction x prefetch x non-temporal x compact layout
         sv.set_launch(0, flags)
         c, g, H = sv.eval(pose, with_loss=with_loss)
         c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
@@ -125,6 +125,51 @@ def test_eval_is_bitwise_reproducible_and_grid_invariant_to_rounding(sv, oracle_
     c = sv.eval(X0)
     sv.set_launch(0, -1)
     assert abs(c[0] - a[0]) <= 1e-12 * abs(a[0]) and np.allclose(c[2], a[2], rtol=1e-12)
+
+
+def _layout(sv):
+    c, g, bc, bg = C.c_int(), C.c_longlong(), C.c_int(), C.c_longlong()
+    _capi.check(_capi.lib().clc_debug_layout(sv._h, C.byref(c), C.byref(g), C.byref(bc), C.byref(bg)), "clc_debug_layout")
+    return c.value, g.value, bc.value, bg.value
+
+
+def test_compact_layout_is_lossless_and_optional(sv, oracle_mod):
+    """The compact (28 B/obs) layout is a lossless re-encoding: same operands, same order ->
+    bitwise the same reduction as the 64-byte tiles.  Arrays without scan structure (every record
+    its own plane) do not compress and silently use the 64-byte path."""
+    S = sd.sim_fixed_count(3, 300, 137, noise_sigma=0.01)  # 137 pts/scan: groups straddle tiles
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    compact, n_groups, _, _ = _layout(sv)
+    assert compact == 1 and n_groups == 300
+    pose = oracle_mod.pose_plus(X0, np.array([0.1, -0.2, 0.05, 0.2, -0.1, 0.3]))
+    sv.set_launch(0, 6)
+    a = sv.eval(pose)
+    sv.set_launch(0, 6 | 16)
+    b = sv.eval(pose)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    ra = sv.solve(X0)
+    sv.set_launch(0, 6)
+    rb = sv.solve(X0)
+    sv.set_launch(0, -1)
+    assert np.array_equal(ra.pose, rb.pose) and ra.summary.final_cost == rb.summary.final_cost
+    # boundary terms: two extra single-record groups per scan (src/LaseCamCalCeres.cpp:281-288)
+    Sb = sd.sim_board_edges(5, n_poses=50, pts_per_pose=30)
+    recb = clc.flatten_observations(Sb, True, True)
+    sv.upload(recb)
+    assert _layout(sv)[:2] == (1, 150)
+    c0, g0, H0 = oracle_mod.evaluate_ne(recb, pose)
+    c1, g1, H1 = sv.eval(pose)
+    assert abs(c1 - c0) <= 1e-11 * abs(c0) and np.abs(H1 - H0).max() <= 1e-11 * np.abs(H0).max()
+    # incompressible: every record its own plane
+    rng = np.random.default_rng(0)
+    junk = rec[:5000].copy()
+    junk[:, 3] += rng.normal(size=5000) * 1e-3
+    sv.upload(junk)
+    assert _layout(sv)[0] == 0
+    c0, g0, H0 = oracle_mod.evaluate_ne(junk, pose)
+    c1, g1, H1 = sv.eval(pose)
+    assert abs(c1 - c0) <= 1e-11 * abs(c0) and np.abs(H1 - H0).max() <= 1e-11 * np.abs(H0).max()
 
 
 def test_eval_empty_and_errors(sv):
