@@ -42,34 +42,40 @@ fetch, write = pmc("fetch"), pmc("write")
 lines += ["", "## HBM traffic per launch from PMC (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate passes)", "",
           "`FETCH_SIZE`/`WRITE_SIZE` are KiB per dispatch.  HBM read bytes = 2 x FETCH_SIZE x 1024 (gfx950: wide coalesced reads are",
           "tallied at half size); write bytes = WRITE_SIZE x 1024.  Infinity-Cache hits are counted by these fabric-side counters.", "",
-          "| kernel | class | launches | FETCH_SIZE KiB (median) | read bytes (corrected) | WRITE_SIZE KiB | algorithmic bytes | traffic / algorithmic |", "|---|---|---|---|---|---|---|---|"]
+          "| kernel | class, layout | launches | FETCH_SIZE KiB (median) | read bytes (corrected) | WRITE_SIZE KiB | algorithmic bytes (64 B/obs) | traffic / algorithmic |", "|---|---|---|---|---|---|---|---|"]
 traffic = {}
 for (k, cname), v in fetch.items():
     if "eval_kernel" not in k:
         continue
+    compact = k.replace(" ", "").endswith("true>") and k.count(",") == 4   # eval_kernel<loss,jac,prefetch,nt,COMPACT>
     groups = collections.defaultdict(list)
     for x in v:
         cls = "no-op" if x < 1000 else ("1e6 obs" if x < 60000 else "8e6 obs")
         groups[cls].append(x)
     wv = write.get((k, "WRITE_SIZE"), [0.0])
-    for cls, g in groups.items():
+    for cls, g in sorted(groups.items()):
         if cls == "no-op":
             continue
-        alg = 64e6 if cls == "1e6 obs" else 512e6
+        nobs = 1e6 if cls == "1e6 obs" else 8e6
+        alg = 64 * nobs
+        layout = (28 if compact else 64) * nobs
         rd = 2 * statistics.median(g) * 1024
         wr = statistics.median(wv) * 1024
-        lines.append(f"| `{k}` | {cls} | {len(g)} | {statistics.median(g):.1f} | {rd:.4g} | {statistics.median(wv):.1f} | {alg:.4g} | {(rd + wr) / alg:.3f} |")
-        traffic[cls] = {"read_bytes": rd, "write_bytes": wr, "algorithmic_bytes": alg}
+        lines.append(f"| `{k}` | {cls}, {'compact 28 B/obs' if compact else 'tiles 64 B/obs'} | {len(g)} | {statistics.median(g):.1f} | {rd:.4g} | {statistics.median(wv):.1f} | {alg:.4g} | {(rd + wr) / alg:.3f} (vs layout bytes {layout:.3g}: {(rd + wr) / layout:.3f}) |")
+        traffic[(cls, compact)] = {"read_bytes": rd, "write_bytes": wr, "algorithmic_bytes": alg, "layout_bytes": layout}
 bl = [l for l in open(os.path.join(src, "bench_plain.log")) if l.startswith("{")]
 if bl:
     d = json.loads(bl[-1])
     lines += ["", "## bench line of the same command (un-profiled run on the same box)", "", "```json", json.dumps(d, indent=1), "```"]
     summary["bench"] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "roofline": d.get("roofline"), "roofline_large": d.get("roofline_large")}
 open(os.path.join(dst, f"{name}_summary.md"), "w").write("\n".join(lines) + "\n")
-if "1e6 obs" in traffic:
-    t = traffic["1e6 obs"]
+key = ("1e6 obs", True) if ("1e6 obs", True) in traffic else ("1e6 obs", False)
+if key in traffic:
+    t = traffic[key]
     json.dump({"hbm_bytes_per_launch": t["read_bytes"] + t["write_bytes"], "read_bytes": t["read_bytes"], "write_bytes": t["write_bytes"],
+               "layout": "compact" if key[1] else "tiled64",
                "source": f"profiles/{name}_summary.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024, median over launches",
-               "large": traffic.get("8e6 obs")}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+               "all": {f"{c}/{'compact' if cp else 'tiled64'}": v for (c, cp), v in traffic.items()}},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, f"{name}_summary.json"), "w"), indent=1)
 print("\n".join(lines[:40]))
