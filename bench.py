@@ -266,6 +266,19 @@ def main():
             "ms_per_solve": 1e3 * cpu_t / n_rep,
             "host_cpus": os.cpu_count(),
         }
+        # other CPU variants of BASELINE.md §3 (evaluation passes only, bounded): normal-equation
+        # accumulation (the GPU's formulation) on 1 thread and on the host cores OpenMP gives us
+        def _time_ne(threads, reps):
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                oracle.evaluate_ne(rec, x0, threads=threads)
+            return n_obs * reps / (time.perf_counter() - t1)
+        nthr = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0)), 64))
+        out["cpu_baseline"]["variants"] = {
+            "ne_1_thread_evals_per_s": _time_ne(1, 10),
+            "ne_openmp_evals_per_s": _time_ne(nthr, 20), "ne_openmp_threads": nthr,
+            "note": "residual+Jacobian+6x6 accumulation passes only (no QR, no LM control)",
+        }
         dT = float(np.abs(sd.T_from_pose7(res.pose) - sd.T_from_pose7(ref.pose)).max())
         out["parity"] = {
             "T_cl_max_abs_err_vs_oracle": dT,

@@ -94,6 +94,29 @@ def lib_path() -> str:
     return _build.LIB_PATH
 
 
+def _preload_process_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    SONAME as /opt/rocm's).  If this extension pulled in the system copy first, a later
+    `import torch` would find no GPUs; so when torch is installed (it is the plumbing for
+    device memory / streams / torch.distributed), its runtime is loaded first and the extension
+    binds to it.  CLC_HIP_RUNTIME=system skips this."""
+    if os.environ.get("CLC_HIP_RUNTIME", "").lower() == "system":
+        return
+    import sys
+    if "torch" in sys.modules:
+        return  # torch already brought its runtime in
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # fall back to whatever the dynamic loader resolves
+
+
 def lib():
     """Load csrc/libclc_hip.so (raises if the HIP extension has not been built)."""
     global _lib
@@ -103,6 +126,7 @@ def lib():
             raise RuntimeError(
                 f"HIP extension {path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(needs hipcc).  camlasercalibratool_amd has no CPU fallback.")
+        _preload_process_hip_runtime()
         L = C.CDLL(path)
         L.clc_last_error.restype = C.c_char_p
         L.clc_num_observations.restype = C.c_size_t

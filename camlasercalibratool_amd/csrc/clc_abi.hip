@@ -108,7 +108,10 @@ namespace {
 int eval_grid(const clc_handle* h, size_t n) {
   const long long tiles = (long long)((n + clc::TILE - 1) / clc::TILE);
   long long want = (tiles + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64);  // one tile per wave
-  long long cap = h->grid_override > 0 ? h->grid_override : (long long)kDefaultBlocksPerCU * h->num_cus;
+  // 1 workgroup per CU keeps the partial-row reduction of lm_kernel short; arrays long enough
+  // to give every wave >= 16 tiles are streamed with 2 workgroups per CU (more loads in flight).
+  const int per_cu = tiles >= 16LL * (clc::BLOCK / 64) * 2 * h->num_cus ? 2 * kDefaultBlocksPerCU : kDefaultBlocksPerCU;
+  long long cap = h->grid_override > 0 ? h->grid_override : (long long)per_cu * h->num_cus;
   if (want < 1) want = 1;
   return (int)(want < cap ? want : cap);
 }
