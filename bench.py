@@ -105,7 +105,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        res = solver.solve(x0, opt)
+        res = solver.solve(x0, opt, trace_cap=0)
     result_rec = torch.zeros(12, dtype=torch.float64, device=coll_dev)
     gathered = torch.zeros(12 * world, dtype=torch.float64, device=coll_dev) if dist is not None else None
     if dist is not None:
@@ -118,7 +118,7 @@ def main():
     k_ms = 0.0
     k_launches = 0
     for _ in range(args.steps):
-        res = solver.solve(x0, opt)
+        res = solver.solve(x0, opt, trace_cap=0)  # no iteration trace: nothing forces a stream sync
         evals += res.summary.num_evaluations * n_obs
         iters += res.summary.num_iterations
         k_ms += res.summary.eval_kernel_ms
@@ -206,7 +206,7 @@ def main():
         ev_ms, ev_n = (k_ms, k_launches)
         if ev_n == 0:
             for _ in range(10):
-                r_ev = solver.solve(x0, opt_ev)
+                r_ev = solver.solve(x0, opt_ev, trace_cap=0)
                 ev_ms += r_ev.summary.eval_kernel_ms
                 ev_n += r_ev.summary.eval_kernel_launches
         roof["in_solve_event_pair_ms"] = ev_ms / max(ev_n, 1)

@@ -118,7 +118,7 @@ class Solver:
     def solve(self, pose0: np.ndarray, options: Optional[Options] = None, trace_cap: int = 256) -> SolveResult:
         pose = np.array(pose0, dtype=np.float64).copy()
         s = Summary()
-        tr = (Iteration * max(trace_cap, 1))()
+        tr = (Iteration * trace_cap)() if trace_cap > 0 else None
         o = options or default_options()
         check(self._L.clc_solve(self._h, C.byref(o), dptr(pose), C.byref(s), tr, C.c_int(trace_cap)), "clc_solve")
         n = max(0, min(trace_cap, s.num_iterations + 1))
