@@ -5,11 +5,12 @@ The package is a thin host layer over a C-ABI shared library of hand-written HIP
 (csrc/, include/clc.h).  It mirrors the reference's call surface
 (CamLaserCalibration / CamLaserCalClosedSolution / Oberserve) and has no CPU fallback."""
 from .simdata import GenerateSimData, Oberserve, ObservationSet  # noqa: F401
-from ._capi import ClcError, Options, Summary, Iteration, TERMINATION, default_options  # noqa: F401
+from ._capi import ClcError, Options, Summary, Iteration, TERMINATION, default_line_options, default_options  # noqa: F401
 from .solver import Solver, SolveResult, flatten_observations  # noqa: F401
-from .calib import CamLaserCalibration, CamLaserCalClosedSolution, CalibrationReport  # noqa: F401
+from .calib import (CamLaserCalibration, CamLaserCalClosedSolution, CalibrationReport, LineFittingCeres,  # noqa: F401
+                    points_on_fitted_lines)
 
 __all__ = [
-    "CamLaserCalibration", "CamLaserCalClosedSolution", "Oberserve", "ObservationSet", "GenerateSimData",
+    "CamLaserCalibration", "CamLaserCalClosedSolution", "LineFittingCeres", "Oberserve", "ObservationSet", "GenerateSimData",
     "Solver", "SolveResult", "Options", "default_options", "flatten_observations", "ClcError",
 ]

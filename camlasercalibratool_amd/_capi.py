@@ -27,6 +27,7 @@ EXPORTED = [
     "clc_set_launch", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
     "clc_factor_evaluate", "clc_pose_plus", "clc_pose_plus_jacobian", "clc_eval", "clc_solve",
     "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
+    "clc_line_options_default", "clc_line_fit_batched",
 ]
 
 
@@ -161,4 +162,11 @@ def iptr(a):
 def default_options() -> Options:
     o = Options()
     lib().clc_options_default(C.byref(o))
+    return o
+
+
+def default_line_options() -> Options:
+    """Ceres defaults + LineFittingCeres' settings (10 iterations, CauchyLoss(0.05))."""
+    o = Options()
+    lib().clc_line_options_default(C.byref(o))
     return o

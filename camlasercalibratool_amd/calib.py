@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Union
 import numpy as np
 
 from . import simdata
-from ._capi import Options, TERMINATION, default_options
+from ._capi import Options, TERMINATION, default_line_options, default_options
 from .simdata import Oberserve, ObservationSet
 from .solver import SolveResult, Solver, flatten_observations
 
@@ -97,3 +97,57 @@ def CamLaserCalibration(obs: ObsLike, Tcl: np.ndarray, use_linefitting_data: boo
             print(null)
         print("\nrecover chi2: ", chi2 / 2.0)
     return CalibrationReport(res, H, b, chi2, svals, null)
+
+
+def LineFittingCeres(Points: np.ndarray, Line: np.ndarray, solver: Optional[Solver] = None,
+                     options: Optional[Options] = None) -> None:
+    """Robust 2-parameter line fit of one scan, `Line` (m0, m1 of m0 x + m1 y + 1 = 0) in/out —
+    mirror of LineFittingCeres(Points, Line), src/LaseCamCalCeres.cpp:401-433."""
+    P = np.asarray(Points, dtype=np.float64).reshape(-1, 3)
+    own = solver is None
+    sv = solver or Solver()
+    try:
+        lines, _ = sv.line_fit_batched(P[:, :2], np.array([0, P.shape[0]], dtype=np.int64),
+                                       np.asarray(Line, dtype=np.float64).reshape(1, 2), options, want_summaries=False)
+    finally:
+        if own:
+            sv.close()
+    Line[...] = lines[0]
+
+
+def points_on_fitted_lines(obs_set: ObservationSet, solver: Optional[Solver] = None,
+                           line0=(0.0, 0.0)) -> ObservationSet:
+    """The scan front-end step of main/calibr_offline.cpp:121-142 for all scans at once: fit a line
+    to every scan's `points` (batched on the GPU) and replace `points_on_line` by the two points of
+    the fitted line at the first / last scan point's abscissa (or ordinate for near-vertical lines)."""
+    S = obs_set.n_poses
+    own = solver is None
+    sv = solver or Solver()
+    try:
+        lines, _ = sv.line_fit_batched(obs_set.pts[:, :2], obs_set.pts_off, np.tile(np.asarray(line0, dtype=np.float64), (S, 1)),
+                                       want_summaries=False)
+    finally:
+        if own:
+            sv.close()
+    ptl = np.zeros((2 * S, 3))
+    keep = np.ones(S, dtype=bool)
+    for i in range(S):
+        lo, hi = obs_set.pts_off[i], obs_set.pts_off[i + 1]
+        if hi - lo < 2:
+            keep[i] = False
+            continue
+        xs, ys = obs_set.pts[lo, 0], obs_set.pts[lo, 1]
+        xe, ye = obs_set.pts[hi - 1, 0], obs_set.pts[hi - 1, 1]
+        m0, m1 = lines[i]
+        if abs(xe - xs) > abs(ye - ys):   # :126-131
+            ys = -(xs * m0 + 1) / m1
+            ye = -(xe * m0 + 1) / m1
+        else:                             # :132-136
+            xs = -(ys * m1 + 1) / m0
+            xe = -(ye * m1 + 1) / m0
+        ptl[2 * i] = (xs, ys, 0.0)
+        ptl[2 * i + 1] = (xe, ye, 0.0)
+    ptl_off = np.zeros(S + 1, dtype=np.int64)
+    ptl_off[1:] = np.cumsum(np.where(keep, 2, 0))
+    ptl = ptl[np.repeat(keep, 2)]
+    return ObservationSet(obs_set.tag_q, obs_set.tag_t, obs_set.pts_off, obs_set.pts, ptl_off, np.ascontiguousarray(ptl))

@@ -824,6 +824,69 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   return CLC_OK;
 }
 
+// ---- line fitting ---------------------------------------------------------------------------
+void clc_line_options_default(clc_options* o) {
+  clc_options_default(o);
+  if (!o) return;
+  o->max_num_iterations = 10;   // src/LaseCamCalCeres.cpp:425
+  o->loss_scale_factor = 0.05;  // CauchyLoss(0.05), :416 (no per-residual scale here)
+}
+
+int clc_line_fit_batched(clc_handle* h, const clc_options* opt_in, const double* xy, const int64_t* offsets,
+                         size_t n_scans, double* lines, clc_summary* summaries) {
+  if (!h || !offsets || !lines || (n_scans > 0 && offsets[n_scans] > offsets[0] && !xy))
+    return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched: bad argument");
+  clc_options opt;
+  if (opt_in) opt = *opt_in; else clc_line_options_default(&opt);
+  if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched: max_num_iterations < 0");
+  if (opt.use_loss && !(opt.loss_scale_factor > 0.0))
+    return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched: loss_scale_factor must be > 0");
+  if (n_scans == 0) return CLC_OK;
+  if (n_scans > 0x7FFFFFF0ull) return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched: too many scans");
+  for (size_t k = 0; k < n_scans; ++k)
+    if (offsets[k + 1] < offsets[k]) return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched: offsets not monotone");
+  for (size_t i = 0; i < 2 * n_scans; ++i)
+    if (!std::isfinite(lines[i])) return fail(CLC_ERR_NONFINITE, "clc_line_fit_batched: non-finite initial line");
+  CLC_HIP(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t n_pts = (size_t)(offsets[n_scans] - offsets[0]);
+  std::vector<long long> rel(n_scans + 1);
+  for (size_t k = 0; k <= n_scans; ++k) rel[k] = offsets[k] - offsets[0];
+  double *d_xy = nullptr, *d_lines = nullptr;
+  long long* d_off = nullptr;
+  clc_summary* d_sum = nullptr;
+  CLC_HIP(hipMalloc(&d_xy, std::max<size_t>(n_pts, 1) * 2 * sizeof(double)));
+  CLC_HIP(hipMalloc(&d_off, (n_scans + 1) * sizeof(long long)));
+  CLC_HIP(hipMalloc(&d_lines, n_scans * 2 * sizeof(double)));
+  if (summaries) CLC_HIP(hipMalloc(&d_sum, n_scans * sizeof(clc_summary)));
+  hipError_t e = hipSuccess;
+  if (n_pts > 0) e = hipMemcpyAsync(d_xy, xy + 2 * offsets[0], n_pts * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_off, rel.data(), (n_scans + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_lines, lines, n_scans * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    const unsigned blocks = (unsigned)((n_scans + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64));
+    if (opt.use_loss)
+      hipLaunchKernelGGL((clc::line_fit_kernel<true>), dim3(blocks), dim3(clc::BLOCK), 0, h->stream, d_xy, d_off,
+                         (int)n_scans, opt, d_lines, d_sum);
+    else
+      hipLaunchKernelGGL((clc::line_fit_kernel<false>), dim3(blocks), dim3(clc::BLOCK), 0, h->stream, d_xy, d_off,
+                         (int)n_scans, opt, d_lines, d_sum);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(lines, d_lines, n_scans * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && summaries)
+    e = hipMemcpyAsync(summaries, d_sum, n_scans * sizeof(clc_summary), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d_xy); (void)hipFree(d_off); (void)hipFree(d_lines);
+  if (d_sum) (void)hipFree(d_sum);
+  if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_line_fit_batched", e);
+  if (summaries) {
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t k = 0; k < n_scans; ++k) summaries[k].solve_ms = ms;
+  }
+  return CLC_OK;
+}
+
 // ---- test hooks --------------------------------------------------------------------------
 // Runs only the wavefront reduction on in[64*28] -> out[28] (reduce_mode 0 butterfly, 1 shuffle).
 int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int reduce_mode) {

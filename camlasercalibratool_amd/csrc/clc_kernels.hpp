@@ -1036,4 +1036,75 @@ __global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_
   summaries[p] = sm;
 }
 
+// ---------------------------------------------------------------------------------------
+// K6 — LineFittingCeres batched over scans (src/LaseCamCalCeres.cpp:385-433).
+// One wavefront per scan runs the whole <= 10-iteration LM loop in-kernel: the lanes stride over
+// the scan's points (residual m0 x + m1 y + 1, Jacobian [x, y], Cauchy loss a, corrector as in K1),
+// an xor-butterfly leaves the identical {H00, H01, H11, g0, g1, cost} in every lane, and every
+// lane runs the 2-parameter controller redundantly in registers (SIMT: same cost as one lane, no
+// broadcast).  A scan is ~10^2 points = a few KiB re-read from L1/L2 per iteration: latency-bound,
+// parallel over scans (4 scans per workgroup).
+// ---------------------------------------------------------------------------------------
+template <bool WITH_LOSS>
+__global__ __launch_bounds__(BLOCK) void line_fit_kernel(const double* __restrict__ xy,
+                                                         const long long* __restrict__ off, const int n_scans,
+                                                         const clc_options opt, double* __restrict__ lines,
+                                                         clc_summary* __restrict__ summaries) {
+  const int scan = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (scan >= n_scans) return;
+  const double2* pts = reinterpret_cast<const double2*>(xy) + off[scan];
+  const long long n = off[scan + 1] - off[scan];
+  using M = Euclid2Manifold;
+  LmStateT<M> st;
+  LmScratchT<M> w;
+  const double x0[2] = {lines[2 * (size_t)scan], lines[2 * (size_t)scan + 1]};
+  lm_init(st, opt, x0);
+  const double a = opt.loss_scale_factor;
+  const double inv_b = 1.0 / (a * a);
+  while (st.status == CLC_RUNNING) {
+    const double m0 = st.x_eval[0], m1 = st.x_eval[1];
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // H00 H01 H11 g0 g1 cost
+    for (long long k = lane; k < n; k += 64) {
+      const double2 p = pts[k];
+      const double r = fma(m0, p.x, fma(m1, p.y, 1.0));  // :391
+      double wt = 1.0;
+      if (WITH_LOSS) {
+        const double sum = fma(r * r, inv_b, 1.0);
+        acc[5] += log_ge1(sum);
+        wt = fmax(2.2250738585072014e-308, fast_rcp(sum));
+      } else {
+        acc[5] = fma(r, r, acc[5]);
+      }
+      const double wx = wt * p.x, wy = wt * p.y;
+      acc[0] = fma(wx, p.x, acc[0]);
+      acc[1] = fma(wx, p.y, acc[1]);
+      acc[2] = fma(wy, p.y, acc[2]);
+      acc[3] = fma(wx, r, acc[3]);
+      acc[4] = fma(wy, r, acc[4]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double v = acc[i];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);  // commutative pairs: all lanes bitwise equal
+      acc[i] = v;
+    }
+    const double cost = WITH_LOSS ? 0.5 * (a * a) * acc[5] : 0.5 * acc[5];
+    lm_advance(st, w, opt, nullptr, 0, cost, acc + 3, acc);
+  }
+  if (lane == 0) {
+    lines[2 * (size_t)scan] = st.x_out[0];
+    lines[2 * (size_t)scan + 1] = st.x_out[1];
+    if (summaries != nullptr) {
+      clc_summary sm;
+      lm_fill_summary(st, sm);
+      sm.solve_ms = 0.0;
+      sm.eval_kernel_ms = 0.0;
+      sm.eval_kernel_launches = 0;
+      summaries[scan] = sm;
+    }
+  }
+}
+
 }  // namespace clc

@@ -70,40 +70,45 @@ CLC_HD void pose_plus_rcp(const double* x, const double* delta, double* out) {
   out[6] = w * inv;
 }
 
-CLC_HD double norm7(const double* x) {
+template <int N>
+CLC_HD double norm_n(const double* x) {
   double s = 0.0;
-  CLC_ROLLED for (int i = 0; i < 7; ++i) s += x[i] * x[i];
+  CLC_ROLLED for (int i = 0; i < N; ++i) s += x[i] * x[i];
   return sqrt(s);
 }
+CLC_HD double norm7(const double* x) { return norm_n<7>(x); }
 
-// index of (a,b), a<=b, in the packed upper triangle (row-major: 00 01 .. 05 11 ..)
-CLC_HD int tri6(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
+// index of (a,b), a<=b, in the packed upper triangle of an N x N matrix (row-major: 00 01 .. 11 ..)
+template <int N>
+CLC_HD int tri(int a, int b) { return a * N - (a * (a - 1)) / 2 + (b - a); }
+CLC_HD int tri6(int a, int b) { return tri<6>(a, b); }
 
-// Solve A y = b for symmetric positive definite 6x6 A (row-major). false if a pivot <= 0.
+// Solve A y = b for symmetric positive definite N x N A (row-major). false if a pivot <= 0.
 // One reciprocal square root per column (the serial controller is division-latency bound on
-// the GPU); L holds the factor with the INVERSE diagonal on its diagonal.  L (36), z (6) scratch.
-CLC_HD bool chol6_solve(const double* A, const double* b, double* y, double* L, double* z) {
-  CLC_ROLLED for (int j = 0; j < 6; ++j) {
-    double d = A[6 * j + j];
-    CLC_ROLLED for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+// the GPU); L holds the factor with the INVERSE diagonal on its diagonal.  L (N*N), z (N) scratch.
+template <int N>
+CLC_HD bool chol_solve(const double* A, const double* b, double* y, double* L, double* z) {
+  CLC_ROLLED for (int j = 0; j < N; ++j) {
+    double d = A[N * j + j];
+    CLC_ROLLED for (int k = 0; k < j; ++k) d -= L[N * j + k] * L[N * j + k];
     if (!(d > 0.0)) return false;
     const double inv = 1.0 / sqrt(d);
-    L[6 * j + j] = inv;
-    CLC_ROLLED for (int i = j + 1; i < 6; ++i) {
-      double s = A[6 * i + j];
-      CLC_ROLLED for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
-      L[6 * i + j] = s * inv;
+    L[N * j + j] = inv;
+    CLC_ROLLED for (int i = j + 1; i < N; ++i) {
+      double s = A[N * i + j];
+      CLC_ROLLED for (int k = 0; k < j; ++k) s -= L[N * i + k] * L[N * j + k];
+      L[N * i + j] = s * inv;
     }
   }
-  CLC_ROLLED for (int i = 0; i < 6; ++i) {
+  CLC_ROLLED for (int i = 0; i < N; ++i) {
     double s = b[i];
-    CLC_ROLLED for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
-    z[i] = s * L[6 * i + i];
+    CLC_ROLLED for (int k = 0; k < i; ++k) s -= L[N * i + k] * z[k];
+    z[i] = s * L[N * i + i];
   }
-  CLC_ROLLED for (int i = 5; i >= 0; --i) {
+  CLC_ROLLED for (int i = N - 1; i >= 0; --i) {
     double s = z[i];
-    CLC_ROLLED for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
-    y[i] = s * L[6 * i + i];
+    CLC_ROLLED for (int k = i + 1; k < N; ++k) s -= L[N * k + i] * y[k];
+    y[i] = s * L[N * i + i];
   }
   return true;
 }

@@ -8,7 +8,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _capi
-from ._capi import Iteration, Options, Summary, TERMINATION, check, default_options, dptr, iptr
+from ._capi import Iteration, Options, Summary, TERMINATION, check, default_line_options, default_options, dptr, iptr
 
 
 @dataclass
@@ -156,6 +156,20 @@ class Solver:
         o = options or default_options()
         check(self._L.clc_solve_batched(self._h, C.byref(o), dptr(poses), sm), "clc_solve_batched")
         return poses, sm
+
+    # ---- scan line fitting ----
+    def line_fit_batched(self, xy: np.ndarray, offsets: np.ndarray, lines0: np.ndarray,
+                         options: Optional[Options] = None, want_summaries: bool = True):
+        """LineFittingCeres for many scans: xy [M,2], CSR offsets [S+1], lines0 [S,2] -> (lines [S,2], summaries)."""
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        S = len(offsets) - 1
+        lines = np.ascontiguousarray(np.array(lines0, dtype=np.float64).reshape(S, 2)).copy()
+        sm = (Summary * S)() if want_summaries and S > 0 else None
+        o = options or default_line_options()
+        check(self._L.clc_line_fit_batched(self._h, C.byref(o), dptr(xy), iptr(offsets), C.c_size_t(S), dptr(lines), sm),
+              "clc_line_fit_batched")
+        return lines, sm
 
     # ---- test / profiling hooks ----
     def debug_wave_reduce(self, lanes: np.ndarray, reduce_mode: int) -> np.ndarray:

@@ -6,10 +6,12 @@
 // main/calibr_simulation.cpp:130 compile unchanged.  The two functions on the hot path,
 //     CamLaserCalClosedSolution()   (reference body: src/LaseCamCalCeres.cpp:112-203)
 //     CamLaserCalibration()         (reference body: src/LaseCamCalCeres.cpp:213-383)
+// and the scan front-end step next to it,
+//     LineFittingCeres()            (reference body: src/LaseCamCalCeres.cpp:401-433)
 // are defined here as thin host adapters: flatten std::vector<Oberserve> -> C-ABI (clc.h) ->
-// hand-written HIP kernels on the MI355X.  LineFittingCeres() and
-// CalibrationTool_SavePlanePoints() are out of scope (per-scan front-end fit / debug dump) and
-// stay declared only: they keep coming from the reference's own translation unit.
+// hand-written HIP kernels on the MI355X.  CalibrationTool_SavePlanePoints() is out of scope
+// (debug file dump) and stays declared only: it keeps coming from the reference's own
+// translation unit.  For many scans at once use clc_line_fit_batched() directly.
 // Link with libclc_hip.so; see INTEGRATION.md.
 //
 // Conventions kept from the reference: `obs` by value; `Tlc` / `Tcl` are in/out 4x4 matrices
@@ -48,7 +50,6 @@ struct Oberserve
 };
 
 // unchanged, CPU, provided by the reference's own src/LaseCamCalCeres.cpp
-void LineFittingCeres(const std::vector<Eigen::Vector3d> Points, Eigen::Vector2d & Line);
 void CalibrationTool_SavePlanePoints(const std::vector<Oberserve> obs, const Eigen::Matrix4d Tcl, const std::string path);
 
 namespace clc_adapter {
@@ -127,6 +128,26 @@ struct Handle {  // RAII around clc_handle
 };
 
 }  // namespace clc_adapter
+
+// Robust line fit of one scan; Line = (m0, m1) of m0 x + m1 y + 1 = 0, in/out.
+// Reference: src/LaseCamCalCeres.cpp:401-433 (Cauchy 0.05, DENSE_QR, 10 iterations).
+inline void LineFittingCeres(const std::vector<Eigen::Vector3d> Points, Eigen::Vector2d & Line)
+{
+    std::vector<double> xy;
+    xy.reserve(2 * Points.size());
+    for (size_t i = 0; i < Points.size(); ++i) { xy.push_back(Points[i](0)); xy.push_back(Points[i](1)); }  // :412
+    const int64_t off[2] = {0, (int64_t)Points.size()};
+    double line[2] = {Line(0), Line(1)};                                                                     // :403
+    clc_adapter::Handle H;
+    if (!H.h) return;
+    clc_options opt; clc_line_options_default(&opt);                                                         // :416,:424-425
+    if (clc_line_fit_batched(H.h, &opt, xy.data(), off, 1, line, NULL) != CLC_OK) {
+        std::cerr << "[clc] " << clc_last_error() << std::endl;
+        return;
+    }
+    Line(0) = line[0];                                                                                       // :430-431
+    Line(1) = line[1];
+}
 
 // Closed-form initial guess of Tlc (camera -> laser).  Reference: src/LaseCamCalCeres.cpp:112-203.
 inline void CamLaserCalClosedSolution(const std::vector<Oberserve> obs, Eigen::Matrix4d &Tlc)

@@ -208,6 +208,17 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt, double* poses,
                       clc_summary* summaries);
 size_t clc_num_problems(const clc_handle* h);
 
+/* ---- scan line fitting (the step that produces points_on_line) -----------------------------
+ * LineFittingCeres, src/LaseCamCalCeres.cpp:385-433, for n_scans scans at once.  Scan k owns
+ * points [offsets[k], offsets[k+1]) of xy[2*M] (x, y of every scan point; z is not used, :412).
+ * lines[2*n_scans] is in/out = (m0, m1) of the line m0 x + m1 y + 1 = 0: initial guess in (:403),
+ * result out (:430-431).  Residual m0 x + m1 y + 1 (:391), CauchyLoss(opt->loss_scale_factor) per
+ * point (:416), the same Ceres LM semantics as clc_solve.  clc_line_options_default() = Ceres
+ * defaults with max_num_iterations = 10 and loss 0.05 (:416,:424-425).  summaries nullable. */
+void clc_line_options_default(clc_options* opt);
+int clc_line_fit_batched(clc_handle* h, const clc_options* opt, const double* xy, const int64_t* offsets,
+                         size_t n_scans, double* lines, clc_summary* summaries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,8 @@ def lib():
         L.oracle_solve.restype = C.c_int
         L.oracle_closed_form.restype = C.c_int
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_line_fit.restype = C.c_int
+        L.oracle_line_evaluate.restype = C.c_double
         _lib = L
     return _lib
 
@@ -258,3 +260,33 @@ def closed_form(obs: np.ndarray):
 
 def max_threads() -> int:
     return lib().oracle_max_threads()
+
+
+def default_line_options() -> Options:
+    """Ceres defaults + max_num_iterations = 10 (src/LaseCamCalCeres.cpp:425)."""
+    o = default_options()
+    o.max_num_iterations = 10
+    return o
+
+
+def line_evaluate(xy: np.ndarray, line, with_loss=True, loss_a=0.05):
+    """-> (cost, g[2], H3 = [H00, H01, H11]) of the line-fit problem at `line`."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    g = np.empty(2); H = np.empty(3)
+    c = lib().oracle_line_evaluate(_p(xy), C.c_longlong(xy.shape[0]), _p(np.ascontiguousarray(line, dtype=np.float64)),
+                                   C.c_int(int(with_loss)), C.c_double(loss_a), None, None, C.c_longlong(0), _p(g), _p(H))
+    return c, g, H
+
+
+def line_fit(xy: np.ndarray, line0, options: Optional[Options] = None, loss_a: float = 0.05,
+             linear_solver: str = "qr", trace_cap: int = 64) -> SolveResult:
+    """LineFittingCeres restatement (src/LaseCamCalCeres.cpp:401-433): result.pose = (m0, m1)."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    o = options or default_line_options()
+    line = np.array(line0, dtype=np.float64).copy()
+    s = Summary()
+    tr = (Iteration * trace_cap)()
+    lib().oracle_line_fit(_p(xy), C.c_longlong(xy.shape[0]), C.byref(o), C.c_double(loss_a), _p(line), C.byref(s), tr,
+                          C.c_int(trace_cap), C.c_int(0 if linear_solver == "qr" else 1))
+    n = min(trace_cap, s.num_iterations + 1)
+    return SolveResult(line, s, [tr[i] for i in range(n)])

@@ -414,11 +414,10 @@ void oracle_factor_evaluate_batch(const double* obs, long long N, const double p
 // Dense linear algebra used by the LM loop.
 // -------------------------------------------------------------------------------------
 
-// Householder QR least squares min ||A y - b||, A (m x 6) column-major ld=m, overwritten.
+// Householder QR least squares min ||A y - b||, A (m x n) column-major ld=m, overwritten.
 // Mirrors Eigen::HouseholderQR (unblocked path; make_householder + apply on the left)
 // as called by Ceres DenseQRSolver: x = A.householderQr().solve(rhs).
-static void householder_qr_solve6(double* A, long long m, double* b, double y[6]) {
-  const int n = 6;
+static void householder_qr_solve(double* A, long long m, int n, double* b, double* y) {
   for (int k = 0; k < n; ++k) {
     double* col = A + (size_t)k * m;
     double tail_sq = 0.0;
@@ -448,80 +447,91 @@ static void householder_qr_solve6(double* A, long long m, double* b, double y[6]
       }
     }
   }
-  for (int i = n - 1; i >= 0; --i) {  // back substitution with R (upper 6x6)
+  for (int i = n - 1; i >= 0; --i) {  // back substitution with R (upper n x n)
     double s = b[i];
     for (int j = i + 1; j < n; ++j) s -= A[(size_t)j * m + i] * y[j];
     y[i] = s / A[(size_t)i * m + i];
   }
 }
 
-// 6x6 SPD solve by Cholesky (normal-equation variant). Returns false if not PD.
-static bool cholesky_solve6(const double Ain[36], const double b[6], double y[6]) {
-  double L[36];
-  for (int i = 0; i < 36; ++i) L[i] = 0.0;
-  for (int j = 0; j < 6; ++j) {
-    double d = Ain[6 * j + j];
-    for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+// n x n SPD solve by Cholesky (normal-equation variant), n <= 9. Returns false if not PD.
+static bool cholesky_solve(const double* Ain, const double* b, double* y, int n) {
+  double L[81], z[9];
+  for (int i = 0; i < n * n; ++i) L[i] = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double d = Ain[n * j + j];
+    for (int k = 0; k < j; ++k) d -= L[n * j + k] * L[n * j + k];
     if (!(d > 0.0)) return false;
     const double ljj = std::sqrt(d);
-    L[6 * j + j] = ljj;
-    for (int i = j + 1; i < 6; ++i) {
-      double s = Ain[6 * i + j];
-      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
-      L[6 * i + j] = s / ljj;
+    L[n * j + j] = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double s = Ain[n * i + j];
+      for (int k = 0; k < j; ++k) s -= L[n * i + k] * L[n * j + k];
+      L[n * i + j] = s / ljj;
     }
   }
-  double z[6];
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < n; ++i) {
     double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k];
-    z[i] = s / L[6 * i + i];
+    for (int k = 0; k < i; ++k) s -= L[n * i + k] * z[k];
+    z[i] = s / L[n * i + i];
   }
-  for (int i = 5; i >= 0; --i) {
+  for (int i = n - 1; i >= 0; --i) {
     double s = z[i];
-    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * y[k];
-    y[i] = s / L[6 * i + i];
+    for (int k = i + 1; k < n; ++k) s -= L[n * k + i] * y[k];
+    y[i] = s / L[n * i + i];
   }
   return true;
 }
 
-static double norm7(const double* x) {
-  double s = 0.0;
-  for (int i = 0; i < 7; ++i) s += x[i] * x[i];
-  return std::sqrt(s);
-}
+}  // extern "C" (helpers below use C++ types)
+
+#include <functional>
+
+// A least-squares problem as Ceres sees it: `np` local / `na` ambient parameters, N residuals.
+//   eval_dense(x, res, J, ldj, g): one evaluation pass -> cost; robustified residuals res[N]
+//       (nullable), robustified local Jacobian J (N x np, column-major, leading dim ldj; nullable),
+//       gradient g[np] = J^T res (nullable).
+//   eval_ne(x, g, H): the same pass reduced to the normal equation (H packed upper triangle).
+//   plus(x, delta, out): the LocalParameterization's Plus.
+struct LmProblem {
+  int np, na;
+  long long n_res;
+  std::function<double(const double*, double*, double*, long long, double*)> eval_dense;
+  std::function<double(const double*, double*, double*)> eval_ne;
+  std::function<void(const double*, const double*, double*)> plus;
+};
 
 // -------------------------------------------------------------------------------------
 // ceres::Solve with TRUST_REGION / LEVENBERG_MARQUARDT / DENSE_QR as configured at
-// src/LaseCamCalCeres.cpp:299-307.  Control flow restates Ceres 1.13-2.1
-// TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy + TrustRegionStepEvaluator
-// (monotonic) — SURVEY.md Appendix A, with three details taken from the Ceres source
-// rather than the appendix's summary:
-//   * gradient_max_norm = ||x - Plus(x, -g)||_inf in the ambient 7-space;
+// src/LaseCamCalCeres.cpp:299-307 (pose problem) and :423-428 (line fit).  Control flow
+// restates Ceres 1.13-2.1 TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy +
+// TrustRegionStepEvaluator (monotonic) — SURVEY.md Appendix A, with three details taken from
+// the Ceres source rather than the appendix's summary:
+//   * gradient_max_norm = ||x - Plus(x, -g)||_inf in the ambient space;
 //   * an invalid step calls StepRejected(0): radius /= decrease_factor; decrease_factor *= 2;
 //   * final_cost = min over recorded iteration costs (Solver::SetSummaryFinalCost).
-// linear_solver: 0 = DENSE_QR on the dense N x 6 Jacobian (what the reference runs),
-//                1 = 6x6 normal equations + Cholesky (what the GPU path runs).
-// threads: only used by linear_solver=1 (OpenMP evaluation).
-// pose is in/out (LaseCamCalCeres.cpp:219, :311-314).
+// linear_solver: 0 = DENSE_QR on the dense N x np Jacobian (what the reference runs),
+//                1 = np x np normal equations + Cholesky (what the GPU path runs).
 // -------------------------------------------------------------------------------------
-int oracle_solve(const double* obs, long long N, const oracle_options* opt, double pose[7],
-                 oracle_summary* summary, oracle_iteration* trace, int trace_cap,
-                 int linear_solver, int threads) {
+static int lm_minimize(const LmProblem& pb, const oracle_options* opt, double* xio, oracle_summary* summary,
+                       oracle_iteration* trace, int trace_cap, int linear_solver) {
+  const int np = pb.np, na = pb.na;
+  const long long N = pb.n_res;
   const bool use_qr = (linear_solver == 0);
   std::vector<double> J, Jaug, res, rhs;
-  const long long m = N + 6;
+  const long long m = N + np;
   if (use_qr) {
-    J.resize((size_t)N * 6);
-    Jaug.resize((size_t)m * 6);
+    J.resize((size_t)N * np);
+    Jaug.resize((size_t)m * np);
     res.resize((size_t)N);
     rhs.resize((size_t)m);
   }
-  double x[7], x_cand[7], g[6], H21[21], scale[6], diag[6], step[6], delta[6];
-  for (int i = 0; i < 7; ++i) x[i] = pose[i];
-  for (int i = 0; i < 6; ++i) scale[i] = 1.0;
+  const int nh = np * (np + 1) / 2;
+  std::vector<double> x(na), x_cand(na), g(np), H(nh), scale(np, 1.0), diag(np), step(np), delta(np);
+  for (int i = 0; i < na; ++i) x[i] = xio[i];
+  auto norm_a = [&](const double* v) { double s = 0.0; for (int i = 0; i < na; ++i) s += v[i] * v[i]; return std::sqrt(s); };
   double x_cost = 0.0, candidate_cost = 0.0, model_cost_change = 0.0;
-  double x_norm = norm7(x);
+  double x_norm = norm_a(x.data());
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
   bool reuse_diagonal = false;
   int n_invalid = 0;
@@ -540,57 +550,53 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
   // EvaluateGradientAndJacobian(): evaluate at x, (iteration 0) compute Jacobi scaling,
   // scale columns, projected gradient norms.
   auto evaluate_gradient_and_jacobian = [&](bool first) {
-    if (use_qr) {
-      x_cost = oracle_evaluate(obs, N, x, opt->use_loss, opt->loss_scale_factor, res.data(),
-                               J.data(), N, g);
-    } else {
-      x_cost = oracle_evaluate_ne(obs, N, x, opt->use_loss, opt->loss_scale_factor, g, H21, threads);
-    }
+    if (use_qr) x_cost = pb.eval_dense(x.data(), res.data(), J.data(), N, g.data());
+    else x_cost = pb.eval_ne(x.data(), g.data(), H.data());
     summary->num_residual_evaluations++;
     summary->num_jacobian_evaluations++;
     if (opt->jacobi_scaling) {
       if (first) {
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < np; ++c) {
           double sq = 0.0;
           if (use_qr) {
             const double* col = J.data() + (size_t)c * N;
             for (long long k = 0; k < N; ++k) sq += col[k] * col[k];
           } else {
             int idx = 0;
-            for (int a = 0; a < c; ++a) idx += 6 - a;
-            sq = H21[idx];
+            for (int a = 0; a < c; ++a) idx += np - a;
+            sq = H[idx];
           }
           scale[c] = 1.0 / (1.0 + std::sqrt(sq));
         }
       }
       if (use_qr) {
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < np; ++c) {
           double* col = J.data() + (size_t)c * N;
           const double s = scale[c];
           for (long long k = 0; k < N; ++k) col[k] *= s;
         }
       }
     }
-    double neg_g[6], proj[7];
-    for (int c = 0; c < 6; ++c) neg_g[c] = -g[c];
-    oracle_pose_plus(x, neg_g, proj);
+    std::vector<double> neg_g(np), proj(na);
+    for (int c = 0; c < np; ++c) neg_g[c] = -g[c];
+    pb.plus(x.data(), neg_g.data(), proj.data());
     double gmax = 0.0;
-    for (int i = 0; i < 7; ++i) gmax = std::max(gmax, std::fabs(x[i] - proj[i]));
+    for (int i = 0; i < na; ++i) gmax = std::max(gmax, std::fabs(x[i] - proj[i]));
     it.gradient_max_norm = gmax;
     last_gmax = gmax;
     it.cost = x_cost;
   };
 
   // scaled normal-equation pieces for the NE variant
-  auto scaled_H = [&](double Hs[36], double gs[6]) {
+  auto scaled_H = [&](double* Hs, double* gs) {
     int idx = 0;
-    for (int a = 0; a < 6; ++a)
-      for (int b = a; b < 6; ++b) {
-        const double v = H21[idx++] * scale[a] * scale[b];
-        Hs[6 * a + b] = v;
-        Hs[6 * b + a] = v;
+    for (int a = 0; a < np; ++a)
+      for (int b = a; b < np; ++b) {
+        const double v = H[idx++] * scale[a] * scale[b];
+        Hs[np * a + b] = v;
+        Hs[np * b + a] = v;
       }
-    for (int a = 0; a < 6; ++a) gs[a] = g[a] * scale[a];
+    for (int a = 0; a < np; ++a) gs[a] = g[a] * scale[a];
   };
 
   // ---- IterationZero ----
@@ -608,7 +614,7 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
       summary->num_successful_steps++;
       if (x_cost < minimum_cost) {
         minimum_cost = x_cost;
-        for (int i = 0; i < 7; ++i) pose[i] = x[i];
+        for (int i = 0; i < na; ++i) xio[i] = x[i];
       }
     } else {
       summary->num_unsuccessful_steps++;
@@ -633,24 +639,23 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
     bool solved = true;
     if (use_qr) {
       if (!reuse_diagonal) {
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < np; ++c) {
           const double* col = J.data() + (size_t)c * N;
           double sq = 0.0;
           for (long long k = 0; k < N; ++k) sq += col[k] * col[k];
           diag[c] = std::min(std::max(sq, opt->min_lm_diagonal), opt->max_lm_diagonal);
         }
       }
-      double lm_diag[6];
-      for (int c = 0; c < 6; ++c) lm_diag[c] = std::sqrt(diag[c] / radius);
-      for (int c = 0; c < 6; ++c) {  // [J; diag(D)]
+      std::vector<double> lm_diag(np), y(np);
+      for (int c = 0; c < np; ++c) lm_diag[c] = std::sqrt(diag[c] / radius);
+      for (int c = 0; c < np; ++c) {  // [J; diag(D)]
         std::memcpy(Jaug.data() + (size_t)c * m, J.data() + (size_t)c * N, sizeof(double) * (size_t)N);
-        for (int r = 0; r < 6; ++r) Jaug[(size_t)c * m + N + r] = (r == c) ? lm_diag[c] : 0.0;
+        for (int r = 0; r < np; ++r) Jaug[(size_t)c * m + N + r] = (r == c) ? lm_diag[c] : 0.0;
       }
-      std::memcpy(rhs.data(), res.data(), sizeof(double) * (size_t)N);
-      for (int r = 0; r < 6; ++r) rhs[(size_t)N + r] = 0.0;
-      double y[6];
-      householder_qr_solve6(Jaug.data(), m, rhs.data(), y);
-      for (int c = 0; c < 6; ++c) {
+      if (N > 0) std::memcpy(rhs.data(), res.data(), sizeof(double) * (size_t)N);
+      for (int r = 0; r < np; ++r) rhs[(size_t)N + r] = 0.0;
+      householder_qr_solve(Jaug.data(), m, np, rhs.data(), y.data());
+      for (int c = 0; c < np; ++c) {
         if (!std::isfinite(y[c])) solved = false;
         step[c] = -y[c];
       }
@@ -660,36 +665,34 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
         double mcc = 0.0;
         for (long long k = 0; k < N; ++k) {
           double mr = 0.0;
-          for (int c = 0; c < 6; ++c) mr += J[(size_t)c * N + k] * step[c];
+          for (int c = 0; c < np; ++c) mr += J[(size_t)c * N + k] * step[c];
           mcc += mr * (res[k] + mr / 2.0);
         }
         model_cost_change = -mcc;
       }
     } else {
-      double Hs[36], gs[6];
+      double Hs[81], gs[9], A[81], y[9];
       scaled_H(Hs, gs);
       if (!reuse_diagonal)
-        for (int c = 0; c < 6; ++c)
-          diag[c] = std::min(std::max(Hs[6 * c + c], opt->min_lm_diagonal), opt->max_lm_diagonal);
-      double A[36];
-      for (int i = 0; i < 36; ++i) A[i] = Hs[i];
-      for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < np; ++c)
+          diag[c] = std::min(std::max(Hs[np * c + c], opt->min_lm_diagonal), opt->max_lm_diagonal);
+      for (int i = 0; i < np * np; ++i) A[i] = Hs[i];
+      for (int c = 0; c < np; ++c) {
         const double d = std::sqrt(diag[c] / radius);
-        A[6 * c + c] += d * d;
+        A[np * c + c] += d * d;
       }
-      double y[6];
-      solved = cholesky_solve6(A, gs, y);
-      for (int c = 0; c < 6; ++c) {
+      solved = cholesky_solve(A, gs, y, np);
+      for (int c = 0; c < np; ++c) {
         if (solved && !std::isfinite(y[c])) solved = false;
         step[c] = -y[c];
       }
       reuse_diagonal = true;
       if (solved) {
         double sg = 0.0, shs = 0.0;
-        for (int a = 0; a < 6; ++a) {
+        for (int a = 0; a < np; ++a) {
           sg += step[a] * gs[a];
           double row = 0.0;
-          for (int b = 0; b < 6; ++b) row += Hs[6 * a + b] * step[b];
+          for (int b = 0; b < np; ++b) row += Hs[np * a + b] * step[b];
           shs += step[a] * row;
         }
         model_cost_change = -(sg + 0.5 * shs);
@@ -712,22 +715,18 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
       continue;
     }
     n_invalid = 0;
-    for (int c = 0; c < 6; ++c) delta[c] = step[c] * scale[c];  // undo column scaling
+    for (int c = 0; c < np; ++c) delta[c] = step[c] * scale[c];  // undo column scaling
 
     // ---- ComputeCandidatePointAndEvaluateCost ----
-    oracle_pose_plus(x, delta, x_cand);
-    if (use_qr)
-      candidate_cost = oracle_evaluate(obs, N, x_cand, opt->use_loss, opt->loss_scale_factor,
-                                       nullptr, nullptr, 0, nullptr);
-    else
-      candidate_cost = oracle_evaluate_ne(obs, N, x_cand, opt->use_loss, opt->loss_scale_factor,
-                                          nullptr, nullptr, threads);
+    pb.plus(x.data(), delta.data(), x_cand.data());
+    if (use_qr) candidate_cost = pb.eval_dense(x_cand.data(), nullptr, nullptr, 0, nullptr);
+    else candidate_cost = pb.eval_ne(x_cand.data(), nullptr, nullptr);
     summary->num_residual_evaluations++;
 
     // ---- ParameterToleranceReached ----
     {
       double s = 0.0;
-      for (int i = 0; i < 7; ++i) s += (x[i] - x_cand[i]) * (x[i] - x_cand[i]);
+      for (int i = 0; i < na; ++i) s += (x[i] - x_cand[i]) * (x[i] - x_cand[i]);
       it.step_norm = std::sqrt(s);
       const double tol = opt->parameter_tolerance * (x_norm + opt->parameter_tolerance);
       if (it.step_norm <= tol) { status = ORACLE_CONVERGENCE_PARAMETER; break; }
@@ -741,8 +740,8 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
     it.relative_decrease = it.cost_change / model_cost_change;
     if (it.relative_decrease > opt->min_relative_decrease) {
       // ---- HandleSuccessfulStep ----
-      for (int i = 0; i < 7; ++i) x[i] = x_cand[i];
-      x_norm = norm7(x);
+      for (int i = 0; i < na; ++i) x[i] = x_cand[i];
+      x_norm = norm_a(x.data());
       evaluate_gradient_and_jacobian(false);
       it.step_is_successful = 1;
       const double q = 2.0 * it.relative_decrease - 1.0;  // StepAccepted
@@ -764,6 +763,77 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
   summary->num_iterations = n_trace - 1;
   summary->final_cost = std::min(summary->initial_cost, min_iter_cost);
   return status;
+}
+
+extern "C" {
+
+// ceres::Solve on the pose problem of CamLaserCalibration (src/LaseCamCalCeres.cpp:299-307).
+// threads: only used by linear_solver=1 (OpenMP evaluation).  pose is in/out (:219, :311-314).
+int oracle_solve(const double* obs, long long N, const oracle_options* opt, double pose[7],
+                 oracle_summary* summary, oracle_iteration* trace, int trace_cap,
+                 int linear_solver, int threads) {
+  LmProblem pb;
+  pb.np = 6; pb.na = 7; pb.n_res = N;
+  pb.eval_dense = [&](const double* x, double* res, double* J, long long ldj, double* g) {
+    return oracle_evaluate(obs, N, x, opt->use_loss, opt->loss_scale_factor, res, J, ldj, g);
+  };
+  pb.eval_ne = [&](const double* x, double* g, double* H) {
+    return oracle_evaluate_ne(obs, N, x, opt->use_loss, opt->loss_scale_factor, g, H, threads);
+  };
+  pb.plus = [](const double* x, const double* d, double* out) { oracle_pose_plus(x, d, out); };
+  return lm_minimize(pb, opt, pose, summary, trace, trace_cap, linear_solver);
+}
+
+// -------------------------------------------------------------------------------------
+// LineFittingCeres — src/LaseCamCalCeres.cpp:385-433.  Per scan: residual_i = m0 x_i + m1 y_i + 1
+// (LineFittingResidfual :390-391; autodiff Jacobian = [x_i, y_i]), CauchyLoss(0.05) per residual
+// (:416), DENSE_QR, max_num_iterations = 10 (:424-425), other Ceres defaults; `line` in/out
+// (:403, :430-431).  xy[n*2] are the x,y of the scan points (z is not used, :412).
+// loss_a = 0.05; opt supplies the Ceres defaults with max_num_iterations = 10.
+// -------------------------------------------------------------------------------------
+double oracle_line_evaluate(const double* xy, long long n, const double line[2], int with_loss, double loss_a,
+                            double* res, double* J, long long ldj, double* g, double* H3) {
+  double cost = 0.0, gg[2] = {0, 0}, hh[3] = {0, 0, 0};
+  const bool need_j = J || g || H3;
+  for (long long k = 0; k < n; ++k) {
+    const double x = xy[2 * k], y = xy[2 * k + 1];
+    double r = line[0] * x + line[1] * y + 1.0;  // :391
+    double j0 = x, j1 = y;
+    const double sq = r * r;
+    if (!with_loss) {
+      cost += 0.5 * sq;
+    } else {
+      double rho[3];
+      oracle_cauchy(loss_a, sq, rho);
+      cost += 0.5 * rho[0];
+      const double sr = std::sqrt(rho[1]);
+      if (need_j) { j0 *= sr; j1 *= sr; }
+      r *= sr;
+    }
+    if (res) res[k] = r;
+    if (J) { J[k] = j0; J[ldj + k] = j1; }
+    if (need_j) {
+      gg[0] += j0 * r; gg[1] += j1 * r;
+      hh[0] += j0 * j0; hh[1] += j0 * j1; hh[2] += j1 * j1;
+    }
+  }
+  if (g) { g[0] = gg[0]; g[1] = gg[1]; }
+  if (H3) { H3[0] = hh[0]; H3[1] = hh[1]; H3[2] = hh[2]; }
+  return cost;
+}
+
+int oracle_line_fit(const double* xy, long long n, const oracle_options* opt, double loss_a, double line[2],
+                    oracle_summary* summary, oracle_iteration* trace, int trace_cap, int linear_solver) {
+  LmProblem pb;
+  pb.np = 2; pb.na = 2; pb.n_res = n;
+  pb.eval_dense = [&](const double* x, double* res, double* J, long long ldj, double* g) {
+    return oracle_line_evaluate(xy, n, x, opt->use_loss, loss_a, res, J, ldj, g, nullptr);
+  };
+  pb.eval_ne = [&](const double* x, double* g, double* H) {
+    return oracle_line_evaluate(xy, n, x, opt->use_loss, loss_a, nullptr, nullptr, 0, g, H);
+  };
+  pb.plus = [](const double* x, const double* d, double* out) { out[0] = x[0] + d[0]; out[1] = x[1] + d[1]; };
+  return lm_minimize(pb, opt, line, summary, trace, trace_cap, linear_solver);
 }
 
 // -------------------------------------------------------------------------------------

@@ -62,7 +62,34 @@ int main(int argc, char** argv) {
     GenerateSimData(obs, 7u, offline_flow ? 0.01 : 0.0);
     std::cout << "obs size: " << obs.size() << std::endl;
     Eigen::Matrix4d Tlc_initial = Eigen::Matrix4d::Identity();
-    if (offline_flow) CamLaserCalClosedSolution(obs, Tlc_initial);      // calibr_offline.cpp:167
+    if (offline_flow) {
+        // calibr_offline.cpp:121-142: fit a line to every scan, keep its two end points
+        std::vector<Oberserve> kept;
+        for (size_t i = 0; i < obs.size(); ++i) {
+            const std::vector<Eigen::Vector3d>& points = obs[i].points;
+            if (points.size() < 10) continue;
+            Eigen::Vector2d line;
+            line(0) = 0.0; line(1) = 0.0;
+            LineFittingCeres(points, line);
+            double x_start = points.front().x(), x_end = points.back().x();
+            double y_start = points.front().y(), y_end = points.back().y();
+            if (std::fabs(x_end - x_start) > std::fabs(y_end - y_start)) {
+                y_start = -(x_start * line(0) + 1) / line(1);
+                y_end = -(x_end * line(0) + 1) / line(1);
+            } else {
+                x_start = -(y_start * line(1) + 1) / line(0);
+                x_end = -(y_end * line(1) + 1) / line(0);
+            }
+            Oberserve ob = obs[i];
+            ob.points_on_line.clear();
+            ob.points_on_line.push_back(Eigen::Vector3d(x_start, y_start, 0));
+            ob.points_on_line.push_back(Eigen::Vector3d(x_end, y_end, 0));
+            kept.push_back(ob);
+        }
+        obs = kept;
+        std::cout << "scans with a fitted line: " << obs.size() << std::endl;
+        CamLaserCalClosedSolution(obs, Tlc_initial);                    // calibr_offline.cpp:167
+    }
     Eigen::Matrix4d Tcl = invert(Tlc_initial);
     CamLaserCalibration(obs, Tcl, false);                               // calibr_simulation.cpp:130 / calibr_offline.cpp:170
     Eigen::Matrix4d Tlc = invert(Tcl);

@@ -411,6 +411,71 @@ def test_c2_full_size_properties_and_parity(sv, oracle_mod):
     assert _dT(again.pose, res.pose) < 1e-5
 
 
+def _scans(n_scans, seed):
+    rng = np.random.default_rng(seed)
+    xs, truth, off = [], [], [0]
+    for k in range(n_scans):
+        n = int(rng.integers(0, 4)) if k % 50 == 7 else int(rng.integers(40, 400))
+        th = rng.uniform(-1.3, 1.3); c = rng.uniform(0.8, 5.0)
+        t = np.sort(rng.uniform(-0.5, 0.5, n))
+        xy = np.stack([c * np.cos(th) - t * np.sin(th), c * np.sin(th) + t * np.cos(th)], 1) + rng.normal(size=(n, 2)) * 0.004
+        bad = rng.random(n) < 0.08
+        xy[bad] += rng.normal(size=(int(bad.sum()), 2)) * 0.3
+        xs.append(xy); truth.append([-np.cos(th) / c, -np.sin(th) / c]); off.append(off[-1] + n)
+    return np.concatenate(xs), np.array(off, dtype=np.int64), np.array(truth)
+
+
+def test_line_fit_batched_matches_oracle(sv, oracle_mod):
+    """LineFittingCeres (LaseCamCalCeres.cpp:385-433) for 600 ragged scans in one launch, against
+    the oracle's DENSE_QR restatement scan by scan (incl. empty / 1-3 point scans)."""
+    xy, off, truth = _scans(600, 11)
+    lines0 = np.zeros((600, 2))
+    lines, sms = sv.line_fit_batched(xy, off, lines0)
+    worst = 0.0
+    for k in range(600):
+        ref = oracle_mod.line_fit(xy[off[k]:off[k + 1]], lines0[k], linear_solver="qr")
+        assert sms[k].termination == ref.summary.termination, k
+        assert sms[k].num_iterations == ref.summary.num_iterations, k
+        assert np.abs(lines[k] - ref.pose).max() <= 1e-9 * max(1.0, np.abs(ref.pose).max()), k
+        assert abs(sms[k].final_cost - ref.summary.final_cost) <= 1e-12, k
+        if off[k + 1] - off[k] >= 40:
+            worst = max(worst, np.abs(lines[k] - truth[k]).max() / np.abs(truth[k]).max())
+    assert worst < 0.05
+    # options are honoured (no loss, iteration cap) and the single-scan mirror is in/out
+    o = clc.default_line_options(); o.use_loss = 0; o.max_num_iterations = 3
+    l2, s2 = sv.line_fit_batched(xy, off, lines0, o)
+    oo = oracle_mod.default_line_options(); oo.use_loss = 0; oo.max_num_iterations = 3
+    for k in (0, 5, 100):
+        ref = oracle_mod.line_fit(xy[off[k]:off[k + 1]], lines0[k], options=oo)
+        assert s2[k].num_iterations == ref.summary.num_iterations and np.abs(l2[k] - ref.pose).max() < 1e-9
+    L = np.zeros(2)
+    P3 = np.concatenate([xy[off[0]:off[1]], np.zeros((off[1] - off[0], 1))], 1)
+    clc.LineFittingCeres(P3, L, solver=sv)
+    assert np.array_equal(L, lines[0])
+
+
+def test_offline_front_end_flow_with_line_fit(sv, oracle_mod):
+    """main/calibr_offline.cpp:121-170: fit a line per scan -> two points_on_line per scan ->
+    closed form on them -> nonlinear refinement.  Everything O(points) on the GPU."""
+    S = sd.GenerateSimData(21, noise_sigma=0.005)
+    keep = (S.pts_off[1:] - S.pts_off[:-1]) >= 10
+    S = sd.ObservationSet.from_list([o for o, k in zip(S.to_list(), keep) if k])
+    S2 = clc.points_on_fitted_lines(S, solver=sv)
+    assert S2.ptl.shape[0] == 2 * S2.n_poses
+    # the two points lie on the board plane (up to noise) at the scan's end abscissae
+    rec = clc.flatten_observations(S2, True)
+    gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    r, _ = oracle_mod.factor_evaluate_batch(rec, gt, want_jac=False)
+    assert np.abs(r).max() < 0.02
+    Tlc = np.eye(4)
+    clc.CamLaserCalClosedSolution(S2, Tlc, solver=sv, verbose=False)
+    Tcl = np.linalg.inv(Tlc)
+    rep = clc.CamLaserCalibration(S2, Tcl, True, False, solver=sv, verbose=False)
+    ref = oracle_mod.solve(rec, sd.pose7_from_T(np.linalg.inv(oracle_mod.closed_form(rec)[0])))
+    assert np.abs(Tcl - sd.T_from_pose7(ref.pose)).max() <= T_TOL
+    assert np.abs(np.linalg.inv(Tcl)[:3, 3] - sd.GT_TLC).max() < 0.03
+
+
 def test_bench_two_rank_path_dry_run():
     """bench.py's N>1 code path (per-rank problem, gather of result records, max-over-ranks
     timing) with 2 ranks oversubscribing the one visible GPU and gloo standing in for RCCL."""

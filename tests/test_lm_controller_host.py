@@ -133,3 +133,47 @@ def test_shared_math_matches_oracle(shim, oracle_mod):
         assert np.abs(out - oracle_mod.pose_plus(x, d)).max() < 1e-15
         shim.shim_quat_to_rot(x[3:].copy().ctypes.data_as(dp), R.ctypes.data_as(dp))
         assert np.array_equal(R.reshape(3, 3), oracle_mod.quat_to_rot(x[3:]))
+
+
+EVAL2_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def _scan(seed, n=90, noise=0.004, outliers=0.1):
+    rng = np.random.default_rng(seed)
+    th = rng.uniform(-1.2, 1.2)
+    c = rng.uniform(1.0, 4.0)          # line at distance c from the lidar, normal direction th
+    t = np.linspace(-0.4, 0.4, n)
+    x = c * np.cos(th) - t * np.sin(th)
+    y = c * np.sin(th) + t * np.cos(th)
+    xy = np.stack([x, y], 1) + rng.normal(size=(n, 2)) * noise
+    bad = rng.random(n) < outliers
+    xy[bad] += rng.normal(size=(bad.sum(), 2)) * 0.3
+    truth = np.array([-np.cos(th) / c, -np.sin(th) / c])  # m0 x + m1 y + 1 = 0
+    return xy, truth
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_line_fit_controller_trace_matches_oracle(shim, oracle_mod, seed):
+    """The same controller template with the 2-parameter Euclidean manifold (what line_fit_kernel
+    runs per scan) against the oracle's LineFittingCeres restatement (DENSE_QR, 10 iterations)."""
+    xy, truth = _scan(seed)
+    opt = _capi.default_line_options()
+    assert opt.max_num_iterations == 10 and opt.loss_scale_factor == 0.05  # LaseCamCalCeres.cpp:416,425
+
+    def ev(line, cost, g, H):
+        c, gg, HH = oracle_mod.line_evaluate(xy, np.array([line[0], line[1]]))
+        cost[0] = c
+        g[0], g[1] = gg
+        H[0], H[1], H[2] = HH
+
+    line = np.zeros(2)
+    sm = _capi.Summary()
+    tr = (_capi.Iteration * 32)()
+    shim.shim_lm2_solve(C.byref(opt), line.ctypes.data_as(C.POINTER(C.c_double)), C.byref(sm), tr, C.c_int(32), EVAL2_FN(ev))
+    ref = oracle_mod.line_fit(xy, (0.0, 0.0), linear_solver="qr")
+    assert sm.termination == ref.summary.termination and sm.num_iterations == ref.summary.num_iterations
+    assert np.abs(line - ref.pose).max() < 1e-10 and abs(sm.final_cost - ref.summary.final_cost) < 1e-13
+    for a, b in zip([tr[i] for i in range(sm.num_iterations + 1)], ref.trace):
+        assert a.step_is_successful == b.step_is_successful
+        assert a.cost == pytest.approx(b.cost, rel=1e-10, abs=1e-16)
+    assert np.abs(line - truth).max() < 0.02 * np.abs(truth).max() + 2e-3

@@ -118,3 +118,35 @@ def test_closed_form_recovers_ground_truth(oracle_mod):
     Tn, _, _ = oracle_mod.closed_form(recn)
     r = oracle_mod.solve(recn, sd.pose7_from_T(np.linalg.inv(Tn)))
     assert r.summary.num_iterations < 12
+
+
+def test_line_fit_oracle_known_answers(oracle_mod):
+    """LineFittingCeres restatement (LaseCamCalCeres.cpp:385-433): exact on noise-free points,
+    robust to outliers, QR == normal equations, gradient of the cost by finite differences."""
+    x = np.linspace(-1, 1, 60)
+    xy = np.stack([x, 2 * x + 4], 1)                    # y = 2x + 4  <=>  0.5 x - 0.25 y + 1 = 0
+    o = oracle_mod.default_line_options()
+    o.max_num_iterations = 50
+    r = oracle_mod.line_fit(xy, (0.0, 0.0), options=o)
+    assert np.abs(r.pose - [0.5, -0.25]).max() < 1e-9 and r.summary.final_cost < 1e-16
+    r10 = oracle_mod.line_fit(xy, (0.0, 0.0))           # the reference's 10-iteration cap
+    assert r10.summary.num_iterations <= 10 and np.abs(r10.pose - [0.5, -0.25]).max() < 1e-6
+    rng = np.random.default_rng(0)
+    noisy = xy + rng.normal(size=xy.shape) * 0.005
+    noisy[::7, 1] += 0.8
+    a = oracle_mod.line_fit(noisy, (0.0, 0.0), linear_solver="qr")
+    b = oracle_mod.line_fit(noisy, (0.0, 0.0), linear_solver="ne")
+    assert a.summary.num_iterations == b.summary.num_iterations and np.abs(a.pose - b.pose).max() < 1e-12
+    assert np.abs(a.pose - [0.5, -0.25]).max() < 5e-3   # Cauchy(0.05) ignores the 0.8 m outliers
+    o2 = oracle_mod.default_line_options(); o2.use_loss = 0
+    l2 = oracle_mod.line_fit(noisy, (0.0, 0.0), options=o2)
+    assert np.abs(l2.pose - [0.5, -0.25]).max() > 3 * np.abs(a.pose - [0.5, -0.25]).max()
+    line = np.array([0.3, -0.2]); h = 1e-6
+    c, g, H = oracle_mod.line_evaluate(noisy, line)
+    for k in range(2):
+        d = np.zeros(2); d[k] = h
+        fd = (oracle_mod.line_evaluate(noisy, line + d)[0] - oracle_mod.line_evaluate(noisy, line - d)[0]) / (2 * h)
+        assert abs(fd - g[k]) < 1e-6 * max(1, abs(g[k]))
+    # empty scan: converged at iteration 0, line untouched
+    e = oracle_mod.line_fit(np.zeros((0, 2)), (0.1, 0.2))
+    assert e.summary.num_iterations == 0 and np.array_equal(e.pose, [0.1, 0.2])
