@@ -411,6 +411,28 @@ def test_c2_full_size_properties_and_parity(sv, oracle_mod):
     assert _dT(again.pose, res.pose) < 1e-5
 
 
+def test_c5_full_size_board_edge_terms(sv, oracle_mod):
+    """configs[4] at full size: 10^6 point residuals + 2 board-edge residuals per scan (1 004 000
+    records, mixed unit / un-normalised planes), same kernel."""
+    S5 = sd.sim_board_edges(5, 2000, 500, noise_sigma=0.002)
+    rec5 = clc.flatten_observations(S5, True, True)
+    assert rec5.shape[0] == 1_004_000
+    gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    x0 = oracle_mod.pose_plus(gt, np.array([0.05, -0.04, 0.03, 0.05, -0.06, 0.04]))
+    sv.upload(rec5)
+    res = sv.solve(x0)
+    ref = oracle_mod.solve(rec5, x0, linear_solver="qr")
+    assert _dT(res.pose, ref.pose) <= T_TOL and abs(res.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert res.summary.num_iterations == ref.summary.num_iterations
+    assert _dT(res.pose, gt) < 1e-4
+    # the analysis pass skips the edge terms (LaseCamCalCeres.cpp:316-362): upload the point records only
+    recp = clc.flatten_observations(S5, True, False)
+    sv.upload(recp)
+    H, b, chi2, s6, V, nn = sv.information(res.pose)
+    H0, b0, chi0, s60, V0, nn0 = oracle_mod.information(recp, res.pose)
+    assert np.allclose(H, H0, rtol=1e-11) and abs(chi2 - chi0) <= 1e-11 * chi0 and nn == nn0
+
+
 def _scans(n_scans, seed):
     rng = np.random.default_rng(seed)
     xs, truth, off = [], [], [0]
