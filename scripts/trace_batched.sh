@@ -1,6 +1,6 @@
 #!/bin/bash
 REPO=$(pwd); OUT=$REPO/gpurun_out/trace_batched; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT -o t -- python $REPO/scripts/bench_batched.py 2>&1 | grep -E "BEST" | cut -c1-200
+rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT -o t -- python $REPO/tests/tools/bench_batched.py 2>&1 | grep -E "BEST" | cut -c1-200
 cd $REPO
 python - <<PY
 import csv

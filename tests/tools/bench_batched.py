@@ -3,7 +3,7 @@
 python scripts/bench_batched.py [n_problems] [n_poses] [pts]   (default 1024 x 20 x 500 = 10k obs each)"""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import camlasercalibratool_amd as clc
 from camlasercalibratool_amd import simdata as sd
 

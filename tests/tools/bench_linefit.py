@@ -2,7 +2,7 @@
 """LineFittingCeres batched (clc_line_fit_batched) vs the CPU oracle, synthetic scans."""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import camlasercalibratool_amd as clc
 import oracle
 

@@ -3,7 +3,7 @@
 timing, one C4 shard (8192 problems x 10^4 obs = 5.2 GB, what each of 8 GPUs holds)."""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import camlasercalibratool_amd as clc
 from camlasercalibratool_amd import simdata as sd
 import oracle
