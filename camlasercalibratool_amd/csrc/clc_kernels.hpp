@@ -11,19 +11,21 @@
 // once per evaluation pass: 64 algorithmic bytes per residual+Jacobian evaluation.
 //
 // Kernels
-//   retile_kernel        AoS records -> tiles (once per upload)
-//   eval_kernel          K1: per-observation residual + analytic 6-DoF Jacobian (a3), Cauchy
-//                        corrector (a4), rank-1 accumulation of {H(21), g(6), cost} in 28 FP64
-//                        registers per lane, wave butterfly reduction (permlane32/16 swap +
-//                        DPP), LDS-staged per-wave partials, one 28-double partial per block
-//   lm_kernel            K2: fixed-order reduction of the block partials + the LM controller
-//                        (clc_lm.hpp) for the single-problem solve
-//   reduce_kernel        fixed-order reduction of block partials for clc_eval
-//   factor_kernel        per-record residual / 1x7 Jacobian rows (plug-in level parity)
-//   plus_kernel          batched PoseLocalParameterization::Plus
-//   normal9_kernel       K5: 9x9 normal equation of the closed-form initialiser
-//   group_flag/build_*   upload-time lossless compression into the compact (28 B/obs) layout
-//   batched_*_kernel     K4: independent problems in lockstep (eval + controller per iteration)
+//   retile_kernel, retile_batched_kernel      AoS records -> 64-byte tiles (once per upload)
+//   group_flag/build_groups/build_ctiles      upload-time lossless re-encoding into the compact layout
+//   eval_kernel            K1: per-observation residual + analytic 6-DoF Jacobian (a3), Cauchy
+//                          corrector (a4), rank-1 accumulation of {H(21), g(6), cost} in 28 FP64
+//                          registers per lane, wave butterfly reduction (permlane32/16 swap + DPP),
+//                          LDS-staged per-wave partials, one 28-double partial per workgroup;
+//                          template variants: loss / Jacobian / prefetch / nt loads / compact layout
+//   lm_kernel              K2: fixed-order reduction of the block partials + the LM controller
+//                          (clc_lm.hpp) for the single-problem solve; publishes to a pinned mailbox
+//   eval_lm_kernel         K1+K2 in one launch (controller in the last-arriving workgroup), optional
+//   reduce_kernel          fixed-order reduction of block partials for clc_eval
+//   batched_*_kernel       K4: independent problems in lockstep (eval + controller per iteration)
+//   normal9_kernel         K5: 9x9 normal equation of the closed-form initialiser
+//   line_fit_kernel        K6: LineFittingCeres, one wavefront per scan, LM loop in-kernel
+//   factor_kernel, plus_kernel                plug-in level parity with the Ceres callbacks
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -644,25 +646,31 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
   // c).  One memory latency instead of several.
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   constexpr int RG = BLOCK / 32, UNROLL = 32;
-  const double my_word = threadIdx.x < LM_STATE_WORDS ? reinterpret_cast<const double*>(state)[threadIdx.x] : 0.0;
+  // Loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards: a
+  // "load or 0.0" select on a runtime bound makes hipcc branch around every load and wait in
+  // between (cdna_hip_programming.md §5 trap (c)).
+  const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
+  const double my_word = reinterpret_cast<const double*>(state)[cw];
+  const int cc = c < NACC ? c : NACC - 1;
+  const int last = n_blocks - 1;
   double v[UNROLL];
 #pragma unroll
   for (int j = 0; j < UNROLL; ++j) {
     const int b = rg + RG * j;
-    v[j] = (c < NACC && b < n_blocks) ? load_partial<COHERENT>(partials + (size_t)b * NACC + c) : 0.0;
+    v[j] = load_partial<COHERENT>(partials + (size_t)(b < last ? b : last) * NACC + cc);
   }
   if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = my_word;
   double s = 0.0;
 #pragma unroll
-  for (int j = 0; j < UNROLL; ++j) s += v[j];
+  for (int j = 0; j < UNROLL; ++j) s += (c < NACC && rg + RG * j < n_blocks) ? v[j] : 0.0;
   for (int b0 = rg + RG * UNROLL; b0 < n_blocks; b0 += RG * UNROLL) {  // grids beyond 256 workgroups
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) {
       const int b = b0 + RG * j;
-      v[j] = (c < NACC && b < n_blocks) ? load_partial<COHERENT>(partials + (size_t)b * NACC + c) : 0.0;
+      v[j] = load_partial<COHERENT>(partials + (size_t)(b < last ? b : last) * NACC + cc);
     }
 #pragma unroll
-    for (int j = 0; j < UNROLL; ++j) s += v[j];
+    for (int j = 0; j < UNROLL; ++j) s += (c < NACC && b0 + RG * j < n_blocks) ? v[j] : 0.0;
   }
   red[rg][c] = s;
   __syncthreads();
