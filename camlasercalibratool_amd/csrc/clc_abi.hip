@@ -36,6 +36,17 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     if (e_ != hipSuccess) return fail(CLC_ERR_HIP, #expr, e_);        \
   } while (0)
 
+// Device allocation freed on scope exit (temporaries of one call: no leak on early error returns).
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)); }
+};
+
 bool all_finite(const double* p, int n) {
   for (int i = 0; i < n; ++i)
     if (!std::isfinite(p[i])) return false;
@@ -207,8 +218,9 @@ int compress_records(clc_handle* h, const double* d_aos, size_t n_total, const s
   *n_groups_out = 0;
   const size_t P = rec_off.size() - 1;
   if (n_total == 0 || P == 0) return CLC_OK;
-  unsigned char* d_flag = nullptr;
-  CLC_HIP(hipMalloc(&d_flag, n_total));
+  DevBuf<unsigned char> bflag;
+  CLC_HIP(bflag.alloc(n_total));
+  unsigned char* d_flag = bflag.p;
   const int threads = 256;
   hipLaunchKernelGGL(clc::group_flag_kernel, dim3((unsigned)((n_total + threads - 1) / threads)), dim3(threads), 0,
                      h->stream, d_aos, (long long)n_total, d_flag);
@@ -216,7 +228,6 @@ int compress_records(clc_handle* h, const double* d_aos, size_t n_total, const s
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(flag.data(), d_flag, n_total, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(d_flag);
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "compress_records: flags", e);
   for (size_t k = 0; k < P; ++k)
     if ((size_t)rec_off[k] < n_total) flag[(size_t)rec_off[k]] = 1;  // a problem never shares a group
@@ -234,12 +245,14 @@ int compress_records(clc_handle* h, const double* d_aos, size_t n_total, const s
   if (rc != CLC_OK) return rc;
   rc = ensure_bytes(d_gr, gr_cap, G * clc::GROUP_DOUBLES * sizeof(double));
   if (rc != CLC_OK) return rc;
-  unsigned int* d_gid = nullptr;
-  long long *d_starts = nullptr, *d_roff = nullptr, *d_toff = nullptr;
-  CLC_HIP(hipMalloc(&d_gid, n_total * sizeof(unsigned int)));
-  CLC_HIP(hipMalloc(&d_starts, G * sizeof(long long)));
-  CLC_HIP(hipMalloc(&d_roff, (P + 1) * sizeof(long long)));
-  CLC_HIP(hipMalloc(&d_toff, (P + 1) * sizeof(long long)));
+  DevBuf<unsigned int> bgid;
+  DevBuf<long long> bstarts, broff, btoff;
+  CLC_HIP(bgid.alloc(n_total));
+  CLC_HIP(bstarts.alloc(G));
+  CLC_HIP(broff.alloc(P + 1));
+  CLC_HIP(btoff.alloc(P + 1));
+  unsigned int* d_gid = bgid.p;
+  long long *d_starts = bstarts.p, *d_roff = broff.p, *d_toff = btoff.p;
   e = hipMemcpy(d_gid, gid.data(), n_total * sizeof(unsigned int), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_starts, starts.data(), G * sizeof(long long), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_roff, rec_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice);
@@ -255,7 +268,6 @@ int compress_records(clc_handle* h, const double* d_aos, size_t n_total, const s
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   }
-  (void)hipFree(d_gid); (void)hipFree(d_starts); (void)hipFree(d_roff); (void)hipFree(d_toff);
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "compress_records: build", e);
   *n_groups_out = (long long)G;
   *ok = true;
@@ -390,15 +402,12 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
 int clc_upload(clc_handle* h, const clc_observation* records, size_t n) {
   if (!h || (n > 0 && !records)) return fail(CLC_ERR_INVALID_ARG, "clc_upload: bad argument");
   CLC_HIP(hipSetDevice(h->device));
-  double* d_aos = nullptr;
+  DevBuf<double> aos;
   if (n > 0) {
-    CLC_HIP(hipMalloc(&d_aos, n * sizeof(clc_observation)));
-    hipError_t e = hipMemcpy(d_aos, records, n * sizeof(clc_observation), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d_aos); return fail(CLC_ERR_HIP, "clc_upload: hipMemcpy", e); }
+    CLC_HIP(aos.alloc(n * 8));
+    CLC_HIP(hipMemcpy(aos.p, records, n * sizeof(clc_observation), hipMemcpyHostToDevice));
   }
-  int rc = clc_upload_device(h, reinterpret_cast<const clc_observation*>(d_aos), n);
-  if (d_aos) (void)hipFree(d_aos);
-  return rc;
+  return clc_upload_device(h, reinterpret_cast<const clc_observation*>(aos.p), n);
 }
 
 size_t clc_num_observations(const clc_handle* h) { return h ? h->n_obs : 0; }
@@ -409,9 +418,10 @@ int clc_factor_evaluate(clc_handle* h, const double pose[7], double* residuals, 
   CLC_HIP(hipSetDevice(h->device));
   const size_t n = h->n_obs;
   if (n == 0) return CLC_OK;
-  double *d_r = nullptr, *d_j = nullptr;
-  CLC_HIP(hipMalloc(&d_r, n * sizeof(double)));
-  if (jacobians) CLC_HIP(hipMalloc(&d_j, n * 7 * sizeof(double)));
+  DevBuf<double> br, bj;
+  CLC_HIP(br.alloc(n));
+  if (jacobians) CLC_HIP(bj.alloc(n * 7));
+  double *d_r = br.p, *d_j = bj.p;
   std::memcpy(h->h_small, pose, 7 * sizeof(double));
   CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const int threads = 256;
@@ -421,8 +431,6 @@ int clc_factor_evaluate(clc_handle* h, const double pose[7], double* residuals, 
   CLC_HIP(hipStreamSynchronize(h->stream));
   CLC_HIP(hipMemcpy(residuals, d_r, n * sizeof(double), hipMemcpyDeviceToHost));
   if (jacobians) CLC_HIP(hipMemcpy(jacobians, d_j, n * 7 * sizeof(double), hipMemcpyDeviceToHost));
-  (void)hipFree(d_r);
-  if (d_j) (void)hipFree(d_j);
   return CLC_OK;
 }
 
@@ -430,9 +438,9 @@ int clc_pose_plus(clc_handle* h, const double* x, const double* delta, double* o
   if (!h || (n > 0 && (!x || !delta || !out))) return fail(CLC_ERR_INVALID_ARG, "clc_pose_plus: bad argument");
   if (n == 0) return CLC_OK;
   CLC_HIP(hipSetDevice(h->device));
-  double* d = nullptr;
-  CLC_HIP(hipMalloc(&d, n * 20 * sizeof(double)));
-  double *d_x = d, *d_d = d + 7 * n, *d_o = d + 13 * n;
+  DevBuf<double> buf;
+  CLC_HIP(buf.alloc(n * 20));
+  double *d_x = buf.p, *d_d = buf.p + 7 * n, *d_o = buf.p + 13 * n;
   CLC_HIP(hipMemcpy(d_x, x, n * 7 * sizeof(double), hipMemcpyHostToDevice));
   CLC_HIP(hipMemcpy(d_d, delta, n * 6 * sizeof(double), hipMemcpyHostToDevice));
   const int threads = 256;
@@ -441,7 +449,6 @@ int clc_pose_plus(clc_handle* h, const double* x, const double* delta, double* o
   CLC_HIP(hipGetLastError());
   CLC_HIP(hipStreamSynchronize(h->stream));
   CLC_HIP(hipMemcpy(out, d_o, n * 7 * sizeof(double), hipMemcpyDeviceToHost));
-  (void)hipFree(d);
   return CLC_OK;
 }
 
@@ -703,27 +710,27 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
   CLC_HIP(hipMemcpy(h->d_nobs, nobs.data(), sizeof(long long) * P, hipMemcpyHostToDevice));
   // stage the AoS records, then re-tile every problem into its own whole tiles
   const size_t n_total = (size_t)(offsets[P] - offsets[0]);
-  double* d_aos = nullptr;
-  long long* d_off = nullptr;
+  DevBuf<double> baos;
+  DevBuf<long long> boff;
   if (n_total > 0) {
-    CLC_HIP(hipMalloc(&d_aos, n_total * sizeof(clc_observation)));
-    CLC_HIP(hipMemcpy(d_aos, records + offsets[0], n_total * sizeof(clc_observation), hipMemcpyHostToDevice));
+    CLC_HIP(baos.alloc(n_total * 8));
+    CLC_HIP(hipMemcpy(baos.p, records + offsets[0], n_total * sizeof(clc_observation), hipMemcpyHostToDevice));
   }
+  double* d_aos = n_total > 0 ? baos.p : nullptr;
   std::vector<long long> rel(P + 1);
   for (size_t k = 0; k <= P; ++k) rel[k] = offsets[k] - offsets[0];
-  CLC_HIP(hipMalloc(&d_off, sizeof(long long) * (P + 1)));
+  CLC_HIP(boff.alloc(P + 1));
+  long long* d_off = boff.p;
   CLC_HIP(hipMemcpy(d_off, rel.data(), sizeof(long long) * (P + 1), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(clc::retile_batched_kernel, dim3((unsigned)P), dim3(256), 0, h->stream, d_aos, d_off,
                      h->d_tile_off, h->d_btiles);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(d_off);
   int crc = CLC_OK;
   h->bcompact_ok = false;
   if (e == hipSuccess && d_aos)
     crc = compress_records(h, d_aos, n_total, rel, tile_off, &h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups,
                            &h->bgroups_cap_bytes, &h->bn_groups, &h->bcompact_ok);
-  if (d_aos) (void)hipFree(d_aos);
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
   if (crc != CLC_OK) return crc;
   h->n_problems = P;
@@ -852,13 +859,16 @@ int clc_line_fit_batched(clc_handle* h, const clc_options* opt_in, const double*
   const size_t n_pts = (size_t)(offsets[n_scans] - offsets[0]);
   std::vector<long long> rel(n_scans + 1);
   for (size_t k = 0; k <= n_scans; ++k) rel[k] = offsets[k] - offsets[0];
-  double *d_xy = nullptr, *d_lines = nullptr;
-  long long* d_off = nullptr;
-  clc_summary* d_sum = nullptr;
-  CLC_HIP(hipMalloc(&d_xy, std::max<size_t>(n_pts, 1) * 2 * sizeof(double)));
-  CLC_HIP(hipMalloc(&d_off, (n_scans + 1) * sizeof(long long)));
-  CLC_HIP(hipMalloc(&d_lines, n_scans * 2 * sizeof(double)));
-  if (summaries) CLC_HIP(hipMalloc(&d_sum, n_scans * sizeof(clc_summary)));
+  DevBuf<double> bxy, blines;
+  DevBuf<long long> boff;
+  DevBuf<clc_summary> bsum;
+  CLC_HIP(bxy.alloc(n_pts * 2));
+  CLC_HIP(boff.alloc(n_scans + 1));
+  CLC_HIP(blines.alloc(n_scans * 2));
+  if (summaries) CLC_HIP(bsum.alloc(n_scans));
+  double *d_xy = bxy.p, *d_lines = blines.p;
+  long long* d_off = boff.p;
+  clc_summary* d_sum = bsum.p;
   hipError_t e = hipSuccess;
   if (n_pts > 0) e = hipMemcpyAsync(d_xy, xy + 2 * offsets[0], n_pts * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_off, rel.data(), (n_scans + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream);
@@ -877,8 +887,6 @@ int clc_line_fit_batched(clc_handle* h, const clc_options* opt_in, const double*
   if (e == hipSuccess && summaries)
     e = hipMemcpyAsync(summaries, d_sum, n_scans * sizeof(clc_summary), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  (void)hipFree(d_xy); (void)hipFree(d_off); (void)hipFree(d_lines);
-  if (d_sum) (void)hipFree(d_sum);
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_line_fit_batched", e);
   if (summaries) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -892,15 +900,15 @@ int clc_line_fit_batched(clc_handle* h, const clc_options* opt_in, const double*
 int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int reduce_mode) {
   if (!h || !in || !out) return fail(CLC_ERR_INVALID_ARG, "clc_debug_wave_reduce: bad argument");
   CLC_HIP(hipSetDevice(h->device));
-  double* d = nullptr;
-  CLC_HIP(hipMalloc(&d, sizeof(double) * (64 * clc::NACC + clc::NACC)));
+  DevBuf<double> buf;
+  CLC_HIP(buf.alloc(64 * clc::NACC + clc::NACC));
+  double* d = buf.p;
   CLC_HIP(hipMemcpy(d, in, sizeof(double) * 64 * clc::NACC, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(clc::wave_reduce_test_kernel, dim3(1), dim3(64), 0, h->stream, d, d + 64 * clc::NACC,
                      reduce_mode);
   CLC_HIP(hipGetLastError());
   CLC_HIP(hipStreamSynchronize(h->stream));
   CLC_HIP(hipMemcpy(out, d + 64 * clc::NACC, sizeof(double) * clc::NACC, hipMemcpyDeviceToHost));
-  (void)hipFree(d);
   return CLC_OK;
 }
 
