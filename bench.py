@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--large-obs", type=int, default=8_000_000,
                     help="extra >Infinity-Cache evaluation-kernel measurement (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-batched", action="store_true", help="skip the extra C3 (1024 problems x 1e4 obs) measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -240,6 +241,36 @@ def main():
                                              "frac": BYTES_PER_EVAL * big.shape[0] / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         del big
         solver.upload(rec)
+
+    # ---- BASELINE.json configs[2] (C3): 1 024 independent T_cl problems x 10^4 observations ----
+    if rank == 0 and world == 1 and not args.no_batched:
+        Pb = 1024
+        probs, gts = sd.sim_batch(4242, Pb, 20, 500, noise_sigma=0.01)
+        recs = [clc.flatten_observations(p, False) for p in probs]
+        offb = np.zeros(Pb + 1, dtype=np.int64)
+        offb[1:] = np.cumsum([r.shape[0] for r in recs])
+        xb = solver.pose_plus(np.stack([sd.pose7_from_T(g) for g in gts]), np.random.default_rng(1).normal(size=(Pb, 6)) * 0.05)
+        solver.upload_batched(np.concatenate(recs), offb)
+        tb = []
+        for _ in range(12):
+            t1 = time.perf_counter()
+            pb, smb = solver.solve_batched(xb)
+            tb.append(time.perf_counter() - t1)
+        dtb = float(np.median(tb[2:]))
+        evb = sum(smb[k].num_evaluations * int(offb[k + 1] - offb[k]) for k in range(Pb))
+        out["batched_c3"] = {
+            "workload": "C3: 1024 independent T_cl problems x 10000 observations (655 MB), start 5 cm / 3 deg off the truth",
+            "ms_per_batch": 1e3 * dtb, "problems_per_s": Pb / dtb, "evals_per_s": evb / dtb,
+            "lm_iterations_min_max": [min(s_.num_iterations for s_ in smb), max(s_.num_iterations for s_ in smb)],
+            "max_abs_T_err_vs_ground_truth": float(max(np.abs(sd.T_from_pose7(pb[k]) - gts[k]).max() for k in range(Pb))),
+        }
+        if not args.no_cpu_baseline:
+            import oracle as _o
+            w = 0.0
+            for k in (0, 511, 1023):
+                rk = _o.solve(recs[k], xb[k], linear_solver="qr")
+                w = max(w, float(np.abs(sd.T_from_pose7(pb[k]) - sd.T_from_pose7(rk.pose)).max()))
+            out["batched_c3"]["T_cl_max_abs_err_vs_oracle_sample"] = w
 
     # ---- CPU baseline + parity (rank 0, N=1): the oracle's DENSE_QR Ceres restatement, 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
