@@ -47,7 +47,7 @@ class Options(C.Structure):
         ("function_tolerance", C.c_double),
         ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),
-        ("sync_interval", C.c_int32),
+        ("launch_ahead", C.c_int32),
         ("profile_events", C.c_int32),
     ]
 

@@ -298,7 +298,7 @@ void clc_options_default(clc_options* o) {
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
-  o->sync_interval = 0;
+  o->launch_ahead = 0;
   o->profile_events = 0;
 }
 
@@ -519,7 +519,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // Launch-ahead depth: the host keeps this many LM iterations queued beyond the last one the
   // device has reported done (pinned mailbox), so the stream never drains and the host never
   // blocks; at most `lookahead` already-queued iterations turn into no-ops after termination.
-  const int lookahead = opt.sync_interval > 0 ? opt.sync_interval : kDefaultLookahead;
+  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
   const bool fused = (h->launch_flags & clc::FLAG_FUSED_LM) != 0;
 
   clc::HostMailbox* mb = h->h_mailbox;
@@ -771,7 +771,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   hipLaunchKernelGGL(clc::batched_init_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
                      opt, h->d_poses, (int)P);
   CLC_HIP(hipGetLastError());
-  const int lookahead = opt.sync_interval > 0 ? opt.sync_interval : kDefaultLookahead;
+  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
   const int max_evals = opt.max_num_iterations + 1;
   const bool bcompact = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->bcompact_ok;
   const bool bnt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;

@@ -77,7 +77,7 @@ typedef struct clc_options {
   double gradient_tolerance;                 /* 1e-10                                        */
   double parameter_tolerance;                /* 1e-8                                         */
   /* execution knobs (no effect on results beyond reduction order) */
-  int32_t sync_interval;  /* launch-ahead depth: LM iterations the host keeps queued beyond the
+  int32_t launch_ahead;  /* launch-ahead depth: LM iterations the host keeps queued beyond the
                              last one the device reported done (pinned mailbox, no blocking
                              sync); 0 = library default (2)                                  */
   int32_t profile_events; /* 1: bracket every evaluation-kernel launch with HIP events on the

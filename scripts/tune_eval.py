@@ -35,7 +35,7 @@ print("default  jac+loss %.2f us | cost-only %.2f us | no-loss %.2f us" % (
 for flags, grid in ((6, 256), (18, 256), (18, 384), (18, 512), (22, 512)):
     sv.set_launch(grid, flags)
     for la in (2, 3):
-        o = clc.default_options(); o.sync_interval = la
+        o = clc.default_options(); o.launch_ahead = la
         for _ in range(5): sv.solve(x0, o)
         t = time.perf_counter()
         for _ in range(50): r = sv.solve(x0, o)

@@ -228,8 +228,8 @@ def test_solver_options_are_honoured(sv, oracle_mod):
     rec = clc.flatten_observations(S, False)
     sv.upload(rec)
     for kw in [dict(max_num_iterations=3), dict(use_loss=0), dict(jacobi_scaling=0),
-               dict(initial_trust_region_radius=1e12, max_num_iterations=40), dict(sync_interval=1),
-               dict(sync_interval=7), dict(function_tolerance=1e-12, parameter_tolerance=1e-12)]:
+               dict(initial_trust_region_radius=1e12, max_num_iterations=40), dict(launch_ahead=1),
+               dict(launch_ahead=7), dict(function_tolerance=1e-12, parameter_tolerance=1e-12)]:
         o = clc.default_options()
         for k, v in kw.items():
             setattr(o, k, v)

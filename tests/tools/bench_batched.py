@@ -29,7 +29,7 @@ best = None
 import itertools
 for flags, grid, si in [(6, 1024, 2), (6, 4096, 2), (18, 1024, 2), (18, 2048, 2), (18, 4096, 2), (18, 8192, 2), (22, 4096, 2), (-1, 0, 2)]:
     sv.set_launch(grid, flags)
-    o = clc.default_options(); o.sync_interval = si
+    o = clc.default_options(); o.launch_ahead = si
     times = []
     for rep in range(12):
         t = time.perf_counter(); poses, sms = sv.solve_batched(x0, o); times.append(time.perf_counter() - t)
@@ -37,7 +37,7 @@ for flags, grid, si in [(6, 1024, 2), (6, 4096, 2), (18, 1024, 2), (18, 2048, 2)
         dt = float(np.median(times))
         evals = sum(sms[k].num_evaluations * (off[k+1]-off[k]) for k in range(P))
         iters = [sms[k].num_iterations for k in range(P)]
-        line = dict(flags=flags, grid=grid, sync_interval=si, ms=dt*1e3, evals_per_s=evals/dt, problems_per_s=P/dt, iters_min=min(iters), iters_max=max(iters), iters_mean=float(np.mean(iters)),
+        line = dict(flags=flags, grid=grid, launch_ahead=si, ms=dt*1e3, evals_per_s=evals/dt, problems_per_s=P/dt, iters_min=min(iters), iters_max=max(iters), iters_mean=float(np.mean(iters)),
                     GBps=64*evals/dt/1e9)
         if best is None or line["evals_per_s"] > best["evals_per_s"]: best = line
     print(json.dumps(line), flush=True)
