@@ -27,7 +27,7 @@ EXPORTED = [
     "clc_set_launch", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
     "clc_factor_evaluate", "clc_pose_plus", "clc_pose_plus_jacobian", "clc_eval", "clc_solve",
     "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
-    "clc_line_options_default", "clc_line_fit_batched",
+    "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",
 ]
 
 

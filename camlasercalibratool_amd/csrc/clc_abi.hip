@@ -895,6 +895,43 @@ int clc_line_fit_batched(clc_handle* h, const clc_options* opt_in, const double*
   return CLC_OK;
 }
 
+int clc_scan_to_points(clc_handle* h, const float* ranges, const int64_t* offsets, size_t n_scans,
+                       const float* angle_min, const float* angle_increment, const float* range_min,
+                       double* points) {
+  if (!h || !offsets || (n_scans > 0 && (!angle_min || !angle_increment || !range_min)))
+    return fail(CLC_ERR_INVALID_ARG, "clc_scan_to_points: bad argument");
+  if (n_scans == 0) return CLC_OK;
+  if (n_scans > 65535) return fail(CLC_ERR_INVALID_ARG, "clc_scan_to_points: at most 65535 scans per call");
+  for (size_t k = 0; k < n_scans; ++k)
+    if (offsets[k + 1] < offsets[k]) return fail(CLC_ERR_INVALID_ARG, "clc_scan_to_points: offsets not monotone");
+  const size_t n = (size_t)(offsets[n_scans] - offsets[0]);
+  if (n == 0) return CLC_OK;
+  if (!ranges || !points) return fail(CLC_ERR_INVALID_ARG, "clc_scan_to_points: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  std::vector<long long> rel(n_scans + 1);
+  long long longest = 0;
+  for (size_t k = 0; k <= n_scans; ++k) rel[k] = offsets[k] - offsets[0];
+  for (size_t k = 0; k < n_scans; ++k) longest = std::max(longest, rel[k + 1] - rel[k]);
+  DevBuf<float> br, bam, bai, brm;
+  DevBuf<long long> boff;
+  DevBuf<double> bp;
+  CLC_HIP(br.alloc(n)); CLC_HIP(bam.alloc(n_scans)); CLC_HIP(bai.alloc(n_scans)); CLC_HIP(brm.alloc(n_scans));
+  CLC_HIP(boff.alloc(n_scans + 1)); CLC_HIP(bp.alloc(3 * n));
+  CLC_HIP(hipMemcpyAsync(br.p, ranges + offsets[0], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemcpyAsync(bam.p, angle_min, n_scans * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemcpyAsync(bai.p, angle_increment, n_scans * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemcpyAsync(brm.p, range_min, n_scans * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemcpyAsync(boff.p, rel.data(), (n_scans + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  const int threads = 256;
+  const unsigned gx = (unsigned)std::min<long long>(64, std::max<long long>(1, (longest + threads - 1) / threads));
+  hipLaunchKernelGGL(clc::scan_to_points_kernel, dim3(gx, (unsigned)n_scans), dim3(threads), 0, h->stream, br.p, boff.p,
+                     (int)n_scans, bam.p, bai.p, brm.p, bp.p);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipMemcpyAsync(points + 3 * offsets[0], bp.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  return CLC_OK;
+}
+
 // ---- test hooks --------------------------------------------------------------------------
 // Runs only the wavefront reduction on in[64*28] -> out[28] (reduce_mode 0 butterfly, 1 shuffle).
 int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int reduce_mode) {

@@ -1115,4 +1115,26 @@ __global__ __launch_bounds__(BLOCK) void line_fit_kernel(const double* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// TranScanToPoints batched over scans (src/utilities.cpp:181-215): ray i of scan s at
+// theta = angle_min[s] + i * angle_increment[s] -> (r cos, r sin, 0), or (1000, 1000, 0) when the
+// range is outside [range_min[s], 30).  One thread per ray; streaming, 4 B in / 24 B out.
+// ---------------------------------------------------------------------------------------
+__global__ void scan_to_points_kernel(const float* __restrict__ ranges, const long long* __restrict__ off,
+                                      const int n_scans, const float* __restrict__ angle_min,
+                                      const float* __restrict__ angle_inc, const float* __restrict__ range_min,
+                                      double* __restrict__ points) {
+  const int s = blockIdx.y;
+  if (s >= n_scans) return;
+  const long long lo = off[s], n = off[s + 1] - lo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float r = ranges[lo + i];
+    const double th = angle_min[s] + (double)i * angle_inc[s];
+    double x = (double)r * cos(th), y = (double)r * sin(th);
+    if (!(r < 30.0 && r >= range_min[s])) { x = 1000.0; y = 1000.0; }
+    double* p = points + 3 * (lo + i);
+    p[0] = x; p[1] = y; p[2] = 0.0;
+  }
+}
+
 }  // namespace clc

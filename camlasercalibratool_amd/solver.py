@@ -171,6 +171,20 @@ class Solver:
               "clc_line_fit_batched")
         return lines, sm
 
+    def scan_to_points(self, ranges: np.ndarray, offsets: np.ndarray, angle_min, angle_increment, range_min) -> np.ndarray:
+        """TranScanToPoints (src/utilities.cpp:181-215) for many scans: ranges float32 [M], CSR offsets [S+1],
+        per-scan angle_min / angle_increment / range_min -> points [M,3]."""
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        S = len(offsets) - 1
+        f = lambda v: np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float32), (S,)))
+        am, ai, rm = f(angle_min), f(angle_increment), f(range_min)
+        pts = np.empty((r.shape[0], 3))
+        fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        check(self._L.clc_scan_to_points(self._h, fp(r), iptr(offsets), C.c_size_t(S), fp(am), fp(ai), fp(rm), dptr(pts)),
+              "clc_scan_to_points")
+        return pts
+
     # ---- test / profiling hooks ----
     def debug_wave_reduce(self, lanes: np.ndarray, reduce_mode: int) -> np.ndarray:
         lanes = np.ascontiguousarray(lanes, dtype=np.float64).reshape(64, 28)

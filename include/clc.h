@@ -219,6 +219,14 @@ void clc_line_options_default(clc_options* opt);
 int clc_line_fit_batched(clc_handle* h, const clc_options* opt, const double* xy, const int64_t* offsets,
                          size_t n_scans, double* lines, clc_summary* summaries);
 
+/* TranScanToPoints, src/utilities.cpp:181-215, for n_scans (<= 65535) scans at once: scan k owns rays
+ * [offsets[k], offsets[k+1]) of ranges[] (float32 as in sensor_msgs/LaserScan); ray i of scan k
+ * sits at angle_min[k] + i * angle_increment[k] (:192-193) and becomes (r cos, r sin, 0), or
+ * (1000, 1000, 0) when r is outside [range_min[k], 30) (:201-208).  points[3 * total rays]. */
+int clc_scan_to_points(clc_handle* h, const float* ranges, const int64_t* offsets, size_t n_scans,
+                       const float* angle_min, const float* angle_increment, const float* range_min,
+                       double* points);
+
 #ifdef __cplusplus
 }
 #endif

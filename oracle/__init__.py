@@ -290,3 +290,12 @@ def line_fit(xy: np.ndarray, line0, options: Optional[Options] = None, loss_a: f
                           C.c_int(trace_cap), C.c_int(0 if linear_solver == "qr" else 1))
     n = min(trace_cap, s.num_iterations + 1)
     return SolveResult(line, s, [tr[i] for i in range(n)])
+
+
+def scan_to_points(ranges: np.ndarray, angle_min: float, angle_increment: float, range_min: float) -> np.ndarray:
+    """TranScanToPoints (src/utilities.cpp:181-215) for one scan -> points [n,3]."""
+    r = np.ascontiguousarray(ranges, dtype=np.float32)
+    pts = np.empty((r.shape[0], 3))
+    lib().oracle_scan_to_points(r.ctypes.data_as(C.POINTER(C.c_float)), C.c_longlong(r.shape[0]), C.c_float(angle_min),
+                                C.c_float(angle_increment), C.c_float(range_min), _p(pts))
+    return pts

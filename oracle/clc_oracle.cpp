@@ -1025,6 +1025,27 @@ int oracle_closed_form(const double* obs, long long N, double Tlc[16], int* unob
   return 0;
 }
 
+// -------------------------------------------------------------------------------------
+// TranScanToPoints — src/utilities.cpp:181-215.  ranges are float32 as in
+// sensor_msgs/LaserScan; angle_min / angle_increment / range_min are the message's float32
+// fields (promoted to double in the expressions, :192-193,:204).  points[n*3].
+// -------------------------------------------------------------------------------------
+void oracle_scan_to_points(const float* ranges, long long n, float angle_min, float angle_increment,
+                           float range_min, double* points) {
+  for (long long i = 0; i < n; ++i) {
+    const double c = std::cos(angle_min + (double)i * angle_increment);  // :192
+    const double s = std::sin(angle_min + (double)i * angle_increment);  // :193
+    const double x = (double)ranges[i] * c, y = (double)ranges[i] * s;   // :189-190,:196
+    const double range_cutoff = 30.0;                                    // :201
+    const float range = ranges[i];
+    if (range < range_cutoff && range >= range_min) {                    // :203
+      points[3 * i] = x; points[3 * i + 1] = y; points[3 * i + 2] = 0.0;
+    } else {
+      points[3 * i] = 1000.0; points[3 * i + 1] = 1000.0; points[3 * i + 2] = 0.0;  // :208
+    }
+  }
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

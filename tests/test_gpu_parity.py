@@ -498,6 +498,27 @@ def test_offline_front_end_flow_with_line_fit(sv, oracle_mod):
     assert np.abs(np.linalg.inv(Tcl)[:3, 3] - sd.GT_TLC).max() < 0.03
 
 
+def test_scan_to_points_matches_oracle(sv, oracle_mod):
+    """TranScanToPoints (src/utilities.cpp:181-215): 40 scans of 1081 rays (0.25 deg), with
+    out-of-range returns (inf / 0 / > 30 m) mapped to the (1000, 1000, 0) sentinel."""
+    rng = np.random.default_rng(4)
+    S, n = 40, 1081
+    ranges = rng.uniform(0.05, 35.0, size=(S, n)).astype(np.float32)
+    ranges[:, ::97] = np.inf
+    ranges[:, 5::113] = 0.0
+    off = np.arange(S + 1, dtype=np.int64) * n
+    amin = rng.uniform(-2.4, -2.3, S).astype(np.float32)
+    ainc = np.full(S, np.float32(np.deg2rad(0.25)))
+    rmin = np.full(S, np.float32(0.1))
+    pts = sv.scan_to_points(ranges.reshape(-1), off, amin, ainc, rmin)
+    for k in (0, 7, 39):
+        ref = oracle_mod.scan_to_points(ranges[k], amin[k], ainc[k], rmin[k])
+        got = pts[off[k]:off[k + 1]]
+        assert np.array_equal(got[:, 2], ref[:, 2]) and np.array_equal(got == 1000.0, ref == 1000.0)
+        assert np.abs(got - ref).max() <= 4e-15 * 35.0
+    assert (pts[:, 0] == 1000.0).sum() > S  # sentinels present
+
+
 def test_bench_two_rank_path_dry_run():
     """bench.py's N>1 code path (per-rank problem, gather of result records, max-over-ranks
     timing) with 2 ranks oversubscribing the one visible GPU and gloo standing in for RCCL."""

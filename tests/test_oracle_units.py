@@ -187,3 +187,14 @@ def test_information_analysis(oracle_mod):
     rec2 = oracle_mod.flatten(S2, False, False)  # geometry inconsistent, but H only depends on planes/points
     *_, sv2, V2, nn2 = oracle_mod.information(rec2, pose)
     assert nn2 >= 1
+
+
+def test_scan_to_points_oracle(oracle_mod):
+    """TranScanToPoints restatement (src/utilities.cpp:181-215) against numpy."""
+    r = np.array([0.05, 0.5, 2.0, 29.99, 30.0, 45.0, np.inf, 1.0], dtype=np.float32)
+    pts = oracle_mod.scan_to_points(r, -1.0, 0.01, 0.1)
+    th = np.float32(-1.0) + np.arange(8) * np.float64(np.float32(0.01))
+    ok = (r < 30.0) & (r >= np.float32(0.1))
+    assert list(ok) == [False, True, True, True, False, False, False, True]
+    assert np.allclose(pts[ok, 0], r[ok] * np.cos(th[ok]), rtol=1e-15) and np.allclose(pts[ok, 1], r[ok] * np.sin(th[ok]), rtol=1e-15)
+    assert np.all(pts[~ok, :2] == 1000.0) and np.all(pts[:, 2] == 0.0)
