@@ -54,7 +54,7 @@ bool all_finite(const double* p, int n) {
 }
 
 constexpr int kDefaultLookahead = 2;
-constexpr int kDefaultLaunchFlags = 2 | 16;  // prefetch + compact layout (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py)
+constexpr int kDefaultLaunchFlags = 2 | 16 | 32;  // prefetch + compact layout + 512-thread weighted workgroups (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py)
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
 constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
 
@@ -118,10 +118,12 @@ namespace {
 
 int eval_grid(const clc_handle* h, size_t n) {
   const long long tiles = (long long)((n + clc::TILE - 1) / clc::TILE);
-  long long want = (tiles + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64);  // one tile per wave
+  const bool big = (h->launch_flags & clc::FLAG_WG512) != 0;
+  const int slots = big ? 4 * clc::W_OLD + 4 * clc::W_YOUNG : clc::BLOCK / 64;  // virtual waves per workgroup
+  long long want = (tiles + slots - 1) / slots;  // one tile per (virtual) wave
   // 1 workgroup per CU keeps the partial-row reduction of lm_kernel short; arrays long enough
   // to give every wave >= 16 tiles are streamed with 2 workgroups per CU (more loads in flight).
-  const int per_cu = tiles >= 16LL * (clc::BLOCK / 64) * 2 * h->num_cus ? 2 * kDefaultBlocksPerCU : kDefaultBlocksPerCU;
+  const int per_cu = (!big && tiles >= 16LL * (clc::BLOCK / 64) * 2 * h->num_cus) ? 2 * kDefaultBlocksPerCU : kDefaultBlocksPerCU;
   long long cap = h->grid_override > 0 ? h->grid_override : (long long)per_cu * h->num_cus;
   if (want < 1) want = 1;
   return (int)(want < cap ? want : cap);
@@ -157,17 +159,23 @@ int ensure_events(clc_handle* h, size_t n) {
 template <bool WITH_LOSS, bool WITH_JAC>
 void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t* d_status, double lf) {
   const int fl = h->launch_flags;
-#define CLC_LAUNCH(PF, NT, CP)                                                                            \
-  hipLaunchKernelGGL((clc::eval_kernel<WITH_LOSS, WITH_JAC, PF, NT, CP>), dim3(grid), dim3(clc::BLOCK), 0, \
-                     h->stream, (CP) ? h->d_ctiles : h->d_tiles, h->d_groups, (long long)h->n_obs, d_pose, \
+#define CLC_LAUNCH(PF, NT, CP, BT)                                                                          \
+  hipLaunchKernelGGL((clc::eval_kernel<WITH_LOSS, WITH_JAC, PF, NT, CP, BT>), dim3(grid), dim3(BT), 0,       \
+                     h->stream, (CP) ? h->d_ctiles : h->d_tiles, h->d_groups, (long long)h->n_obs, d_pose,   \
                      d_status, lf, fl, h->d_partials)
   const bool pf = (fl & clc::FLAG_PREFETCH) != 0, nt = (fl & clc::FLAG_NONTEMPORAL) != 0;
   const bool cp = (fl & clc::FLAG_COMPACT) != 0 && h->compact_ok;
-  if (cp) { if (nt) CLC_LAUNCH(true, true, true); else CLC_LAUNCH(true, false, true); }
-  else if (pf && nt) CLC_LAUNCH(true, true, false);
-  else if (pf) CLC_LAUNCH(true, false, false);
-  else if (nt) CLC_LAUNCH(false, true, false);
-  else CLC_LAUNCH(false, false, false);
+  const bool big = (fl & clc::FLAG_WG512) != 0;
+  if (cp) {
+    if (big) { if (nt) CLC_LAUNCH(true, true, true, 512); else CLC_LAUNCH(true, false, true, 512); }
+    else { if (nt) CLC_LAUNCH(true, true, true, 256); else CLC_LAUNCH(true, false, true, 256); }
+  } else if (big) {
+    if (nt) CLC_LAUNCH(true, true, false, 512); else CLC_LAUNCH(true, false, false, 512);
+  }
+  else if (pf && nt) CLC_LAUNCH(true, true, false, 256);
+  else if (pf) CLC_LAUNCH(true, false, false, 256);
+  else if (nt) CLC_LAUNCH(false, true, false, 256);
+  else CLC_LAUNCH(false, false, false, 256);
 #undef CLC_LAUNCH
 }
 
@@ -354,7 +362,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 31)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 63)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
@@ -947,6 +955,37 @@ int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int redu
   CLC_HIP(hipStreamSynchronize(h->stream));
   CLC_HIP(hipMemcpy(out, d + 64 * clc::NACC, sizeof(double) * clc::NACC, hipMemcpyDeviceToHost));
   return CLC_OK;
+}
+
+// Per-workgroup timeline of one compact-layout evaluation launch: stamps[grid*8] =
+// {wall_start, wall_end (10 ns ticks), cycles prologue, loop, epilogue, 0, 0, 0}; returns grid.
+int clc_debug_eval_timeline(clc_handle* h, const double pose[7], double lf, long long* stamps, int cap_waves,
+                            int block_threads) {
+  if (!h || !pose || !stamps || (block_threads != 256 && block_threads != 512))
+    return fail(CLC_ERR_INVALID_ARG, "clc_debug_eval_timeline: bad argument");
+  if (!h->compact_ok) return fail(CLC_ERR_NO_DATA, "clc_debug_eval_timeline: needs the compact layout");
+  CLC_HIP(hipSetDevice(h->device));
+  const int grid = eval_grid(h, h->n_obs);
+  const int n_waves = grid * (block_threads / 64);
+  if (n_waves > cap_waves) return fail(CLC_ERR_INVALID_ARG, "clc_debug_eval_timeline: stamps buffer too small");
+  int rc = ensure_partials(h, grid);
+  if (rc != CLC_OK) return rc;
+  DevBuf<long long> bs;
+  CLC_HIP(bs.alloc((size_t)n_waves * 8));
+  std::memcpy(h->h_small, pose, 7 * sizeof(double));
+  CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  for (int rep = 0; rep < 4; ++rep) {  // the last launch is the one reported (warm)
+    if (block_threads == 256)
+      hipLaunchKernelGGL((clc::eval_timeline_kernel<256>), dim3(grid), dim3(256), 0, h->stream, h->d_ctiles, h->d_groups,
+                         (long long)h->n_obs, h->d_small, lf, h->d_partials, bs.p);
+    else
+      hipLaunchKernelGGL((clc::eval_timeline_kernel<512>), dim3(grid), dim3(512), 0, h->stream, h->d_ctiles, h->d_groups,
+                         (long long)h->n_obs, h->d_small, lf, h->d_partials, bs.p);
+  }
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  CLC_HIP(hipMemcpy(stamps, bs.p, sizeof(long long) * (size_t)n_waves * 8, hipMemcpyDeviceToHost));
+  return n_waves;
 }
 
 // Layout report: compact[0/1] + group counts for the single-problem array and the batch.

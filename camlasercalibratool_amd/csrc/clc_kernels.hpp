@@ -7,7 +7,7 @@
 //     tile t, field f (0..7), slot j (0..127)  ->  tiles[t*1024 + f*128 + j]
 // so that a wavefront reads one field of one tile with ONE fully coalesced 1-KiB
 // `global_load_dwordx4` (lane l gets slots 2l, 2l+1 as a double2).  A wave consumes a tile
-// per loop trip: 8 such loads, 2 observations per lane.  Every observation is read exactly
+// per loop trip (8 such loads, 2 observations per lane) and owns a contiguous run of tiles.  Every observation is read exactly
 // once per evaluation pass: 64 algorithmic bytes per residual+Jacobian evaluation.
 //
 // Kernels
@@ -314,8 +314,43 @@ constexpr int FLAG_REDUCE_SHUFFLE = 1;  // reference wave reduction instead of t
 constexpr int FLAG_PREFETCH = 2;        // software-pipelined tile loads (next tile in flight while computing)
 constexpr int FLAG_NONTEMPORAL = 4;     // nt loads for the streamed tiles
 constexpr int FLAG_FUSED_LM = 8;        // clc_solve: controller in the tail of the evaluation launch
+constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 4:3 old/young wave tile weighting
 
 typedef double v2d __attribute__((ext_vector_type(2)));
+
+// Static tile -> wave map.  A wave owns `vw` of V weight units starting at unit `vbase`, and
+// with T tiles in the array it streams the CONTIGUOUS run [T*vbase/V, T*(vbase+vw)/V): shares
+// are proportional to the weights and differ from the ideal by less than one tile.  In a
+// 512-thread workgroup the four first-launched waves (one per SIMD) win the issue arbitration
+// against the four younger ones sharing their SIMDs (measured: 8.0k vs 11.5k cycles for equal
+// work, 99 % repeatable), so the older slots get W_OLD = 4 and the younger W_YOUNG = 3 units:
+// both finish together instead of leaving the tail of the launch at half occupancy.  The map is a
+// pure function of (array length, grid, block size), so the summation order — and the result,
+// bit for bit — stays fixed.
+struct WaveMap {
+  long long vbase, V;
+  int vw;
+  __device__ __forceinline__ long long begin(long long T) const { return T * vbase / V; }
+  __device__ __forceinline__ long long end(long long T) const { return T * (vbase + vw) / V; }
+};
+
+constexpr int W_OLD = 3, W_YOUNG = 2;
+
+template <int BT>
+__device__ __forceinline__ WaveMap make_wave_map(int block, int n_blocks, int wave) {
+  WaveMap m;
+  if (BT == 512) {
+    constexpr int per_block = 4 * W_OLD + 4 * W_YOUNG;
+    m.V = (long long)n_blocks * per_block;
+    m.vw = wave < 4 ? W_OLD : W_YOUNG;
+    m.vbase = (long long)block * per_block + (wave < 4 ? wave * W_OLD : 4 * W_OLD + (wave - 4) * W_YOUNG);
+  } else {
+    m.V = (long long)n_blocks * (BT / 64);
+    m.vw = 1;
+    m.vbase = (long long)block * (BT / 64) + wave;
+  }
+  return m;
+}
 
 template <bool NT>
 __device__ __forceinline__ void load_tile(const double* __restrict__ tiles, long long tile, int lane,
@@ -347,34 +382,34 @@ __device__ __forceinline__ void accumulate_tile(const PoseU& P, double inv_lf2, 
 // + one ragged, zero-padded tile that is masked by index).
 template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT>
 __device__ __forceinline__ void stream_tiles(const double* __restrict__ tiles, const long long n,
-                                             const long long wave_global, const long long n_waves,
-                                             const int lane, const PoseU& P, const double inv_lf2,
-                                             double (&acc)[NACC]) {
+                                             const WaveMap wm, const int lane, const PoseU& P,
+                                             const double inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
+  const int rem = (int)(n % TILE);
+  const long long T = n_full + (rem != 0 ? 1 : 0);
+  const long long t_begin = wm.begin(T), t_last = wm.end(T);     // this wave's run (may include the ragged tile)
+  const long long t_end = t_last < n_full ? t_last : n_full;      // whole tiles only
   if (PREFETCH) {
-    // two register buffers; the loads of tile t+n_waves are in flight while tile t is consumed
+    // two register buffers; the loads of the wave's next tile are in flight while one is consumed
     double2 fa[8], fb[8];
-    long long tile = wave_global;
-    if (tile < n_full) load_tile<NT>(tiles, tile, lane, fa);
-    while (tile < n_full) {
-      const long long t1 = tile + n_waves;
-      if (t1 < n_full) load_tile<NT>(tiles, t1, lane, fb);
+    long long tile = t_begin;
+    if (tile < t_end) load_tile<NT>(tiles, tile, lane, fa);
+    while (tile < t_end) {
+      if (tile + 1 < t_end) load_tile<NT>(tiles, tile + 1, lane, fb);
       accumulate_tile<WITH_LOSS, WITH_JAC>(P, inv_lf2, fa, acc);
-      if (t1 >= n_full) break;
-      const long long t2 = t1 + n_waves;
-      if (t2 < n_full) load_tile<NT>(tiles, t2, lane, fa);
+      if (tile + 1 >= t_end) break;
+      if (tile + 2 < t_end) load_tile<NT>(tiles, tile + 2, lane, fa);
       accumulate_tile<WITH_LOSS, WITH_JAC>(P, inv_lf2, fb, acc);
-      tile = t2;
+      tile += 2;
     }
   } else {
-    for (long long tile = wave_global; tile < n_full; tile += n_waves) {
+    for (long long tile = t_begin; tile < t_end; ++tile) {
       double2 f[8];
       load_tile<NT>(tiles, tile, lane, f);
       accumulate_tile<WITH_LOSS, WITH_JAC>(P, inv_lf2, f, acc);
     }
   }
-  const int rem = (int)(n % TILE);
-  if (rem != 0 && wave_global == (n_full % n_waves)) {  // ragged last tile: masked lanes
+  if (rem != 0 && t_begin <= n_full && n_full < t_last) {  // ragged last tile: masked lanes
     double2 f[8];
     load_tile<false>(tiles, n_full, lane, f);
     if (2 * lane < rem)
@@ -455,37 +490,37 @@ __device__ __forceinline__ void accumulate_cpoint(const PoseU& P, double inv_lf2
 template <bool WITH_LOSS, bool WITH_JAC, bool NT>
 __device__ __forceinline__ void stream_ctiles(const double* __restrict__ ctiles,
                                               const double* __restrict__ groups, const long long n,
-                                              const long long wave_global, const long long n_waves,
-                                              const int lane, const PoseU& P, const double inv_lf2,
-                                              double (&acc)[NACC]) {
+                                              const WaveMap wm, const int lane, const PoseU& P,
+                                              const double inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
+  const int rem = (int)(n % TILE);
+  const long long T = n_full + (rem != 0 ? 1 : 0);
+  const long long t_begin = wm.begin(T), t_last = wm.end(T);
+  const long long t_end = t_last < n_full ? t_last : n_full;
   CTile A, B;
   Planes2 PA, PB;
-  long long tile = wave_global;
-  bool have = tile < n_full;
+  long long tile = t_begin;
+  bool have = tile < t_end;
   if (have) {
     load_ctile<NT>(ctiles, tile, lane, A);
     gather_planes(groups, A.g, PA);
   }
   while (have) {
-    const long long t1 = tile + n_waves;
-    const bool has1 = t1 < n_full;
-    if (has1) load_ctile<NT>(ctiles, t1, lane, B);
+    const bool has1 = tile + 1 < t_end;
+    if (has1) load_ctile<NT>(ctiles, tile + 1, lane, B);
     accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, A, PA, acc);
     if (has1) gather_planes(groups, B.g, PB);
     accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, A, PA, acc);
     if (!has1) break;
-    const long long t2 = t1 + n_waves;
-    const bool has2 = t2 < n_full;
-    if (has2) load_ctile<NT>(ctiles, t2, lane, A);
+    const bool has2 = tile + 2 < t_end;
+    if (has2) load_ctile<NT>(ctiles, tile + 2, lane, A);
     accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, B, PB, acc);
     if (has2) gather_planes(groups, A.g, PA);
     accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, B, PB, acc);
-    tile = t2;
+    tile += 2;
     have = has2;
   }
-  const int rem = (int)(n % TILE);
-  if (rem != 0 && wave_global == (n_full % n_waves)) {  // ragged last tile (zero padded, gid 0)
+  if (rem != 0 && t_begin <= n_full && n_full < t_last) {  // ragged last tile (zero padded, gid 0)
     load_ctile<false>(ctiles, n_full, lane, A);
     gather_planes(groups, A.g, PA);
     if (2 * lane < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, A, PA, acc);
@@ -545,14 +580,14 @@ __global__ void build_ctiles_kernel(const double* __restrict__ aos, const unsign
   }
 }
 
-template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT, bool COMPACT>
-__global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ tiles,
-                                                     const double* __restrict__ groups,
-                                                     const long long n,
-                                                     const double* __restrict__ pose,
-                                                     const int32_t* __restrict__ status,
-                                                     const double lf, const int reduce_mode,
-                                                     double* __restrict__ partials) {
+template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT, bool COMPACT, int BT>
+__global__ __launch_bounds__(BT) void eval_kernel(const double* __restrict__ tiles,
+                                                  const double* __restrict__ groups,
+                                                  const long long n,
+                                                  const double* __restrict__ pose,
+                                                  const int32_t* __restrict__ status,
+                                                  const double lf, const int reduce_mode,
+                                                  double* __restrict__ partials) {
   if (status != nullptr && *status != CLC_RUNNING) return;
   PoseU P;
   load_pose(pose, P);
@@ -561,13 +596,45 @@ __global__ __launch_bounds__(BLOCK) void eval_kernel(const double* __restrict__ 
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
-  const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-  const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
+  const WaveMap wm = make_wave_map<BT>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
   if (COMPACT)
-    stream_ctiles<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wave_global, n_waves, lane, P, inv_lf2, acc);
+    stream_ctiles<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
   else
-    stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wave_global, n_waves, lane, P, inv_lf2, acc);
-  block_reduce_store<BLOCK / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
+    stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wm, lane, P, inv_lf2, acc);
+  block_reduce_store<BT / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
+}
+
+// Profiling twin of the default evaluation kernel (loss, Jacobian, compact layout): identical work,
+// plus per-workgroup stamps {wall start, wall end (100 MHz s_memrealtime, chip-global),
+// shader cycles: prologue, streaming loop, reduction epilogue}.  Debug/analysis only.
+template <int BT>
+__global__ __launch_bounds__(BT) void eval_timeline_kernel(const double* __restrict__ ctiles,
+                                                           const double* __restrict__ groups, const long long n,
+                                                           const double* __restrict__ pose, const double lf,
+                                                           double* __restrict__ partials,
+                                                           long long* __restrict__ stamps) {
+  const long long w0 = wall_clock64();
+  const long long c0 = clock64();
+  PoseU P;
+  load_pose(pose, P);
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long long wave_global = (long long)blockIdx.x * (BT / 64) + wave;
+  const WaveMap wm = make_wave_map<BT>(blockIdx.x, gridDim.x, wave);
+  const long long c1 = clock64();
+  stream_ctiles<true, true, false>(ctiles, groups, n, wm, lane, P, inv_lf2, acc);
+  const long long c2 = clock64();
+  const long long w2 = wall_clock64();
+  block_reduce_store<BT / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
+  const long long c3 = clock64();
+  if (lane == 0) {  // one record per WAVE: {wall start, wall end of loop, cycles prologue, loop, epilogue}
+    long long* s = stamps + 8 * (size_t)wave_global;
+    s[0] = w0; s[1] = w2; s[2] = c1 - c0; s[3] = c2 - c1; s[4] = c3 - c2; s[5] = wall_clock64();
+  }
 }
 
 // Fixed-order sum of the block partials: thread (c, rg) sums rows rg, rg+8, ... of column c
@@ -760,9 +827,8 @@ __global__ __launch_bounds__(BLOCK) void eval_lm_kernel(const double* __restrict
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const long long wave_global = (long long)blockIdx.x * (BLOCK / 64) + wave;
-  const long long n_waves = (long long)gridDim.x * (BLOCK / 64);
-  stream_tiles<WITH_LOSS, true, true, NT>(tiles, n, wave_global, n_waves, lane, P, inv_lf2, acc);
+  const WaveMap wm = make_wave_map<BLOCK>(blockIdx.x, gridDim.x, wave);
+  stream_tiles<WITH_LOSS, true, true, NT>(tiles, n, wm, lane, P, inv_lf2, acc);
   wave_reduce_butterfly(acc, wsum[wave], lane);
   __syncthreads();
   // ---- publish this workgroup's partial row (write-through) and take a ticket ----
@@ -966,14 +1032,13 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
-  const long long wave_global = (long long)j * (BLOCK / 64) + (threadIdx.x >> 6);
-  const long long n_waves = (long long)blocks_per_problem * (BLOCK / 64);
+  const WaveMap wm = make_wave_map<BLOCK>(j, blocks_per_problem, threadIdx.x >> 6);
   if (COMPACT)
-    stream_ctiles<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wave_global,
-                                         n_waves, lane, P, inv_lf2, acc);
+    stream_ctiles<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wm, lane, P,
+                                       inv_lf2, acc);
   else
-    stream_tiles<WITH_LOSS, true, true, NT>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wave_global,
-                                              n_waves, lane, P, inv_lf2, acc);
+    stream_tiles<WITH_LOSS, true, true, NT>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wm, lane, P,
+                                            inv_lf2, acc);
   block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
 }
 

@@ -128,7 +128,8 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
 /* Tuning of the evaluation launch: grid_blocks = number of 256-thread workgroups (0 = library
  * default); flags: 1 = reference shuffle reduction instead of the butterfly, 2 = software
  * prefetch of the next tile, 4 = non-temporal loads, 8 = clc_solve runs the LM controller in the
- * tail of the evaluation launch (one launch per iteration); -1 = library default.  Results change
+ * tail of the evaluation launch (one launch per iteration), 16 = compact 28-byte layout, 32 = 512-thread
+ * workgroups with old/young wave tile weighting; -1 = library default.  Results change
  * only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 

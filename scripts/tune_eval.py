@@ -13,13 +13,13 @@ x0 = sd.pose7_from_T(np.eye(4))
 sv = clc.Solver(0)
 print(sv.device_info())
 res = {}
-for n_mult in ():
+for n_mult in (1, 8):
     big = np.ascontiguousarray(np.tile(rec, (n_mult, 1)))
     sv.upload(big)
     n = big.shape[0]
-    for flags in (6, 22, 18):
+    for flags in (18, 50):
         row = []
-        for grid in (256, 512, 768, 1024, 1280, 1536, 2048, 4096):
+        for grid in (192, 256, 512):
             sv.set_launch(grid, flags)
             ms = min(sv.time_eval(x0, reps=100) for _ in range(3))
             row.append((grid, ms, 64 * n / ms / 1e6))
@@ -32,7 +32,7 @@ print("default  jac+loss %.2f us | cost-only %.2f us | no-loss %.2f us" % (
     1e3 * sv.time_eval(x0, reps=100), 1e3 * sv.time_eval(x0, reps=100, with_jacobian=False),
     1e3 * sv.time_eval(x0, reps=100, with_loss=False)))
 # solve loop: launch-ahead depth
-for flags, grid in ((6, 256), (18, 256), (18, 384), (18, 512), (22, 512)):
+for flags, grid in ((18, 256), (50, 256)):
     sv.set_launch(grid, flags)
     for la in (2, 3):
         o = clc.default_options(); o.launch_ahead = la

@@ -102,7 +102,7 @@ def test_eval_reduction_matches_oracle_ragged_sizes(sv, oracle_mod, n, with_loss
     assert sv.num_observations == n
     pose = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)) if n % 2 else X0
     pose = oracle_mod.pose_plus(pose, rng.normal(size=6) * 0.05)
-    for flags in (0, 1, 2, 4, 6, 7, 16 | 2, 16 | 6, 16 | 7):  # reduction x prefetch x non-temporal x compact layout
+    for flags in (0, 1, 2, 4, 6, 7, 16 | 2, 16 | 6, 16 | 7, 32 | 2, 32 | 6, 32 | 16 | 2, 32 | 16 | 7):  # reduction x prefetch x nt x compact x 512-thread WGs
         sv.set_launch(0, flags)
         c, g, H = sv.eval(pose, with_loss=with_loss)
         c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
@@ -151,8 +151,16 @@ def test_compact_layout_is_lossless_and_optional(sv, oracle_mod):
     ra = sv.solve(X0)
     sv.set_launch(0, 6)
     rb = sv.solve(X0)
-    sv.set_launch(0, -1)
     assert np.array_equal(ra.pose, rb.pose) and ra.summary.final_cost == rb.summary.final_cost
+    # same for the 512-thread workgroups with the weighted tile map (their own fixed order)
+    sv.set_launch(0, 32 | 6)
+    c = sv.eval(pose)
+    sv.set_launch(0, 32 | 16 | 2)
+    d = sv.eval(pose)
+    e = sv.eval(pose)
+    sv.set_launch(0, -1)
+    assert c[0] == d[0] and np.array_equal(c[2], d[2]) and d[0] == e[0] and np.array_equal(d[1], e[1])
+    assert abs(c[0] - a[0]) <= 1e-12 * abs(a[0]) and np.allclose(c[2], a[2], rtol=1e-12)
     # boundary terms: two extra single-record groups per scan (src/LaseCamCalCeres.cpp:281-288)
     Sb = sd.sim_board_edges(5, n_poses=50, pts_per_pose=30)
     recb = clc.flatten_observations(Sb, True, True)
