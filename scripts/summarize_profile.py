@@ -47,7 +47,8 @@ traffic = {}
 for (k, cname), v in fetch.items():
     if "eval_kernel" not in k:
         continue
-    compact = k.replace(" ", "").endswith("true>") and k.count(",") == 4   # eval_kernel<loss,jac,prefetch,nt,COMPACT>
+    targs = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+    compact = len(targs) >= 5 and targs[4] == "true"   # eval_kernel<loss,jac,prefetch,nt,COMPACT,block>
     groups = collections.defaultdict(list)
     for x in v:
         cls = "no-op" if x < 1000 else ("1e6 obs" if x < 60000 else "8e6 obs")
