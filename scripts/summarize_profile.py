@@ -48,16 +48,19 @@ for (k, cname), v in fetch.items():
     if "eval_kernel" not in k:
         continue
     targs = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
-    compact = len(targs) >= 5 and targs[4] == "true"   # eval_kernel<loss,jac,prefetch,nt,COMPACT,block>
+    batched = "batched_eval_kernel" in k
+    compact = (len(targs) >= 2 and targs[1] == "true") if batched else (len(targs) >= 5 and targs[4] == "true")
     groups = collections.defaultdict(list)
     for x in v:
-        cls = "no-op" if x < 1000 else ("1e6 obs" if x < 60000 else "8e6 obs")
+        cls = "no-op" if x < 1000 else ("C3 batch, all 1024 problems running (1.024e7 obs)" if batched and x > 100000 else ("C3 batch, partly finished" if batched else ("1e6 obs" if x < 60000 else "8e6 obs")))
         groups[cls].append(x)
     wv = write.get((k, "WRITE_SIZE"), [0.0])
     for cls, g in sorted(groups.items()):
         if cls == "no-op":
             continue
-        nobs = 1e6 if cls == "1e6 obs" else 8e6
+        if cls == "C3 batch, partly finished":
+            continue
+        nobs = 1e6 if cls == "1e6 obs" else (1.024e7 if batched else 8e6)
         alg = 64 * nobs
         layout = (28 if compact else 64) * nobs
         rd = 2 * statistics.median(g) * 1024
