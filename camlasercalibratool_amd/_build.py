@@ -7,7 +7,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libclc_hip.so")
+LIB_PATH = os.environ.get("CLC_LIBRARY") or os.path.join(CSRC, "libclc_hip.so")  # CLC_LIBRARY: A/B a different build
 SOURCES = ["clc_abi.hip", "clc_kernels.hpp", "clc_lm.hpp", "clc_math.hpp", "clc_host.hpp"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
 

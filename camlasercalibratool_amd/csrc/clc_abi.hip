@@ -157,12 +157,13 @@ int ensure_events(clc_handle* h, size_t n) {
 }
 
 template <bool WITH_LOSS, bool WITH_JAC>
-void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t* d_status, double lf) {
+void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t* d_status, double lf,
+                   const clc::Pose7& pose_arg, int use_pose_arg) {
   const int fl = h->launch_flags;
 #define CLC_LAUNCH(PF, NT, CP, BT)                                                                          \
   hipLaunchKernelGGL((clc::eval_kernel<WITH_LOSS, WITH_JAC, PF, NT, CP, BT>), dim3(grid), dim3(BT), 0,       \
                      h->stream, (CP) ? h->d_ctiles : h->d_tiles, h->d_groups, (long long)h->n_obs, d_pose,   \
-                     d_status, lf, fl, h->d_partials)
+                     d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg)
   const bool pf = (fl & clc::FLAG_PREFETCH) != 0, nt = (fl & clc::FLAG_NONTEMPORAL) != 0;
   const bool cp = (fl & clc::FLAG_COMPACT) != 0 && h->compact_ok;
   const bool big = (fl & clc::FLAG_WG512) != 0;
@@ -181,9 +182,11 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
 
 template <bool WITH_JAC>
 void launch_eval(clc_handle* h, int grid, bool with_loss, const double* d_pose,
-                 const int32_t* d_status, double lf) {
-  if (with_loss) launch_eval_v<true, WITH_JAC>(h, grid, d_pose, d_status, lf);
-  else launch_eval_v<false, WITH_JAC>(h, grid, d_pose, d_status, lf);
+                 const int32_t* d_status, double lf, const clc::Pose7* pose_arg = nullptr) {
+  const clc::Pose7 zero = {};
+  const clc::Pose7& pa = pose_arg ? *pose_arg : zero;
+  if (with_loss) launch_eval_v<true, WITH_JAC>(h, grid, d_pose, d_status, lf, pa, pose_arg ? 1 : 0);
+  else launch_eval_v<false, WITH_JAC>(h, grid, d_pose, d_status, lf, pa, pose_arg ? 1 : 0);
 }
 
 int retile_into(clc_handle* h, const double* d_aos, size_t n, double** d_tiles, size_t* cap_bytes) {
@@ -537,8 +540,10 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 
   clc::Pose7 p0;
   for (int i = 0; i < 7; ++i) p0.v[i] = pose[i];
-  hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, p0, h->d_ticket);
-  CLC_HIP(hipGetLastError());
+  if (fused) {  // the fused kernel reads the LM state at entry: initialise it with its own launch
+    hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, p0, h->d_ticket);
+    CLC_HIP(hipGetLastError());
+  }
 
   const double* d_x_eval = reinterpret_cast<const double*>(
       reinterpret_cast<const char*>(h->d_state) + offsetof(clc::LmState, x_eval));
@@ -569,10 +574,16 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 #undef CLC_LAUNCH_FUSED
         if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
       } else {
-        launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor);
+        // iteration 0 carries the initial pose by value and initialises the LM state in lm_kernel
+        const bool first = launched == 0;
+        launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor, first ? &p0 : nullptr);
         if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
-        hipLaunchKernelGGL(clc::lm_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
-                           h->d_state, opt, d_trace, d_trace_cap, h->d_mailbox);
+        if (first)
+          hipLaunchKernelGGL(clc::lm_kernel<true>, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
+                             h->d_state, opt, d_trace, d_trace_cap, h->d_mailbox, p0);
+        else
+          hipLaunchKernelGGL(clc::lm_kernel<false>, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
+                             h->d_state, opt, d_trace, d_trace_cap, h->d_mailbox, p0);
       }
       ++launched;
       continue;

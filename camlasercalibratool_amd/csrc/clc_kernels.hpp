@@ -49,6 +49,10 @@ __device__ __forceinline__ double make_uniform(double v) {
   return __hiloint2double(hi, lo);
 }
 
+struct Pose7 {  // a pose passed by value as a kernel argument
+  double v[7];
+};
+
 struct PoseU {  // wave-uniform pose: rotation matrix (row-major) + translation
   double R[9];
   double t[3];
@@ -587,10 +591,14 @@ __global__ __launch_bounds__(BT) void eval_kernel(const double* __restrict__ til
                                                   const double* __restrict__ pose,
                                                   const int32_t* __restrict__ status,
                                                   const double lf, const int reduce_mode,
-                                                  double* __restrict__ partials) {
-  if (status != nullptr && *status != CLC_RUNNING) return;
+                                                  double* __restrict__ partials, const Pose7 pose_arg,
+                                                  const int use_pose_arg) {
+  // first launch of a solve: the LM state is not initialised yet (the first lm_kernel does that),
+  // so the pose comes by value and the (stale) termination flag is ignored
+  if (!use_pose_arg && status != nullptr && *status != CLC_RUNNING) return;
   PoseU P;
-  load_pose(pose, P);
+  if (use_pose_arg) load_pose(pose_arg.v, P);
+  else load_pose(pose, P);
   const double inv_lf2 = make_uniform(1.0 / (lf * lf));
   double acc[NACC];
 #pragma unroll
@@ -701,12 +709,12 @@ __device__ __forceinline__ double load_partial(const double* p) {
   return *p;
 }
 
-template <bool COHERENT>
+template <bool COHERENT, bool FIRST>
 __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int n_blocks,
                                         LmState* __restrict__ state, const clc_options& opt,
                                         clc_iteration* __restrict__ trace, int trace_cap,
                                         HostMailbox* mailbox, double (*red)[32], double* sh_state,
-                                        const long long c0) {
+                                        const long long c0, const Pose7* init_pose = nullptr) {
   static_assert(LM_STATE_WORDS <= BLOCK, "one state word per thread");
   // Issue every global load before the first use: the thread's word of the LM state and its
   // share of the block partials (fixed order: thread (c, rg) owns rows rg, rg+8, ... of column
@@ -751,7 +759,9 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
       for (int g = 0; g < RG; ++g) t += red[g][cc];
       tot[cc] = t;
     }
-    LmState st = *reinterpret_cast<LmState*>(sh_state);
+    LmState st;
+    if (FIRST) lm_init(st, opt, init_pose->v);  // first iteration of a solve: nothing to load
+    else st = *reinterpret_cast<LmState*>(sh_state);
     LmScratch scratch;
     lm_advance(st, scratch, opt, trace, trace_cap,
                finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
@@ -781,16 +791,17 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
   if (threadIdx.x < LM_STATE_WORDS) reinterpret_cast<double*>(state)[threadIdx.x] = sh_state[threadIdx.x];
 }
 
+template <bool FIRST>
 __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ partials,
                                                    int n_blocks, LmState* __restrict__ state,
                                                    const clc_options opt,
                                                    clc_iteration* __restrict__ trace,
-                                                   int trace_cap, HostMailbox* mailbox) {
+                                                   int trace_cap, HostMailbox* mailbox, const Pose7 pose0) {
   __shared__ double red[BLOCK / 32][32];
   __shared__ double sh_state[LM_STATE_WORDS];
   const long long c0 = clock64();
-  if (state->status != CLC_RUNNING) return;
-  lm_tail<false>(partials, n_blocks, state, opt, trace, trace_cap, mailbox, red, sh_state, c0);
+  if (!FIRST && state->status != CLC_RUNNING) return;
+  lm_tail<false, FIRST>(partials, n_blocks, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, &pose0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -849,12 +860,8 @@ __global__ __launch_bounds__(BLOCK) void eval_lm_kernel(const double* __restrict
   // ---- last-arriving workgroup: every other row is complete and visible at agent scope ----
   const long long c0 = clock64();
   if (threadIdx.x == 0) __hip_atomic_store(ticket_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  lm_tail<true>(partials, (int)gridDim.x, state, opt, trace, trace_cap, mailbox, red, sh_state, c0);
+  lm_tail<true, false>(partials, (int)gridDim.x, state, opt, trace, trace_cap, mailbox, red, sh_state, c0);
 }
-
-struct Pose7 {
-  double v[7];
-};
 
 __global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0,
                                unsigned int* __restrict__ ticket_counter) {

@@ -1,0 +1,59 @@
+"""Build-time guard (runs without a GPU): hipcc's kernel-resource-usage remarks for gfx950.
+The hot kernels must not spill to scratch and must keep the occupancy the design relies on —
+a silent spill in lm_kernel once cost 10 % of the whole solve."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "camlasercalibratool_amd", "csrc", "clc_abi.hip")
+
+
+@pytest.fixture(scope="module")
+def usage(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("res") / "x.so"
+    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", str(out),
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res, cur = {}, None
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            res[cur][m.group(1).strip()] = int(m.group(2))
+    assert res, "no resource remarks parsed"
+    return res
+
+
+def _find(usage, *frags):
+    hits = [k for k in usage if all(f in k for f in frags)]
+    assert hits, frags
+    return hits
+
+
+def test_hot_kernels_do_not_spill(usage):
+    hot = (_find(usage, "11eval_kernel") + _find(usage, "9lm_kernel") + _find(usage, "19batched_eval_kernel") +
+           _find(usage, "17batched_lm_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "15line_fit_kernel") +
+           _find(usage, "14normal9_kernel"))
+    for k in hot:
+        assert usage[k]["ScratchSize"] == 0, (k, usage[k])
+        assert usage[k]["VGPRs"] <= 256, (k, usage[k])
+
+
+def test_default_evaluation_kernel_occupancy(usage):
+    # eval_kernel<loss, jac, prefetch, nt=0, compact, 512 threads>: 8 waves per workgroup need 2 waves/SIMD
+    (k,) = _find(usage, "11eval_kernelILb1ELb1ELb1ELb0ELb1ELi512E")
+    assert usage[k]["Occupancy"] >= 2 and usage[k]["VGPRs"] <= 256
+    assert usage[k]["TotalSGPRs"] <= 102
+    for k in _find(usage, "19batched_eval_kernel"):
+        assert usage[k]["Occupancy"] >= 2
