@@ -119,13 +119,12 @@ namespace {
 int eval_grid(const clc_handle* h, size_t n) {
   const long long tiles = (long long)((n + clc::TILE - 1) / clc::TILE);
   const bool big = (h->launch_flags & clc::FLAG_WG512) != 0;
-  const int slots = big ? 4 * clc::W_OLD + 4 * clc::W_YOUNG : clc::BLOCK / 64;  // virtual waves per workgroup
-  long long want = (tiles + slots - 1) / slots;  // one tile per (virtual) wave
-  // 1 workgroup per CU keeps the partial-row reduction of lm_kernel short; arrays long enough
-  // to give every wave >= 16 tiles are streamed with 2 workgroups per CU (more loads in flight).
+  // Every CU takes a share (the tile map is proportional, a wave may own zero tiles): up to one
+  // workgroup per CU keeps the partial-row reduction of lm_kernel short; with 256-thread workgroups,
+  // arrays long enough to give every wave >= 16 tiles are streamed with 2 workgroups per CU.
   const int per_cu = (!big && tiles >= 16LL * (clc::BLOCK / 64) * 2 * h->num_cus) ? 2 * kDefaultBlocksPerCU : kDefaultBlocksPerCU;
-  long long cap = h->grid_override > 0 ? h->grid_override : (long long)per_cu * h->num_cus;
-  if (want < 1) want = 1;
+  const long long cap = h->grid_override > 0 ? h->grid_override : (long long)per_cu * h->num_cus;
+  const long long want = tiles < 1 ? 1 : tiles;  // never more workgroups than tiles
   return (int)(want < cap ? want : cap);
 }
 
