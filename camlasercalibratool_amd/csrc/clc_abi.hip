@@ -54,6 +54,7 @@ bool all_finite(const double* p, int n) {
 }
 
 constexpr int kDefaultLookahead = 2;
+constexpr size_t kInfinityCacheBytes = 256u << 20;  // MI355X memory-side cache (MI355X_MICROARCH.md)
 constexpr int kDefaultLaunchFlags = 2 | 16 | 32;  // prefetch + compact layout + 512-thread weighted workgroups (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py)
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
 constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
@@ -79,6 +80,7 @@ struct clc_handle {
   // launch geometry
   int grid_override = 0;
   int launch_flags = kDefaultLaunchFlags;
+  bool launch_auto = true;  // default flags: size-dependent choices (deep pipeline) are made per launch
   double* d_partials = nullptr;
   int partials_cap_blocks = 0;
   // LM state
@@ -166,9 +168,16 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
   const bool pf = (fl & clc::FLAG_PREFETCH) != 0, nt = (fl & clc::FLAG_NONTEMPORAL) != 0;
   const bool cp = (fl & clc::FLAG_COMPACT) != 0 && h->compact_ok;
   const bool big = (fl & clc::FLAG_WG512) != 0;
+  // Compact layout: the deep pipeline (two tiles of points in flight per wave) pays only when the array streams
+  // from HBM, i.e. no longer fits the 256 MiB Infinity Cache (scripts/size_sweep.py: +10 % at 9e8 B, -8 % at 1e8 B).
+  const bool deep = (fl & clc::FLAG_DEEP) != 0 ||
+                    (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
   if (cp) {
-    if (big) { if (nt) CLC_LAUNCH(true, true, true, 512); else CLC_LAUNCH(true, false, true, 512); }
-    else { if (nt) CLC_LAUNCH(true, true, true, 256); else CLC_LAUNCH(true, false, true, 256); }
+    const bool pf = deep;
+    if (big && pf) { if (nt) CLC_LAUNCH(true, true, true, 512); else CLC_LAUNCH(true, false, true, 512); }
+    else if (big) { if (nt) CLC_LAUNCH(false, true, true, 512); else CLC_LAUNCH(false, false, true, 512); }
+    else if (pf) { if (nt) CLC_LAUNCH(true, true, true, 256); else CLC_LAUNCH(true, false, true, 256); }
+    else { if (nt) CLC_LAUNCH(false, true, true, 256); else CLC_LAUNCH(false, false, true, 256); }
   } else if (big) {
     if (nt) CLC_LAUNCH(true, true, false, 512); else CLC_LAUNCH(true, false, false, 512);
   }
@@ -364,10 +373,11 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 63)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 127)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
+  h->launch_auto = flags < 0;
   return CLC_OK;
 }
 

@@ -318,6 +318,7 @@ constexpr int FLAG_REDUCE_SHUFFLE = 1;  // reference wave reduction instead of t
 constexpr int FLAG_PREFETCH = 2;        // software-pipelined tile loads (next tile in flight while computing)
 constexpr int FLAG_NONTEMPORAL = 4;     // nt loads for the streamed tiles
 constexpr int FLAG_FUSED_LM = 8;        // clc_solve: controller in the tail of the evaluation launch
+constexpr int FLAG_DEEP = 64;            // compact layout: two tiles of points in flight per wave (HBM-resident arrays)
 constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 4:3 old/young wave tile weighting
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -532,6 +533,91 @@ __device__ __forceinline__ void stream_ctiles(const double* __restrict__ ctiles,
   }
 }
 
+// Deeper software pipeline for arrays beyond the Infinity Cache.  With one tile in flight per
+// wave a CU keeps 8 x 3.5 KB = 28 KB outstanding, which by Little's law sustains only ~4.4 TB/s
+// chip-wide (measured).  Here, while tile t is consumed, the wave has in flight: the points of
+// tiles t+1 and t+2, the group ids of t+2 and t+3, and the plane gather of t+1.  Issue order per
+// trip is oldest-needed-first — gather(t+1), points(t+2), gid(t+3) — so the in-order vmcnt wait
+// for what tile t+1 needs never drains the younger loads.  Buffers rotate with period 3 (points,
+// gids) and 2 (planes); the trip loop is unrolled x6 so every buffer index is a compile-time
+// constant (runtime-indexed register arrays would go to scratch).
+struct CPoints {
+  double2 p[3];
+};
+
+template <bool NT>
+__device__ __forceinline__ void load_cpoints(const double* __restrict__ ctiles, long long tile, int lane, CPoints& c) {
+  const v2d* pb = reinterpret_cast<const v2d*>(ctiles + tile * CTILE_DOUBLES) + lane;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v2d v;
+    if (NT) v = __builtin_nontemporal_load(pb + k * 64);
+    else v = pb[k * 64];
+    c.p[k].x = v[0];
+    c.p[k].y = v[1];
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ v2u load_cgid(const double* __restrict__ ctiles, long long tile, int lane) {
+  const v2u* gb = reinterpret_cast<const v2u*>(ctiles + tile * CTILE_DOUBLES + 3 * TILE) + lane;
+  if (NT) return __builtin_nontemporal_load(gb);
+  return *gb;
+}
+
+template <bool WITH_LOSS, bool WITH_JAC, int O>
+__device__ __forceinline__ void accumulate_cpoint2(const PoseU& P, double inv_lf2, const CPoints& c, const Planes2& q,
+                                                   double (&acc)[NACC]) {
+  accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, q.nx[O], q.ny[O], q.nz[O], q.d[O],
+                                              O == 0 ? c.p[0].x : c.p[0].y, O == 0 ? c.p[1].x : c.p[1].y,
+                                              O == 0 ? c.p[2].x : c.p[2].y, q.s[O], acc);
+}
+
+template <bool WITH_LOSS, bool WITH_JAC, bool NT>
+__device__ __forceinline__ void stream_ctiles_deep(const double* __restrict__ ctiles,
+                                                   const double* __restrict__ groups, const long long n,
+                                                   const WaveMap wm, const int lane, const PoseU& P,
+                                                   const double inv_lf2, double (&acc)[NACC]) {
+  const long long n_full = n / TILE;
+  const int rem = (int)(n % TILE);
+  const long long T = n_full + (rem != 0 ? 1 : 0);
+  const long long t_begin = wm.begin(T), t_last = wm.end(T);
+  const long long t_end = t_last < n_full ? t_last : n_full;
+  CPoints pt[3];
+  v2u gid[3];
+  Planes2 pl[2];
+  if (t_begin < t_end) {
+    // prologue: gids of the first three tiles, points of the first two, planes of the first
+    gid[0] = load_cgid<NT>(ctiles, t_begin, lane);
+    if (t_begin + 1 < t_end) gid[1] = load_cgid<NT>(ctiles, t_begin + 1, lane);
+    if (t_begin + 2 < t_end) gid[2] = load_cgid<NT>(ctiles, t_begin + 2, lane);
+    load_cpoints<NT>(ctiles, t_begin, lane, pt[0]);
+    if (t_begin + 1 < t_end) load_cpoints<NT>(ctiles, t_begin + 1, lane, pt[1]);
+    gather_planes(groups, gid[0], pl[0]);
+    for (long long base = t_begin; base < t_end; base += 6) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const long long t = base + u;
+        if (t >= t_end) break;
+        // trip for tile t: points in pt[u%3], planes in pl[u%2]; gid[(u+1)%3] = gid(t+1) has landed
+        if (t + 1 < t_end) gather_planes(groups, gid[(u + 1) % 3], pl[(u + 1) % 2]);
+        if (t + 2 < t_end) load_cpoints<NT>(ctiles, t + 2, lane, pt[(u + 2) % 3]);
+        if (t + 3 < t_end) gid[u % 3] = load_cgid<NT>(ctiles, t + 3, lane);  // gid(t) is dead: its planes are gathered
+        accumulate_cpoint2<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, pt[u % 3], pl[u % 2], acc);
+        accumulate_cpoint2<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, pt[u % 3], pl[u % 2], acc);
+      }
+    }
+  }
+  if (rem != 0 && t_begin <= n_full && n_full < t_last) {  // ragged last tile (zero padded, gid 0)
+    CTile A;
+    Planes2 PA;
+    load_ctile<false>(ctiles, n_full, lane, A);
+    gather_planes(groups, A.g, PA);
+    if (2 * lane < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, A, PA, acc);
+    if (2 * lane + 1 < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, A, PA, acc);
+  }
+}
+
 // upload-time helpers of the compact layout -------------------------------------------------
 // flag[k] = 1 when record k starts a new group: (n, d, scale) differ bitwise from record k-1.
 __global__ void group_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag) {
@@ -605,7 +691,9 @@ __global__ __launch_bounds__(BT) void eval_kernel(const double* __restrict__ til
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const WaveMap wm = make_wave_map<BT>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
-  if (COMPACT)
+  if (COMPACT && PREFETCH)
+    stream_ctiles_deep<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
+  else if (COMPACT)
     stream_ctiles<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
   else
     stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wm, lane, P, inv_lf2, acc);

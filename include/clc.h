@@ -127,10 +127,11 @@ void clc_destroy(clc_handle* h);
 int clc_set_stream(clc_handle* h, void* hip_stream);
 /* Tuning of the evaluation launch: grid_blocks = number of 256-thread workgroups (0 = library
  * default); flags: 1 = reference shuffle reduction instead of the butterfly, 2 = software
- * prefetch of the next tile, 4 = non-temporal loads, 8 = clc_solve runs the LM controller in the
- * tail of the evaluation launch (one launch per iteration), 16 = compact 28-byte layout, 32 = 512-thread
- * workgroups with old/young wave tile weighting; -1 = library default.  Results change
- * only in summation order. */
+ * prefetch of the next tile (64-byte layout), 4 = non-temporal loads, 8 = clc_solve runs the LM
+ * controller in the tail of the evaluation launch (one launch per iteration), 16 = compact 28-byte
+ * layout, 32 = 512-thread workgroups with old/young wave tile weighting, 64 = compact layout with
+ * two tiles in flight per wave; -1 = library default (2|16|32, and 64 chosen per launch when the
+ * array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 
 /* ---- problem assembly (host) --------------------------------------------------------

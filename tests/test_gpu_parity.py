@@ -102,7 +102,8 @@ def test_eval_reduction_matches_oracle_ragged_sizes(sv, oracle_mod, n, with_loss
     assert sv.num_observations == n
     pose = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)) if n % 2 else X0
     pose = oracle_mod.pose_plus(pose, rng.normal(size=6) * 0.05)
-    for flags in (0, 1, 2, 4, 6, 7, 16 | 2, 16 | 6, 16 | 7, 32 | 2, 32 | 6, 32 | 16 | 2, 32 | 16 | 7):  # reduction x prefetch x nt x compact x 512-thread WGs
+    for flags in (0, 1, 2, 4, 6, 7, 16 | 2, 16 | 6, 16 | 7, 32 | 2, 32 | 6, 32 | 16 | 2, 32 | 16 | 7,
+                  64 | 16, 64 | 32 | 16 | 4):  # reduction x prefetch x nt x compact x 512-thread WGs x deep pipeline
         sv.set_launch(0, flags)
         c, g, H = sv.eval(pose, with_loss=with_loss)
         c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
@@ -112,6 +113,26 @@ def test_eval_reduction_matches_oracle_ragged_sizes(sv, oracle_mod, n, with_loss
     sv.set_launch(0, -1)  # library default
     c1, _, _ = sv.eval(pose, with_loss=with_loss, want_jacobian=False)  # cost-only variant
     assert abs(c1 - c0) <= 1e-11 * abs(c0) + 1e-300
+
+
+@pytest.mark.parametrize("grid", [1, 2, 3, 7])
+@pytest.mark.parametrize("n", [128 * 40, 128 * 97 + 5, 65536 + 77])
+def test_deep_pipeline_long_tile_runs(sv, oracle_mod, n, grid):
+    """flags bit 64: with few workgroups every wave walks many tiles, so the x6-unrolled
+    rotation of the point / group-id / plane buffers wraps several times (and ends at every
+    residue of the unroll)."""
+    S = sd.sim_fixed_count(11, n_poses=(n + 499) // 500, pts_per_pose=500, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)[:n].copy()
+    sv.upload(rec)
+    pose = oracle_mod.pose_plus(X0, np.random.default_rng(grid).normal(size=6) * 0.05)
+    c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=True)
+    for flags in (64 | 16, 64 | 32 | 16, 64 | 32 | 16 | 4):
+        sv.set_launch(grid, flags)
+        c, g, H = sv.eval(pose, with_loss=True)
+        assert abs(c - c0) <= 1e-11 * abs(c0)
+        assert np.abs(g - g0).max() <= 1e-11 * np.abs(g0).max()
+        assert np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
+    sv.set_launch(0, -1)
 
 
 def test_eval_is_bitwise_reproducible_and_grid_invariant_to_rounding(sv, oracle_mod):
