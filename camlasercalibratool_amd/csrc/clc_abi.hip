@@ -112,6 +112,7 @@ struct clc_handle {
   double* d_bpartials = nullptr;
   size_t bpartials_cap_blocks = 0;
   long long batch_max_tiles = 0;
+  size_t batch_total_tiles = 0;
   size_t n_problems = 0;
   size_t problems_cap = 0;
 };
@@ -713,6 +714,7 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
   }
   h->batch_max_tiles = max_tiles;
   const size_t total_tiles = (size_t)tile_off[P];
+  h->batch_total_tiles = total_tiles;
   const size_t bytes = std::max<size_t>(total_tiles, 1) * clc::TILE_DOUBLES * sizeof(double);
   if (bytes > h->btiles_cap_bytes) {
     if (h->d_btiles) CLC_HIP(hipFree(h->d_btiles));
@@ -803,6 +805,8 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   const int max_evals = opt.max_num_iterations + 1;
   const bool bcompact = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->bcompact_ok;
   const bool bnt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;
+  const bool bdeep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
+                     (h->launch_auto && h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes);
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
   mb->status = CLC_RUNNING;
@@ -818,10 +822,17 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
     if (launched < max_evals && launched - done < lookahead) {
 #define CLC_LAUNCH_B(LOSS, CP, NT)                                                                          \
-  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, CP, NT>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
+  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, CP, NT, false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
                      h->stream, (CP) ? h->d_bctiles : h->d_btiles, h->d_bgroups, h->d_tile_off, h->d_nobs,    \
                      h->d_states, bpp, opt.loss_scale_factor, h->d_bpartials)
-      if (bcompact) {
+#define CLC_LAUNCH_BD(LOSS, NT)                                                                             \
+  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, true, NT, true>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
+                     h->stream, h->d_bctiles, h->d_bgroups, h->d_tile_off, h->d_nobs, h->d_states, bpp,           \
+                     opt.loss_scale_factor, h->d_bpartials)
+      if (bcompact && bdeep) {
+        if (opt.use_loss) { if (bnt) CLC_LAUNCH_BD(true, true); else CLC_LAUNCH_BD(true, false); }
+        else { if (bnt) CLC_LAUNCH_BD(false, true); else CLC_LAUNCH_BD(false, false); }
+      } else if (bcompact) {
         if (opt.use_loss) { if (bnt) CLC_LAUNCH_B(true, true, true); else CLC_LAUNCH_B(true, true, false); }
         else { if (bnt) CLC_LAUNCH_B(false, true, true); else CLC_LAUNCH_B(false, true, false); }
       } else {
@@ -829,6 +840,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
         else { if (bnt) CLC_LAUNCH_B(false, false, true); else CLC_LAUNCH_B(false, false, false); }
       }
 #undef CLC_LAUNCH_B
+#undef CLC_LAUNCH_BD
       hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
                          h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue, h->d_ticket, launched,
                          h->d_mailbox);

@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(BLOCK) void reduce9_kernel(const double* __restrict
 // owns tiles [tile_off[k], tile_off[k+1]) (padded to whole tiles) and n_obs[k] records; no
 // communication between problems.
 // ---------------------------------------------------------------------------------------
-template <bool WITH_LOSS, bool COMPACT, bool NT>
+template <bool WITH_LOSS, bool COMPACT, bool NT, bool DEEP>
 __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
     const double* __restrict__ tiles, const double* __restrict__ groups,
     const long long* __restrict__ tile_off, const long long* __restrict__ n_obs,
@@ -1128,7 +1128,10 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const WaveMap wm = make_wave_map<BLOCK>(j, blocks_per_problem, threadIdx.x >> 6);
-  if (COMPACT)
+  if (COMPACT && DEEP)
+    stream_ctiles_deep<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wm, lane, P,
+                                            inv_lf2, acc);
+  else if (COMPACT)
     stream_ctiles<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wm, lane, P,
                                        inv_lf2, acc);
   else
