@@ -541,7 +541,10 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // device has reported done (pinned mailbox), so the stream never drains and the host never
   // blocks; at most `lookahead` already-queued iterations turn into no-ops after termination.
   const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
-  const bool fused = (h->launch_flags & clc::FLAG_FUSED_LM) != 0;
+  // Controller in the tail of the evaluation launch (one launch per LM iteration) vs its own launch: fused saves a
+  // launch boundary (~1 us per iteration) when the evaluation is short, and loses a little when many workgroups
+  // queue for the ticket (scripts/size_sweep.py: 0.178 vs 0.193 ms at 5 500 obs, 0.222 vs 0.213 at 1e5, equal at 1e6).
+  const bool fused = (h->launch_flags & clc::FLAG_FUSED_LM) != 0 || (h->launch_auto && grid < h->num_cus);
 
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
@@ -575,12 +578,23 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
       if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
       if (fused) {
         const bool nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;
-#define CLC_LAUNCH_FUSED(LOSS, NT)                                                                        \
-  hipLaunchKernelGGL((clc::eval_lm_kernel<LOSS, NT>), dim3(grid), dim3(clc::BLOCK), 0, h->stream,         \
-                     h->d_tiles, (long long)h->n_obs, h->d_state, opt, h->d_partials, h->d_ticket, d_trace, \
-                     d_trace_cap, h->d_mailbox)
-        if (opt.use_loss) { if (nt) CLC_LAUNCH_FUSED(true, true); else CLC_LAUNCH_FUSED(true, false); }
-        else { if (nt) CLC_LAUNCH_FUSED(false, true); else CLC_LAUNCH_FUSED(false, false); }
+        const bool cp = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->compact_ok;
+        const bool big = (h->launch_flags & clc::FLAG_WG512) != 0;
+        const bool deep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
+                          (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
+#define CLC_LAUNCH_FUSED(LOSS, NT, CP, DEEP, BT)                                                          \
+  hipLaunchKernelGGL((clc::eval_lm_kernel<LOSS, NT, CP, DEEP, BT>), dim3(grid), dim3(BT), 0, h->stream,   \
+                     (CP) ? h->d_ctiles : h->d_tiles, h->d_groups, (long long)h->n_obs, h->d_state, opt,  \
+                     h->d_partials, h->d_ticket, d_trace, d_trace_cap, h->d_mailbox)
+#define CLC_LAUNCH_FUSED_L(NT, CP, DEEP, BT)                                                               \
+  do { if (opt.use_loss) CLC_LAUNCH_FUSED(true, NT, CP, DEEP, BT); else CLC_LAUNCH_FUSED(false, NT, CP, DEEP, BT); } while (0)
+        if (cp && big && deep) CLC_LAUNCH_FUSED_L(false, true, true, 512);
+        else if (cp && big) CLC_LAUNCH_FUSED_L(false, true, false, 512);
+        else if (cp && deep) CLC_LAUNCH_FUSED_L(false, true, true, 256);
+        else if (cp) CLC_LAUNCH_FUSED_L(false, true, false, 256);
+        else if (nt) CLC_LAUNCH_FUSED_L(true, false, false, 256);
+        else CLC_LAUNCH_FUSED_L(false, false, false, 256);
+#undef CLC_LAUNCH_FUSED_L
 #undef CLC_LAUNCH_FUSED
         if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
       } else {

@@ -804,6 +804,14 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
                                         HostMailbox* mailbox, double (*red)[32], double* sh_state,
                                         const long long c0, const Pose7* init_pose = nullptr) {
   static_assert(LM_STATE_WORDS <= BLOCK, "one state word per thread");
+  // Called by every thread of the workgroup (it contains barriers); the first BLOCK threads work,
+  // the waves beyond them (512-thread fused launch) only take part in the barriers.
+  const bool helper = threadIdx.x < BLOCK;
+  // Progress for the host's launch-ahead metering is published EARLY, by the first lane of wave 1
+  // (not the controller's wave): the ~1.5 us a store to pinned host memory needs to be
+  // acknowledged then overlaps the controller instead of delaying the end of the launch.
+  long long passes_before = 0;
+  if (!FIRST && threadIdx.x == 64) passes_before = state->n_evals;
   // Issue every global load before the first use: the thread's word of the LM state and its
   // share of the block partials (fixed order: thread (c, rg) owns rows rg, rg+8, ... of column
   // c).  One memory latency instead of several.
@@ -812,31 +820,35 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
   // Loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards: a
   // "load or 0.0" select on a runtime bound makes hipcc branch around every load and wait in
   // between (cdna_hip_programming.md §5 trap (c)).
-  const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
-  const double my_word = reinterpret_cast<const double*>(state)[cw];
-  const int cc = c < NACC ? c : NACC - 1;
-  const int last = n_blocks - 1;
-  double v[UNROLL];
-#pragma unroll
-  for (int j = 0; j < UNROLL; ++j) {
-    const int b = rg + RG * j;
-    v[j] = load_partial<COHERENT>(partials + (size_t)(b < last ? b : last) * NACC + cc);
-  }
-  if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = my_word;
-  double s = 0.0;
-#pragma unroll
-  for (int j = 0; j < UNROLL; ++j) s += (c < NACC && rg + RG * j < n_blocks) ? v[j] : 0.0;
-  for (int b0 = rg + RG * UNROLL; b0 < n_blocks; b0 += RG * UNROLL) {  // grids beyond 256 workgroups
+  if (helper) {  // wave-uniform
+    const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
+    const double my_word = reinterpret_cast<const double*>(state)[cw];
+    const int cc = c < NACC ? c : NACC - 1;
+    const int last = n_blocks - 1;
+    double v[UNROLL];
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) {
-      const int b = b0 + RG * j;
+      const int b = rg + RG * j;
       v[j] = load_partial<COHERENT>(partials + (size_t)(b < last ? b : last) * NACC + cc);
     }
+    if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = my_word;
+    double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < UNROLL; ++j) s += (c < NACC && b0 + RG * j < n_blocks) ? v[j] : 0.0;
+    for (int j = 0; j < UNROLL; ++j) s += (c < NACC && rg + RG * j < n_blocks) ? v[j] : 0.0;
+    for (int b0 = rg + RG * UNROLL; b0 < n_blocks; b0 += RG * UNROLL) {  // grids beyond 256 workgroups
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) {
+        const int b = b0 + RG * j;
+        v[j] = load_partial<COHERENT>(partials + (size_t)(b < last ? b : last) * NACC + cc);
+      }
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) s += (c < NACC && b0 + RG * j < n_blocks) ? v[j] : 0.0;
+    }
+    red[rg][c] = s;
   }
-  red[rg][c] = s;
   __syncthreads();
+  if (threadIdx.x == 64 && mailbox != nullptr)
+    __hip_atomic_store(&mailbox->n_done, (int32_t)(passes_before + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x == 0) {
     const long long c1 = clock64();
     double tot[NACC];
@@ -847,16 +859,16 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
       for (int g = 0; g < RG; ++g) t += red[g][cc];
       tot[cc] = t;
     }
-    LmState st;
+    // The LM state is used in place in LDS: copied into registers and back it cost 256 VGPRs + 48 AGPRs
+    // (occupancy 1 for the fused kernel); in place 148-162, at the same controller time.
+    LmState& st = *reinterpret_cast<LmState*>(sh_state);
     if (FIRST) lm_init(st, opt, init_pose->v);  // first iteration of a solve: nothing to load
-    else st = *reinterpret_cast<LmState*>(sh_state);
     LmScratch scratch;
     lm_advance(st, scratch, opt, trace, trace_cap,
                finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
-    *reinterpret_cast<LmState*>(sh_state) = st;
     const long long c2 = clock64();
     if (mailbox != nullptr) {
-      mailbox->prof[0] = c0; mailbox->prof[1] = c1; mailbox->prof[2] = c2;
+      if (opt.profile_events) { mailbox->prof[0] = c0; mailbox->prof[1] = c1; mailbox->prof[2] = c2; }
       if (st.status != CLC_RUNNING) {
         // termination: payload first, then system-scope release stores of the flags
         clc_summary sm;
@@ -868,11 +880,8 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
         for (int i = 0; i < 7; ++i) mailbox->pose[i] = st.x_out[i];
         __hip_atomic_store(&mailbox->n_done, (int32_t)st.n_evals, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&mailbox->status, st.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else {
-        // progress only: nothing to order it against, a relaxed uncached store is enough
-        __hip_atomic_store(&mailbox->n_done, (int32_t)st.n_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      mailbox->prof[3] = clock64();
+      if (opt.profile_events) mailbox->prof[3] = clock64();
     }
   }
   __syncthreads();
@@ -904,17 +913,17 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
 // The ticket counter is reset by the last workgroup (all others have already arrived) and is
 // zeroed by lm_init_kernel before the first launch of a solve.
 // ---------------------------------------------------------------------------------------
-template <bool WITH_LOSS, bool NT>
-__global__ __launch_bounds__(BLOCK) void eval_lm_kernel(const double* __restrict__ tiles,
-                                                        const long long n, LmState* __restrict__ state,
-                                                        const clc_options opt,
-                                                        double* __restrict__ partials,
-                                                        unsigned int* __restrict__ ticket_counter,
-                                                        clc_iteration* __restrict__ trace, int trace_cap,
-                                                        HostMailbox* mailbox) {
+template <bool WITH_LOSS, bool NT, bool COMPACT, bool DEEP, int BT>
+__global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ tiles,
+                                                     const double* __restrict__ groups, const long long n,
+                                                     LmState* __restrict__ state, const clc_options opt,
+                                                     double* __restrict__ partials,
+                                                     unsigned int* __restrict__ ticket_counter,
+                                                     clc_iteration* __restrict__ trace, int trace_cap,
+                                                     HostMailbox* mailbox) {
   __shared__ double red[BLOCK / 32][32];
   __shared__ double sh_state[LM_STATE_WORDS];
-  __shared__ double wsum[BLOCK / 64][NACC];
+  __shared__ double wsum[BT / 64][NACC];
   __shared__ int sh_last;
   if (state->status != CLC_RUNNING) return;
   PoseU P;
@@ -926,15 +935,20 @@ __global__ __launch_bounds__(BLOCK) void eval_lm_kernel(const double* __restrict
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const WaveMap wm = make_wave_map<BLOCK>(blockIdx.x, gridDim.x, wave);
-  stream_tiles<WITH_LOSS, true, true, NT>(tiles, n, wm, lane, P, inv_lf2, acc);
+  const WaveMap wm = make_wave_map<BT>(blockIdx.x, gridDim.x, wave);
+  if (COMPACT && DEEP)
+    stream_ctiles_deep<WITH_LOSS, true, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
+  else if (COMPACT)
+    stream_ctiles<WITH_LOSS, true, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
+  else
+    stream_tiles<WITH_LOSS, true, true, NT>(tiles, n, wm, lane, P, inv_lf2, acc);
   wave_reduce_butterfly(acc, wsum[wave], lane);
   __syncthreads();
   // ---- publish this workgroup's partial row (write-through) and take a ticket ----
   if (threadIdx.x < NACC) {
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) s += wsum[w][threadIdx.x];
+    for (int w = 0; w < BT / 64; ++w) s += wsum[w][threadIdx.x];
     __hip_atomic_store(partials + (size_t)blockIdx.x * NACC + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every (storing) wave: stores acknowledged
