@@ -316,7 +316,7 @@ def main():
             "final_cost_abs_err_vs_oracle": abs(res.summary.final_cost - ref.summary.final_cost),
             "iterations_gpu": res.summary.num_iterations, "iterations_oracle": ref.summary.num_iterations,
             "gates": {"T_cl": 1e-6, "final_cost": 1e-8},
-            "oracle": "CPU restatement of the reference + Ceres LM (parity unpinned: no Ceres available)",
+            "oracle": "CPU restatement of the reference + Ceres LM (reference-owned arithmetic pinned against the reference's own sources, tests/test_ref_pin.py; Ceres minimiser restated, unpinned: no Ceres available)",
         }
 
     if rank == 0:

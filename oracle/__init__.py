@@ -1,6 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/clc_oracle.cpp -> oracle/liboracle.so).
 
-TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see the header of clc_oracle.cpp).
+TEST INFRASTRUCTURE ONLY.  Parity: the reference-owned arithmetic is pinned against the reference's own
+code (oracle/ref.py, tests/test_ref_pin.py); Ceres' minimiser is restated and UNPINNED (header of clc_oracle.cpp).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
 the product package camlasercalibratool_amd never does.
 """
@@ -77,7 +78,8 @@ class Summary(C.Structure):
 def build(force: bool = False) -> str:
     """Compile oracle/liboracle.so with the committed Makefile (gcc, seconds)."""
     src = os.path.join(_HERE, "clc_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "oracle_types.h")))
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 

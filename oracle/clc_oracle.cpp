@@ -1,14 +1,21 @@
 // =====================================================================================
 // oracle/clc_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY, NOT THE PRODUCT.
 //
-// PARITY UNPINNED: the reference (MegviiRobot/CamLaserCalibraTool) has no tests, golden
-// vectors or fixtures for this path, and its arithmetic lives in un-vendored, unpinned
-// Ceres Solver (<= 2.1 by API; CMakeLists.txt:37) + Eigen3 (CMakeLists.txt:35), neither
-// of which exists in this environment.  This file restates (a) the reference's own code
-// line by line and (b) the published Ceres 1.13-2.1 trust-region / DENSE_QR / loss
-// corrector algorithm it calls.  It is pinned only by: the simulation ground truth
-// (main/calibr_simulation.cpp:15-20), finite differences, and an independent
-// scipy.optimize minimisation of the same objective (tests/test_oracle_*.py).
+// PARITY — what is pinned and what is not.
+//  * PINNED against the reference's own code: everything the reference itself computes —
+//    PointInPlaneFactor::Evaluate, PoseLocalParameterization, pi_from_ppp, the assembly
+//    loops of CamLaserCalibration (scales, loss scales, boundary planes), the closed form,
+//    LineFittingCeres' problem and TranScanToPoints.  The reference's translation units are
+//    compiled from /root/reference against stand-in Eigen/Ceres/sensor_msgs headers
+//    (oracle/ref_shim, `make ref` -> oracle/_ref/libref.so) and run; their outputs are
+//    committed as tests/golden/ref_vectors.json and compared live in tests/test_ref_pin.py.
+//  * UNPINNED: Ceres' minimiser.  The LM / DENSE_QR / loss-corrector arithmetic lives in
+//    un-vendored, unpinned Ceres Solver (<= 2.1 by API; CMakeLists.txt:37) + Eigen3
+//    (CMakeLists.txt:35); neither exists in this environment and the reference ships no tests
+//    or golden vectors.  The trust-region loop below restates the published Ceres 1.13-2.1
+//    algorithm; it is anchored only by the simulation ground truth
+//    (main/calibr_simulation.cpp:15-20), finite differences, and an independent
+//    scipy.optimize minimisation of the same objective (tests/test_oracle_*.py).
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
 // The product (camlasercalibratool_amd/csrc) never includes, links or calls it.
@@ -28,59 +35,9 @@
 #include <omp.h>
 #endif
 
+#include "oracle_types.h"
+
 extern "C" {
-
-// Solver options: defaults = Ceres defaults + src/LaseCamCalCeres.cpp:302-304.
-struct oracle_options {
-  int32_t max_num_iterations;                 // 100   (LaseCamCalCeres.cpp:304)
-  int32_t max_num_consecutive_invalid_steps;  // 5
-  int32_t jacobi_scaling;                     // 1
-  int32_t use_loss;                           // 1     (#define LOSSFUNCTION, :212)
-  double loss_scale_factor;                   // 0.05  (CauchyLoss(0.05*scale), :249)
-  double initial_trust_region_radius;         // 1e4
-  double max_trust_region_radius;             // 1e16
-  double min_trust_region_radius;             // 1e-32
-  double min_relative_decrease;               // 1e-3
-  double min_lm_diagonal;                     // 1e-6
-  double max_lm_diagonal;                     // 1e32
-  double function_tolerance;                  // 1e-6
-  double gradient_tolerance;                  // 1e-10
-  double parameter_tolerance;                 // 1e-8
-};
-
-// Termination codes (mirrors ceres::TerminationType + which test fired).
-enum {
-  ORACLE_CONVERGENCE_GRADIENT = 1,
-  ORACLE_CONVERGENCE_PARAMETER = 2,
-  ORACLE_CONVERGENCE_FUNCTION = 3,
-  ORACLE_CONVERGENCE_RADIUS = 4,
-  ORACLE_NO_CONVERGENCE = 5,
-  ORACLE_FAILURE = 6,
-};
-
-struct oracle_iteration {  // ceres::IterationSummary subset
-  int32_t iteration;
-  int32_t step_is_valid;
-  int32_t step_is_successful;
-  int32_t pad_;
-  double cost;
-  double cost_change;
-  double gradient_max_norm;
-  double step_norm;
-  double relative_decrease;
-  double trust_region_radius;
-};
-
-struct oracle_summary {
-  int32_t termination;
-  int32_t num_iterations;  // = iterations.size() - 1 (iteration 0 is the initial evaluation)
-  int32_t num_successful_steps;
-  int32_t num_unsuccessful_steps;
-  int64_t num_residual_evaluations;  // evaluation passes over the data (cost, +jacobian)
-  int64_t num_jacobian_evaluations;
-  double initial_cost;
-  double final_cost;
-};
 
 void oracle_options_default(oracle_options* o) {
   o->max_num_iterations = 100;
@@ -782,6 +739,29 @@ int oracle_solve(const double* obs, long long N, const oracle_options* opt, doub
   };
   pb.plus = [](const double* x, const double* d, double* out) { oracle_pose_plus(x, d, out); };
   return lm_minimize(pb, opt, pose, summary, trace, trace_cap, linear_solver);
+}
+
+// -------------------------------------------------------------------------------------
+// The same minimiser behind C callbacks: lets a caller that owns its residual blocks (the stand-in
+// ceres::Solve of oracle/ref_shim, which drives the reference's own cost functions) run exactly
+// the LM restatement above.  DENSE_QR path only.
+//   eval(ctx, x, res, J, ldj, g) / plus(ctx, x, delta, out): as in LmProblem.
+// -------------------------------------------------------------------------------------
+extern "C" {
+typedef double (*oracle_eval_cb)(void* ctx, const double* x, double* res, double* J, long long ldj, double* g);
+typedef void (*oracle_plus_cb)(void* ctx, const double* x, const double* delta, double* out);
+int oracle_minimize_cb(int np, int na, long long n_res, oracle_eval_cb eval, oracle_plus_cb plus, void* ctx,
+                       const oracle_options* opt, double* x, oracle_summary* summary, oracle_iteration* trace,
+                       int trace_cap) {
+  LmProblem pb;
+  pb.np = np; pb.na = na; pb.n_res = n_res;
+  pb.eval_dense = [=](const double* xx, double* res, double* J, long long ldj, double* g) {
+    return eval(ctx, xx, res, J, ldj, g);
+  };
+  pb.eval_ne = [](const double*, double*, double*) { return 0.0; };  // unused with DENSE_QR
+  pb.plus = [=](const double* xx, const double* d, double* out) { plus(ctx, xx, d, out); };
+  return lm_minimize(pb, opt, x, summary, trace, trace_cap, /*linear_solver=*/0);
+}
 }
 
 // -------------------------------------------------------------------------------------

@@ -1,0 +1,145 @@
+// ref_capi.cpp — C entry points over the REFERENCE'S OWN translation units.
+//
+// TEST INFRASTRUCTURE ONLY.  This file #includes the reference sources from where they lie
+// (-I$(REF_ROOT)/src -I$(REF_ROOT)/include; nothing is copied into this repository) and compiles them
+// against the stand-in Eigen / Ceres / sensor_msgs headers of this directory.  Everything called
+// below — PointInPlaneFactor::Evaluate, PoseLocalParameterization::{Plus,ComputeJacobian},
+// pi_from_ppp, CamLaserCalClosedSolution, CamLaserCalibration, LineFittingCeres, TranScanToPoints —
+// is the reference's code running as written; only the linear algebra primitives and the minimiser
+// behind ceres::Solve are stand-ins (mini_eigen.hpp, mini_ceres.hpp).
+// Built by `make -C oracle ref` into oracle/_ref/libref.so (git-ignored).
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <vector>
+
+#include "LaseCamCalCeres.cpp"               // reference: src/LaseCamCalCeres.cpp
+#include "pose_local_parameterization.cpp"   // reference: src/pose_local_parameterization.cpp
+#include "utilities.cpp"                     // reference: src/utilities.cpp
+
+namespace {
+
+struct CoutSilencer {  // the reference reports on std::cout (:175-177, :202, :309, :365-381)
+  std::ostringstream sink;
+  std::streambuf* old;
+  CoutSilencer() : old(std::cout.rdbuf(sink.rdbuf())) {}
+  ~CoutSilencer() { std::cout.rdbuf(old); }
+};
+
+std::vector<Oberserve> make_obs(int n_poses, const double* tag_q_wxyz, const double* tag_t, const long long* pts_off,
+                                const double* pts, const long long* ptl_off, const double* ptl) {
+  std::vector<Oberserve> obs((size_t)n_poses);
+  for (int i = 0; i < n_poses; ++i) {
+    Oberserve& o = obs[(size_t)i];
+    o.tagPose_Qca = Eigen::Quaterniond(tag_q_wxyz[4 * i], tag_q_wxyz[4 * i + 1], tag_q_wxyz[4 * i + 2], tag_q_wxyz[4 * i + 3]);
+    o.tagPose_tca = Eigen::Vector3d(tag_t[3 * i], tag_t[3 * i + 1], tag_t[3 * i + 2]);
+    for (long long k = pts_off[i]; k < pts_off[i + 1]; ++k) o.points.push_back(Eigen::Vector3d(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]));
+    for (long long k = ptl_off[i]; k < ptl_off[i + 1]; ++k) o.points_on_line.push_back(Eigen::Vector3d(ptl[3 * k], ptl[3 * k + 1], ptl[3 * k + 2]));
+  }
+  return obs;
+}
+
+}  // namespace
+
+extern "C" {
+
+// PointInPlaneFactor::Evaluate, src/LaseCamCalCeres.cpp:43-66.  jac7 may be NULL.
+void ref_factor_evaluate(const double plane[4], const double point[3], double scale, const double pose[7],
+                         double* residual, double* jac7) {
+  PointInPlaneFactor f(Eigen::Vector4d(plane[0], plane[1], plane[2], plane[3]), Eigen::Vector3d(point[0], point[1], point[2]), scale);
+  const double* params[1] = {pose};
+  double* jacs[1] = {jac7};
+  f.Evaluate(params, residual, jac7 ? jacs : nullptr);
+}
+
+// PoseLocalParameterization, src/pose_local_parameterization.cpp:15-40 (its members are private in the
+// reference's class declaration: reach them through the public ceres::LocalParameterization interface).
+void ref_pose_plus(const double x[7], const double delta[6], double out[7]) {
+  PoseLocalParameterization p;
+  static_cast<const ceres::LocalParameterization&>(p).Plus(x, delta, out);
+}
+void ref_pose_plus_jacobian(const double x[7], double jac42[42]) {
+  PoseLocalParameterization p;
+  static_cast<const ceres::LocalParameterization&>(p).ComputeJacobian(x, jac42);
+}
+int ref_pose_sizes(int* global_size, int* local_size) {
+  PoseLocalParameterization p;
+  *global_size = static_cast<const ceres::LocalParameterization&>(p).GlobalSize();
+  *local_size = static_cast<const ceres::LocalParameterization&>(p).LocalSize();
+  return 0;
+}
+
+// pi_from_ppp, src/utilities.cpp:267-272
+void ref_pi_from_ppp(const double x1[3], const double x2[3], const double x3[3], double pi[4]) {
+  const Eigen::Vector4d r = pi_from_ppp(Eigen::Vector3d(x1[0], x1[1], x1[2]), Eigen::Vector3d(x2[0], x2[1], x2[2]),
+                                        Eigen::Vector3d(x3[0], x3[1], x3[2]));
+  for (int i = 0; i < 4; ++i) pi[i] = r[i];
+}
+
+// CamLaserCalClosedSolution, src/LaseCamCalCeres.cpp:112-203.  Tlc row-major 4x4, in/out.
+void ref_closed_solution(int n_poses, const double* tag_q_wxyz, const double* tag_t, const long long* pts_off,
+                         const double* pts, const long long* ptl_off, const double* ptl, double Tlc[16]) {
+  CoutSilencer quiet;
+  Eigen::Matrix4d T;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T(i, j) = Tlc[4 * i + j];
+  CamLaserCalClosedSolution(make_obs(n_poses, tag_q_wxyz, tag_t, pts_off, pts, ptl_off, ptl), T);
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tlc[4 * i + j] = T(i, j);
+}
+
+// CamLaserCalibration, src/LaseCamCalCeres.cpp:213-383.  Tcl row-major 4x4, in/out.
+// record[6] = {termination, iterations, successful, unsuccessful, initial_cost, final_cost} of the
+// stand-in ceres::Solve; *n_blocks = residual blocks the reference's loop added.  Returns -1 when the
+// reference throws std::out_of_range (empty scan in boundary mode).
+int ref_calibration(int n_poses, const double* tag_q_wxyz, const double* tag_t, const long long* pts_off,
+                     const double* pts, const long long* ptl_off, const double* ptl, double Tcl[16],
+                     int use_linefitting_data, int use_boundary_constraint, double record[6], long long* n_blocks) {
+  CoutSilencer quiet;
+  Eigen::Matrix4d T;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T(i, j) = Tcl[4 * i + j];
+  try {
+    CamLaserCalibration(make_obs(n_poses, tag_q_wxyz, tag_t, pts_off, pts, ptl_off, ptl), T, use_linefitting_data != 0,
+                        use_boundary_constraint != 0);
+  } catch (const std::out_of_range&) {
+    return -1;  // obi.points.at(0) on an empty scan, :278-279
+  }
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tcl[4 * i + j] = T(i, j);
+  const ceres::SolveRecord& r = ceres::last_solve_record();
+  if (record) {
+    record[0] = r.termination; record[1] = r.num_iterations; record[2] = r.num_successful_steps;
+    record[3] = r.num_unsuccessful_steps; record[4] = r.initial_cost; record[5] = r.final_cost;
+  }
+  if (n_blocks) *n_blocks = r.num_residual_blocks;
+  return 0;
+}
+
+// LineFittingCeres, src/LaseCamCalCeres.cpp:401-433.  pts = n x 3, line in/out.
+void ref_line_fitting(const double* pts, long long n, double line[2], double record[6]) {
+  CoutSilencer quiet;
+  std::vector<Eigen::Vector3d> P;
+  for (long long k = 0; k < n; ++k) P.push_back(Eigen::Vector3d(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]));
+  Eigen::Vector2d L(line[0], line[1]);
+  LineFittingCeres(P, L);
+  line[0] = L(0);
+  line[1] = L(1);
+  const ceres::SolveRecord& r = ceres::last_solve_record();
+  if (record) {
+    record[0] = r.termination; record[1] = r.num_iterations; record[2] = r.num_successful_steps;
+    record[3] = r.num_unsuccessful_steps; record[4] = r.initial_cost; record[5] = r.final_cost;
+  }
+}
+
+// TranScanToPoints, src/utilities.cpp:181-215.  out = n x 3.
+void ref_scan_to_points(const float* ranges, long long n, float angle_min, float angle_increment, float range_min,
+                        double* out) {
+  sensor_msgs::LaserScan scan;
+  scan.angle_min = angle_min;
+  scan.angle_increment = angle_increment;
+  scan.range_min = range_min;
+  scan.ranges.assign(ranges, ranges + n);
+  std::vector<Eigen::Vector3d> P;
+  TranScanToPoints(scan, P);
+  for (long long k = 0; k < n; ++k)
+    for (int c = 0; c < 3; ++c) out[3 * k + c] = P[(size_t)k][c];
+}
+
+}  // extern "C"

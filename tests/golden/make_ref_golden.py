@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_vectors.json from the REFERENCE'S OWN code.
+
+The numbers in that file are outputs of the reference's translation units
+(src/LaseCamCalCeres.cpp, src/pose_local_parameterization.cpp, src/utilities.cpp), compiled from
+/root/reference against the stand-in Eigen / Ceres / sensor_msgs headers of oracle/ref_shim/ and run in
+this container (`make -C oracle ref`, oracle/ref.py).  They pin what the reference itself computes:
+
+  * PointInPlaneFactor::Evaluate            residual + 1x7 Jacobian           (exact code path)
+  * PoseLocalParameterization::Plus/Jacobian                                   (exact code path)
+  * pi_from_ppp, TranScanToPoints                                              (exact code path)
+  * CamLaserCalClosedSolution               whole function (SVD/LDLT are stand-ins: ~1e-14)
+  * CamLaserCalibration / LineFittingCeres  whole function: the reference's assembly loop, factor,
+                                            loss objects and parameterisation drive the stand-in
+                                            ceres::Solve, i.e. the oracle's LM restatement.
+
+What they do NOT pin is Ceres' own minimiser (absent here): iteration counts and termination in this
+file are those of the restated LM.  /root/reference does not exist on the GPU box, so the vectors are
+committed and the tests read only this file.
+
+    python tests/golden/make_ref_golden.py        # rewrite the fixture (needs /root/reference)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle.ref as ref  # noqa: E402
+from camlasercalibratool_amd import simdata as sd  # noqa: E402
+
+rng = np.random.default_rng(20240924)
+G = dict(provenance="reference sources compiled against oracle/ref_shim stand-ins (see make_ref_golden.py)", factor=[], plus=[],
+         pi_from_ppp=[], closed_solution=[], calibration=[], line_fitting=[], scan_to_points=[])
+
+
+def unit(v):
+    return v / np.linalg.norm(v)
+
+
+for k in range(48):
+    plane = np.r_[unit(rng.normal(size=3)) * (1.0 if k % 4 else rng.uniform(0.1, 3.0)), rng.normal()]  # some non-unit normals (edge planes)
+    point = rng.normal(size=3) * 3
+    scale = float(rng.uniform(0.03, 1.0))
+    q = rng.normal(size=4)
+    if k % 3:
+        q = unit(q)  # and some non-unit quaternions: the factor does not normalise
+    pose = np.r_[rng.normal(size=3), q]
+    r, j = ref.factor_evaluate(plane, point, scale, pose)
+    G["factor"].append(dict(plane=plane.tolist(), point=point.tolist(), scale=scale, pose=pose.tolist(), residual=r, jacobian=j.tolist()))
+
+for k in range(48):
+    x = np.r_[rng.normal(size=3), unit(rng.normal(size=4))]
+    d = rng.normal(size=6) * (10.0 ** rng.uniform(-6, 0))
+    G["plus"].append(dict(x=x.tolist(), delta=d.tolist(), out=ref.pose_plus(x, d).tolist()))
+G["plus_jacobian"] = ref.pose_plus_jacobian(np.r_[0, 0, 0, 0, 0, 0, 1.0]).tolist()
+G["pose_sizes"] = list(ref.pose_sizes())
+
+for k in range(16):
+    a, b, c = rng.normal(size=(3, 3))
+    if k % 2 == 0:
+        c = np.zeros(3)  # the call pattern of :275-276
+    G["pi_from_ppp"].append(dict(x1=a.tolist(), x2=b.tolist(), x3=c.tolist(), pi=ref.pi_from_ppp(a, b, c).tolist()))
+
+for seed, noise in [(0, 0.0), (1, 0.01), (4, 0.01), (7, 0.03)]:
+    S = sd.GenerateSimData(seed, noise_sigma=noise)
+    G["closed_solution"].append(dict(generator="GenerateSimData", seed=seed, noise=noise, Tlc=ref.closed_solution(S).tolist()))
+
+for gen, seed, noise, lf, bd, init in [("GenerateSimData", 0, 0.0, False, False, "identity"), ("GenerateSimData", 1, 0.01, False, False, "identity"),
+                                       ("GenerateSimData", 2, 0.03, False, False, "identity"), ("GenerateSimData", 3, 0.01, True, False, "identity"),
+                                       ("GenerateSimData", 5, 0.01, False, False, "closed_form"), ("sim_board_edges", 11, 0.002, True, True, "near_gt"),
+                                       ("sim_fixed_count", 21, 0.01, False, False, "identity")]:
+    if gen == "GenerateSimData":
+        S = sd.GenerateSimData(seed, noise_sigma=noise)
+    elif gen == "sim_board_edges":
+        S = sd.sim_board_edges(seed, 40, 30, noise_sigma=noise)
+    else:
+        S = sd.sim_fixed_count(seed, 64, 200, noise_sigma=noise)
+    if init == "identity":
+        T0 = np.eye(4)
+    elif init == "closed_form":
+        T0 = np.linalg.inv(ref.closed_solution(S))
+    else:
+        T0 = sd.T_from_pose7(ref.pose_plus(sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)), np.array([0.05, -0.04, 0.03, 0.05, -0.06, 0.04])))
+    Tcl, record, nb = ref.calibration(S, T0, lf, bd)
+    G["calibration"].append(dict(generator=gen, seed=seed, noise=noise, linefit=lf, boundary=bd, init=init, Tcl0=T0.tolist(), Tcl=Tcl.tolist(),
+                                 n_blocks=nb, **record))
+
+for k in range(8):
+    n = int(rng.integers(5, 160))
+    t = rng.uniform(-1, 1, n)
+    p0 = rng.uniform(-2, 2, 2) + np.array([0, 3.0])
+    d = unit(rng.normal(size=2))
+    xy = p0 + t[:, None] * d + rng.normal(size=(n, 2)) * 0.01
+    xy[rng.integers(0, n)] += 0.5  # an outlier for the Cauchy loss
+    pts = np.c_[xy, rng.normal(size=n)]  # z is ignored by the reference (:412)
+    l0 = [0.0, 0.0] if k % 2 else [0.3, 0.2]
+    line, record = ref.line_fitting(pts, l0)
+    G["line_fitting"].append(dict(points=pts.tolist(), line0=l0, line=line.tolist(), **record))
+
+r = rng.uniform(0.05, 40, 360).astype(np.float32)
+r[::7] = np.inf
+r[::11] = np.nan
+r[::13] = 0.01
+r[5] = 30.0
+r[6] = np.float32(0.1)
+a0, da, rmin = -1.57, 0.00873, 0.1
+P = ref.scan_to_points(r, a0, da, rmin)
+G["scan_to_points"].append(dict(ranges=[float(v) if np.isfinite(v) else str(v) for v in r], angle_min=a0, angle_increment=da, range_min=rmin,
+                                points=[[float(v) if np.isfinite(v) else str(v) for v in row] for row in P]))
+
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.json")
+json.dump(G, open(out, "w"), indent=0)
+print("wrote", out, os.path.getsize(out), "bytes")
