@@ -328,15 +328,26 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // are proportional to the weights and differ from the ideal by less than one tile.  In a
 // 512-thread workgroup the four first-launched waves (one per SIMD) win the issue arbitration
 // against the four younger ones sharing their SIMDs (measured: 8.0k vs 11.5k cycles for equal
-// work, 99 % repeatable), so the older slots get W_OLD = 4 and the younger W_YOUNG = 3 units:
+// work, 99 % repeatable), so the older slots get W_OLD = 3 and the younger W_YOUNG = 2 units:
 // both finish together instead of leaving the tail of the launch at half occupancy.  The map is a
 // pure function of (array length, grid, block size), so the summation order — and the result,
 // bit for bit — stays fixed.
 struct WaveMap {
   long long vbase, V;
   int vw;
-  __device__ __forceinline__ long long begin(long long T) const { return T * vbase / V; }
-  __device__ __forceinline__ long long end(long long T) const { return T * (vbase + vw) / V; }
+  // floor(T * u / V) for 0 <= u <= V.  A 64-bit division expands to ~150 instructions and two of them
+  // sat in front of the wave's first load (~0.5 us of an 8-us launch); with T = q V + r the same
+  // value is q u + floor(u r / V), three 32-bit divisions, whenever T < 2^32 and V < 2^16 (always,
+  // short of 5x10^11 observations or 3 000 workgroups).
+  __device__ __forceinline__ long long scaled(long long T, long long u) const {
+    if (T < (1LL << 32) && V < 65536) {
+      const unsigned int v = (unsigned int)V, q = (unsigned int)T / v, r = (unsigned int)T - q * v;
+      return (long long)q * u + (long long)(((unsigned int)u * r) / v);
+    }
+    return T * u / V;
+  }
+  __device__ __forceinline__ long long begin(long long T) const { return scaled(T, vbase); }
+  __device__ __forceinline__ long long end(long long T) const { return scaled(T, vbase + vw); }
 };
 
 constexpr int W_OLD = 3, W_YOUNG = 2;
@@ -385,20 +396,29 @@ __device__ __forceinline__ void accumulate_tile(const PoseU& P, double inv_lf2, 
 // The streaming loop shared by every evaluation kernel: wave `wave_global` of `n_waves`
 // consumes tiles wave_global, wave_global + n_waves, ... of an array of n records (whole tiles
 // + one ragged, zero-padded tile that is masked by index).
-template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT>
-__device__ __forceinline__ void stream_tiles(const double* __restrict__ tiles, const long long n,
-                                             const WaveMap wm, const int lane, const PoseU& P,
+//
+// `get_pose(PoseU&) -> bool` fetches the point to evaluate (and the solve's status: false = the
+// solve has terminated, nothing to do).  It is called AFTER the wave's first tile loads have been
+// issued: the pose was written a few microseconds earlier by the controller on another CU, so
+// reading it is a trip to memory — which now overlaps the first tile's latency instead of
+// preceding it (the kernel used to spend ~1.3 us of its ~8 waiting for status, pose and first
+// tile one after the other).
+template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT, class PoseFn>
+__device__ __forceinline__ bool stream_tiles(const double* __restrict__ tiles, const long long n,
+                                             const WaveMap wm, const int lane, PoseFn get_pose,
                                              const double inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
   const int rem = (int)(n % TILE);
   const long long T = n_full + (rem != 0 ? 1 : 0);
   const long long t_begin = wm.begin(T), t_last = wm.end(T);     // this wave's run (may include the ragged tile)
   const long long t_end = t_last < n_full ? t_last : n_full;      // whole tiles only
+  PoseU P;
   if (PREFETCH) {
     // two register buffers; the loads of the wave's next tile are in flight while one is consumed
     double2 fa[8], fb[8];
     long long tile = t_begin;
     if (tile < t_end) load_tile<NT>(tiles, tile, lane, fa);
+    if (!get_pose(P)) return false;
     while (tile < t_end) {
       if (tile + 1 < t_end) load_tile<NT>(tiles, tile + 1, lane, fb);
       accumulate_tile<WITH_LOSS, WITH_JAC>(P, inv_lf2, fa, acc);
@@ -408,6 +428,7 @@ __device__ __forceinline__ void stream_tiles(const double* __restrict__ tiles, c
       tile += 2;
     }
   } else {
+    if (!get_pose(P)) return false;
     for (long long tile = t_begin; tile < t_end; ++tile) {
       double2 f[8];
       load_tile<NT>(tiles, tile, lane, f);
@@ -424,6 +445,7 @@ __device__ __forceinline__ void stream_tiles(const double* __restrict__ tiles, c
       accumulate_observation<WITH_LOSS, WITH_JAC>(P, inv_lf2, f[0].y, f[1].y, f[2].y, f[3].y, f[4].y,
                                                   f[5].y, f[6].y, f[7].y, acc);
   }
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -492,10 +514,10 @@ __device__ __forceinline__ void accumulate_cpoint(const PoseU& P, double inv_lf2
 // wave's next tile are issued before the current tile is consumed, and the group gather of the
 // next tile is issued between the two observations of the current one (its gids have landed by
 // then, and the second observation's arithmetic hides the gather latency).
-template <bool WITH_LOSS, bool WITH_JAC, bool NT>
-__device__ __forceinline__ void stream_ctiles(const double* __restrict__ ctiles,
+template <bool WITH_LOSS, bool WITH_JAC, bool NT, class PoseFn>
+__device__ __forceinline__ bool stream_ctiles(const double* __restrict__ ctiles,
                                               const double* __restrict__ groups, const long long n,
-                                              const WaveMap wm, const int lane, const PoseU& P,
+                                              const WaveMap wm, const int lane, PoseFn get_pose,
                                               const double inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
   const int rem = (int)(n % TILE);
@@ -506,10 +528,10 @@ __device__ __forceinline__ void stream_ctiles(const double* __restrict__ ctiles,
   Planes2 PA, PB;
   long long tile = t_begin;
   bool have = tile < t_end;
-  if (have) {
-    load_ctile<NT>(ctiles, tile, lane, A);
-    gather_planes(groups, A.g, PA);
-  }
+  if (have) load_ctile<NT>(ctiles, tile, lane, A);
+  PoseU P;
+  if (!get_pose(P)) return false;  // after the first loads are in flight (see stream_tiles)
+  if (have) gather_planes(groups, A.g, PA);
   while (have) {
     const bool has1 = tile + 1 < t_end;
     if (has1) load_ctile<NT>(ctiles, tile + 1, lane, B);
@@ -531,6 +553,7 @@ __device__ __forceinline__ void stream_ctiles(const double* __restrict__ ctiles,
     if (2 * lane < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, A, PA, acc);
     if (2 * lane + 1 < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, A, PA, acc);
   }
+  return true;
 }
 
 // Deeper software pipeline for arrays beyond the Infinity Cache.  With one tile in flight per
@@ -573,10 +596,10 @@ __device__ __forceinline__ void accumulate_cpoint2(const PoseU& P, double inv_lf
                                               O == 0 ? c.p[2].x : c.p[2].y, q.s[O], acc);
 }
 
-template <bool WITH_LOSS, bool WITH_JAC, bool NT>
-__device__ __forceinline__ void stream_ctiles_deep(const double* __restrict__ ctiles,
+template <bool WITH_LOSS, bool WITH_JAC, bool NT, class PoseFn>
+__device__ __forceinline__ bool stream_ctiles_deep(const double* __restrict__ ctiles,
                                                    const double* __restrict__ groups, const long long n,
-                                                   const WaveMap wm, const int lane, const PoseU& P,
+                                                   const WaveMap wm, const int lane, PoseFn get_pose,
                                                    const double inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
   const int rem = (int)(n % TILE);
@@ -586,6 +609,7 @@ __device__ __forceinline__ void stream_ctiles_deep(const double* __restrict__ ct
   CPoints pt[3];
   v2u gid[3];
   Planes2 pl[2];
+  PoseU P;
   if (t_begin < t_end) {
     // prologue: gids of the first three tiles, points of the first two, planes of the first
     gid[0] = load_cgid<NT>(ctiles, t_begin, lane);
@@ -593,6 +617,9 @@ __device__ __forceinline__ void stream_ctiles_deep(const double* __restrict__ ct
     if (t_begin + 2 < t_end) gid[2] = load_cgid<NT>(ctiles, t_begin + 2, lane);
     load_cpoints<NT>(ctiles, t_begin, lane, pt[0]);
     if (t_begin + 1 < t_end) load_cpoints<NT>(ctiles, t_begin + 1, lane, pt[1]);
+  }
+  if (!get_pose(P)) return false;  // after the prologue loads are in flight (see stream_tiles)
+  if (t_begin < t_end) {
     gather_planes(groups, gid[0], pl[0]);
     for (long long base = t_begin; base < t_end; base += 6) {
 #pragma unroll
@@ -616,6 +643,7 @@ __device__ __forceinline__ void stream_ctiles_deep(const double* __restrict__ ct
     if (2 * lane < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 0>(P, inv_lf2, A, PA, acc);
     if (2 * lane + 1 < rem) accumulate_cpoint<WITH_LOSS, WITH_JAC, 1>(P, inv_lf2, A, PA, acc);
   }
+  return true;
 }
 
 // upload-time helpers of the compact layout -------------------------------------------------
@@ -681,22 +709,29 @@ __global__ __launch_bounds__(BT) void eval_kernel(const double* __restrict__ til
                                                   const int use_pose_arg) {
   // first launch of a solve: the LM state is not initialised yet (the first lm_kernel does that),
   // so the pose comes by value and the (stale) termination flag is ignored
-  if (!use_pose_arg && status != nullptr && *status != CLC_RUNNING) return;
-  PoseU P;
-  if (use_pose_arg) load_pose(pose_arg.v, P);
-  else load_pose(pose, P);
+  auto get_pose = [&](PoseU& P) -> bool {
+    if (use_pose_arg) {
+      load_pose(pose_arg.v, P);
+      return true;
+    }
+    const int32_t st = status != nullptr ? *status : (int32_t)CLC_RUNNING;  // both scalar loads issued before the
+    load_pose(pose, P);                                                     // first use: one wait, not two
+    return st == CLC_RUNNING;
+  };
   const double inv_lf2 = make_uniform(1.0 / (lf * lf));
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const WaveMap wm = make_wave_map<BT>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
+  bool active;
   if (COMPACT && PREFETCH)
-    stream_ctiles_deep<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
+    active = stream_ctiles_deep<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else if (COMPACT)
-    stream_ctiles<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
+    active = stream_ctiles<WITH_LOSS, WITH_JAC, NT>(tiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else
-    stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wm, lane, P, inv_lf2, acc);
+    active = stream_tiles<WITH_LOSS, WITH_JAC, PREFETCH, NT>(tiles, n, wm, lane, get_pose, inv_lf2, acc);
+  if (!active) return;  // uniform over the launch: the solve had already terminated
   block_reduce_store<BT / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 
@@ -722,7 +757,7 @@ __global__ __launch_bounds__(BT) void eval_timeline_kernel(const double* __restr
   const long long wave_global = (long long)blockIdx.x * (BT / 64) + wave;
   const WaveMap wm = make_wave_map<BT>(blockIdx.x, gridDim.x, wave);
   const long long c1 = clock64();
-  stream_ctiles<true, true, false>(ctiles, groups, n, wm, lane, P, inv_lf2, acc);
+  stream_ctiles<true, true, false>(ctiles, groups, n, wm, lane, [&](PoseU& Q) { Q = P; return true; }, inv_lf2, acc);
   const long long c2 = clock64();
   const long long w2 = wall_clock64();
   block_reduce_store<BT / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
@@ -925,9 +960,11 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
   __shared__ double sh_state[LM_STATE_WORDS];
   __shared__ double wsum[BT / 64][NACC];
   __shared__ int sh_last;
-  if (state->status != CLC_RUNNING) return;
-  PoseU P;
-  load_pose(state->x_eval, P);
+  auto get_pose = [&](PoseU& P) -> bool {
+    const int32_t st = state->status;  // issued together with the pose loads: one wait
+    load_pose(state->x_eval, P);
+    return st == CLC_RUNNING;
+  };
   const double lf = opt.loss_scale_factor;
   const double inv_lf2 = make_uniform(1.0 / (lf * lf));
   double acc[NACC];
@@ -936,12 +973,14 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const WaveMap wm = make_wave_map<BT>(blockIdx.x, gridDim.x, wave);
+  bool active;
   if (COMPACT && DEEP)
-    stream_ctiles_deep<WITH_LOSS, true, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
+    active = stream_ctiles_deep<WITH_LOSS, true, NT>(tiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else if (COMPACT)
-    stream_ctiles<WITH_LOSS, true, NT>(tiles, groups, n, wm, lane, P, inv_lf2, acc);
+    active = stream_ctiles<WITH_LOSS, true, NT>(tiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else
-    stream_tiles<WITH_LOSS, true, true, NT>(tiles, n, wm, lane, P, inv_lf2, acc);
+    active = stream_tiles<WITH_LOSS, true, true, NT>(tiles, n, wm, lane, get_pose, inv_lf2, acc);
+  if (!active) return;  // uniform over the launch
   wave_reduce_butterfly(acc, wsum[wave], lane);
   __syncthreads();
   // ---- publish this workgroup's partial row (write-through) and take a ticket ----
@@ -1133,24 +1172,28 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
   const int prob = blockIdx.x / blocks_per_problem;
   const int j = blockIdx.x - prob * blocks_per_problem;
   const LmState* st = states + prob;
-  if (st->status != CLC_RUNNING) return;
-  PoseU P;
-  load_pose(st->x_eval, P);
+  auto get_pose = [&](PoseU& P) -> bool {
+    const int32_t s = st->status;  // issued together with the pose loads: one wait
+    load_pose(st->x_eval, P);
+    return s == CLC_RUNNING;
+  };
   const double inv_lf2 = make_uniform(1.0 / (lf * lf));
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const WaveMap wm = make_wave_map<BLOCK>(j, blocks_per_problem, threadIdx.x >> 6);
+  bool active;
   if (COMPACT && DEEP)
-    stream_ctiles_deep<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wm, lane, P,
-                                            inv_lf2, acc);
+    active = stream_ctiles_deep<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wm, lane,
+                                                     get_pose, inv_lf2, acc);
   else if (COMPACT)
-    stream_ctiles<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wm, lane, P,
-                                       inv_lf2, acc);
+    active = stream_ctiles<WITH_LOSS, true, NT>(tiles + tile_off[prob] * CTILE_DOUBLES, groups, n_obs[prob], wm, lane,
+                                                get_pose, inv_lf2, acc);
   else
-    stream_tiles<WITH_LOSS, true, true, NT>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wm, lane, P,
-                                            inv_lf2, acc);
+    active = stream_tiles<WITH_LOSS, true, true, NT>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wm, lane,
+                                                     get_pose, inv_lf2, acc);
+  if (!active) return;  // uniform over the problem's workgroups: it has terminated
   block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
 }
 
