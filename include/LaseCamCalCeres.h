@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "clc.h"
@@ -119,12 +120,31 @@ inline int device_index()
     return e ? std::atoi(e) : 0;
 }
 
-struct Handle {  // RAII around clc_handle
+// One solver context per process, created on first use and shared by every call below: creating a context
+// (stream, device and pinned buffers) costs milliseconds, and main/calibr_offline.cpp:124 calls LineFittingCeres once
+// per scan.  It is deliberately never destroyed — the HIP runtime may already be gone when static destructors run.
+// The reference calls this API from its main thread only; the mutex makes concurrent callers queue up instead of
+// sharing the context's stream.
+inline clc_handle* create_shared_handle()
+{
+    clc_handle* h = NULL;
+    if (clc_create(&h, device_index()) != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; h = NULL; }
+    return h;
+}
+inline clc_handle* shared_handle()
+{
+    static clc_handle* h = create_shared_handle();
+    return h;
+}
+inline std::mutex& shared_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+struct Handle {  // the shared context, locked for the duration of one API call
+    std::lock_guard<std::mutex> lock;
     clc_handle* h;
-    Handle() : h(NULL) {
-        if (clc_create(&h, device_index()) != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; h = NULL; }
-    }
-    ~Handle() { if (h) clc_destroy(h); }
+    Handle() : lock(shared_mutex()), h(shared_handle()) {}
 };
 
 }  // namespace clc_adapter

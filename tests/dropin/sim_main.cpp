@@ -3,6 +3,7 @@
 // CamLaserCalibration(obs, Tcl, false) -> print Tlc) and of main/calibr_offline.cpp:166-170
 // (closed form -> invert -> refine), written against the drop-in header exactly as the
 // reference's nodes use it.  Prints "RESULT tlc_err R_err" for the test to parse.
+#include <chrono>
 #include <cstdio>
 #include <random>
 
@@ -56,8 +57,14 @@ static void GenerateSimData(std::vector<Oberserve>& obs, unsigned seed, double s
     }
 }
 
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int main(int argc, char** argv) {
     const bool offline_flow = argc > 1 && std::string(argv[1]) == "offline";
+    double t_fit = 0.0, t_closed = 0.0;
+    int n_fit = 0;
     std::vector<Oberserve> obs;
     GenerateSimData(obs, 7u, offline_flow ? 0.01 : 0.0);
     std::cout << "obs size: " << obs.size() << std::endl;
@@ -70,7 +77,9 @@ int main(int argc, char** argv) {
             if (points.size() < 10) continue;
             Eigen::Vector2d line;
             line(0) = 0.0; line(1) = 0.0;
+            const double t0 = now_ms();
             LineFittingCeres(points, line);
+            if (n_fit++ > 0) t_fit += now_ms() - t0;  // the first call pays for HIP start-up and the context
             double x_start = points.front().x(), x_end = points.back().x();
             double y_start = points.front().y(), y_end = points.back().y();
             if (std::fabs(x_end - x_start) > std::fabs(y_end - y_start)) {
@@ -88,10 +97,21 @@ int main(int argc, char** argv) {
         }
         obs = kept;
         std::cout << "scans with a fitted line: " << obs.size() << std::endl;
+        const double t0 = now_ms();
         CamLaserCalClosedSolution(obs, Tlc_initial);                    // calibr_offline.cpp:167
+        t_closed = now_ms() - t0;
     }
     Eigen::Matrix4d Tcl = invert(Tlc_initial);
+    const double tc0 = now_ms();
     CamLaserCalibration(obs, Tcl, false);                               // calibr_simulation.cpp:130 / calibr_offline.cpp:170
+    const double t_cal = now_ms() - tc0;
+    {   // the same call once more on a warm context: what a second calibration in the same process costs
+        Eigen::Matrix4d Tw = invert(Tlc_initial);
+        const double t0 = now_ms();
+        CamLaserCalibration(obs, Tw, false);
+        std::printf("TIMING calibration first %.3f ms, warm %.3f ms; closed form %.3f ms; line fit %.4f ms per scan (%d scans, after the first)\n",
+                    t_cal, now_ms() - t0, t_closed, n_fit > 1 ? t_fit / (n_fit - 1) : 0.0, n_fit);
+    }
     Eigen::Matrix4d Tlc = invert(Tcl);
     std::cout << "\n----- Transform from Camera to Laser Tlc is: -----\n" << std::endl << Tlc << std::endl;
     const double Rgt[3][3] = {{0, 0, 1}, {-1, 0, 0}, {0, -1, 0}}, tgt[3] = {0.1, 0.2, 0.3};
