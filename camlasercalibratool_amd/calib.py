@@ -23,6 +23,18 @@ from .solver import SolveResult, Solver, flatten_observations
 ObsLike = Union[ObservationSet, Sequence[Oberserve]]
 
 
+_shared: Optional[Solver] = None
+
+
+def _shared_solver() -> Solver:
+    """One solver context per process for the calls below (like the C++ drop-in header): creating a
+    context costs milliseconds, the calls themselves a few hundred microseconds."""
+    global _shared
+    if _shared is None or _shared._h is None:
+        _shared = Solver()
+    return _shared
+
+
 def _as_set(obs: ObsLike) -> ObservationSet:
     return obs if isinstance(obs, ObservationSet) else ObservationSet.from_list(list(obs))
 
@@ -41,14 +53,9 @@ def CamLaserCalClosedSolution(obs: ObsLike, Tlc: np.ndarray, solver: Optional[So
     """Closed-form initialiser; overwrites Tlc (camera->laser) like LaseCamCalCeres.cpp:198-200."""
     S = _as_set(obs)
     rec = flatten_observations(S, use_linefitting_data=True, use_boundary_constraint=False)  # points_on_line only, :143
-    own = solver is None
-    sv = solver or Solver()
-    try:
-        sv.upload(rec)
-        T, unobservable, sv9 = sv.closed_form()
-    finally:
-        if own:
-            sv.close()
+    sv = solver or _shared_solver()
+    sv.upload(rec)
+    T, unobservable, sv9 = sv.closed_form()
     if unobservable and verbose:  # :173-178
         print("\n~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~")
         print(" Notice Notice Notice: system unobservable !!!!!!!")
@@ -66,27 +73,23 @@ def CamLaserCalibration(obs: ObsLike, Tcl: np.ndarray, use_linefitting_data: boo
     S = _as_set(obs)
     rec = flatten_observations(S, use_linefitting_data, use_boundary_constraint)
     pose0 = simdata.pose7_from_T(np.asarray(Tcl, dtype=np.float64))  # :215-219
-    own = solver is None
-    sv = solver or Solver()
-    try:
-        sv.upload(rec)
-        res = sv.solve(pose0, options)
-        if verbose:  # stands in for summary.FullReport(), :309
-            s = res.summary
-            print(f"Solver Summary: iterations {s.num_iterations} (successful {s.num_successful_steps - 1}, "
-                  f"unsuccessful {s.num_unsuccessful_steps}), initial cost {s.initial_cost:.6e}, "
-                  f"final cost {s.final_cost:.6e}, termination {TERMINATION.get(s.termination)}, "
-                  f"residuals {rec.shape[0]}, passes {s.num_evaluations}, time {s.solve_ms:.3f} ms")
-        Tcl[...] = simdata.T_from_pose7(res.pose)  # :311-314
-        # analysis pass: no loss, no boundary terms (:316-362)
-        rec_pts = rec if not (use_boundary_constraint and use_linefitting_data) else flatten_observations(
-            S, use_linefitting_data, False)
-        if rec_pts is not rec:
-            sv.upload(rec_pts)
-        H, b, chi2, svals, V, n_null = sv.information(res.pose)
-    finally:
-        if own:
-            sv.close()
+    sv = solver or _shared_solver()
+    sv.upload(rec)
+    res = sv.solve(pose0, options)
+    if verbose:  # stands in for summary.FullReport(), :309
+        s = res.summary
+        print(f"Solver Summary: iterations {s.num_iterations} (successful {s.num_successful_steps - 1}, "
+              f"unsuccessful {s.num_unsuccessful_steps}), initial cost {s.initial_cost:.6e}, "
+              f"final cost {s.final_cost:.6e}, termination {TERMINATION.get(s.termination)}, "
+              f"residuals {rec.shape[0]}, passes {s.num_evaluations}, time {s.solve_ms:.3f} ms")
+    Tcl[...] = simdata.T_from_pose7(res.pose)  # :311-314
+    # analysis pass: no loss, no boundary terms (:316-362)
+    rec_pts = rec if not (use_boundary_constraint and use_linefitting_data) else flatten_observations(
+        S, use_linefitting_data, False)
+    if rec_pts is not rec:
+        sv.upload(rec_pts)
+    H, b, chi2, svals, V, n_null = sv.information(res.pose)
+
     null = V[:, 6 - n_null:] if n_null > 0 else np.zeros((6, 0))
     if verbose:  # :365-381
         print("----- H singular values--------:")
@@ -104,14 +107,10 @@ def LineFittingCeres(Points: np.ndarray, Line: np.ndarray, solver: Optional[Solv
     """Robust 2-parameter line fit of one scan, `Line` (m0, m1 of m0 x + m1 y + 1 = 0) in/out —
     mirror of LineFittingCeres(Points, Line), src/LaseCamCalCeres.cpp:401-433."""
     P = np.asarray(Points, dtype=np.float64).reshape(-1, 3)
-    own = solver is None
-    sv = solver or Solver()
-    try:
-        lines, _ = sv.line_fit_batched(P[:, :2], np.array([0, P.shape[0]], dtype=np.int64),
-                                       np.asarray(Line, dtype=np.float64).reshape(1, 2), options, want_summaries=False)
-    finally:
-        if own:
-            sv.close()
+    sv = solver or _shared_solver()
+    lines, _ = sv.line_fit_batched(P[:, :2], np.array([0, P.shape[0]], dtype=np.int64),
+                                   np.asarray(Line, dtype=np.float64).reshape(1, 2), options, want_summaries=False)
+
     Line[...] = lines[0]
 
 
@@ -121,14 +120,10 @@ def points_on_fitted_lines(obs_set: ObservationSet, solver: Optional[Solver] = N
     to every scan's `points` (batched on the GPU) and replace `points_on_line` by the two points of
     the fitted line at the first / last scan point's abscissa (or ordinate for near-vertical lines)."""
     S = obs_set.n_poses
-    own = solver is None
-    sv = solver or Solver()
-    try:
-        lines, _ = sv.line_fit_batched(obs_set.pts[:, :2], obs_set.pts_off, np.tile(np.asarray(line0, dtype=np.float64), (S, 1)),
-                                       want_summaries=False)
-    finally:
-        if own:
-            sv.close()
+    sv = solver or _shared_solver()
+    lines, _ = sv.line_fit_batched(obs_set.pts[:, :2], obs_set.pts_off, np.tile(np.asarray(line0, dtype=np.float64), (S, 1)),
+                                   want_summaries=False)
+
     ptl = np.zeros((2 * S, 3))
     keep = np.ones(S, dtype=bool)
     for i in range(S):
