@@ -150,3 +150,23 @@ def scan_to_points(ranges, angle_min, angle_increment, range_min) -> np.ndarray:
     lib().ref_scan_to_points(r.ctypes.data_as(C.POINTER(C.c_float)), C.c_longlong(r.shape[0]), C.c_float(angle_min),
                              C.c_float(angle_increment), C.c_float(range_min), _p(out))
     return out
+
+
+def last_stdout() -> str:
+    """What the last closed_solution() / calibration() call printed on std::cout (the reference reports its
+    analysis pass — H singular values, null space, chi2 — only there, src/LaseCamCalCeres.cpp:365-381)."""
+    L = lib()
+    L.ref_last_stdout.restype = C.c_longlong
+    n = L.ref_last_stdout(None, C.c_longlong(0))
+    buf = C.create_string_buffer(int(n) + 1)
+    L.ref_last_stdout(buf, C.c_longlong(n + 1))
+    return buf.value.decode("utf-8", "replace")
+
+
+def parse_analysis(text: str):
+    """-> (singular values [6], chi2/2) from the analysis printout (default ostream precision: 6 digits)."""
+    lines = text.splitlines()
+    i = next(k for k, l in enumerate(lines) if "H singular values" in l)
+    sv = [float(lines[i + 1 + k]) for k in range(6)]
+    chi_half = float(next(l for l in lines if l.startswith("recover chi2:")).split(":")[1])
+    return np.array(sv), chi_half

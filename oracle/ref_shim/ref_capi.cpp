@@ -11,6 +11,8 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <string>
+#include <cstring>
 #include <vector>
 
 #include "LaseCamCalCeres.cpp"               // reference: src/LaseCamCalCeres.cpp
@@ -19,11 +21,15 @@
 
 namespace {
 
-struct CoutSilencer {  // the reference reports on std::cout (:175-177, :202, :309, :365-381)
+struct CoutSilencer {  // the reference reports on std::cout (:175-177, :202, :309, :365-381): capture it
   std::ostringstream sink;
   std::streambuf* old;
-  CoutSilencer() : old(std::cout.rdbuf(sink.rdbuf())) {}
-  ~CoutSilencer() { std::cout.rdbuf(old); }
+  std::string* keep;
+  explicit CoutSilencer(std::string* k = nullptr) : old(std::cout.rdbuf(sink.rdbuf())), keep(k) {}
+  ~CoutSilencer() {
+    std::cout.rdbuf(old);
+    if (keep) *keep = sink.str();
+  }
 };
 
 std::vector<Oberserve> make_obs(int n_poses, const double* tag_q_wxyz, const double* tag_t, const long long* pts_off,
@@ -40,6 +46,8 @@ std::vector<Oberserve> make_obs(int n_poses, const double* tag_q_wxyz, const dou
 }
 
 }  // namespace
+
+static std::string g_last_stdout_storage;
 
 extern "C" {
 
@@ -79,7 +87,7 @@ void ref_pi_from_ppp(const double x1[3], const double x2[3], const double x3[3],
 // CamLaserCalClosedSolution, src/LaseCamCalCeres.cpp:112-203.  Tlc row-major 4x4, in/out.
 void ref_closed_solution(int n_poses, const double* tag_q_wxyz, const double* tag_t, const long long* pts_off,
                          const double* pts, const long long* ptl_off, const double* ptl, double Tlc[16]) {
-  CoutSilencer quiet;
+  CoutSilencer quiet(&g_last_stdout_storage);
   Eigen::Matrix4d T;
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T(i, j) = Tlc[4 * i + j];
   CamLaserCalClosedSolution(make_obs(n_poses, tag_q_wxyz, tag_t, pts_off, pts, ptl_off, ptl), T);
@@ -93,7 +101,7 @@ void ref_closed_solution(int n_poses, const double* tag_q_wxyz, const double* ta
 int ref_calibration(int n_poses, const double* tag_q_wxyz, const double* tag_t, const long long* pts_off,
                      const double* pts, const long long* ptl_off, const double* ptl, double Tcl[16],
                      int use_linefitting_data, int use_boundary_constraint, double record[6], long long* n_blocks) {
-  CoutSilencer quiet;
+  CoutSilencer quiet(&g_last_stdout_storage);
   Eigen::Matrix4d T;
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T(i, j) = Tcl[4 * i + j];
   try {
@@ -113,6 +121,18 @@ int ref_calibration(int n_poses, const double* tag_q_wxyz, const double* tag_t, 
 }
 
 // LineFittingCeres, src/LaseCamCalCeres.cpp:401-433.  pts = n x 3, line in/out.
+// What the last ref_calibration / ref_closed_solution call printed on std::cout (the reference reports the
+// analysis pass — H singular values, null space, chi2 — only there, :365-381).  Returns the length.
+long long ref_last_stdout(char* buf, long long cap) {
+  const long long n = (long long)g_last_stdout_storage.size();
+  if (buf && cap > 0) {
+    const long long m = n < cap - 1 ? n : cap - 1;
+    std::memcpy(buf, g_last_stdout_storage.data(), (size_t)m);
+    buf[m] = 0;
+  }
+  return n;
+}
+
 void ref_line_fitting(const double* pts, long long n, double line[2], double record[6]) {
   CoutSilencer quiet;
   std::vector<Eigen::Vector3d> P;

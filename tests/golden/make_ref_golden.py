@@ -10,7 +10,7 @@ this container (`make -C oracle ref`, oracle/ref.py).  They pin what the referen
   * PoseLocalParameterization::Plus/Jacobian                                   (exact code path)
   * pi_from_ppp, TranScanToPoints                                              (exact code path)
   * CamLaserCalClosedSolution               whole function (SVD/LDLT are stand-ins: ~1e-14)
-  * CamLaserCalibration / LineFittingCeres  whole function: the reference's assembly loop, factor,
+  * CamLaserCalibration / LineFittingCeres  whole function (+ the printed analysis pass, 6 digits): the reference's assembly loop, factor,
                                             loss objects and parameterisation drive the stand-in
                                             ceres::Solve, i.e. the oracle's LM restatement.
 
@@ -85,8 +85,9 @@ for gen, seed, noise, lf, bd, init in [("GenerateSimData", 0, 0.0, False, False,
     else:
         T0 = sd.T_from_pose7(ref.pose_plus(sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)), np.array([0.05, -0.04, 0.03, 0.05, -0.06, 0.04])))
     Tcl, record, nb = ref.calibration(S, T0, lf, bd)
+    sv6, chi_half = ref.parse_analysis(ref.last_stdout())  # the analysis pass is only printed (:365-381), 6 significant digits
     G["calibration"].append(dict(generator=gen, seed=seed, noise=noise, linefit=lf, boundary=bd, init=init, Tcl0=T0.tolist(), Tcl=Tcl.tolist(),
-                                 n_blocks=nb, **record))
+                                 n_blocks=nb, analysis_singular_values=sv6.tolist(), analysis_chi2_half=chi_half, **record))
 
 for k in range(8):
     n = int(rng.integers(5, 160))

@@ -91,6 +91,11 @@ def test_oracle_solve_matches_reference_function(oracle_mod, case):
     assert r.summary.initial_cost == pytest.approx(case["initial_cost"], rel=1e-12)
     assert r.summary.final_cost == pytest.approx(case["final_cost"], rel=1e-10, abs=1e-18)
     assert np.abs(sd.T_from_pose7(r.pose) - np.array(case["Tcl"])).max() < 1e-12
+    # analysis pass (:316-381: no loss, no board-edge terms); the reference only prints it, with 6 significant digits
+    rec_pts = oracle_mod.flatten(S, case["linefit"], False)
+    H, b, chi2, sv6, V, n_null = oracle_mod.information(rec_pts, r.pose)
+    assert np.allclose(sv6, case["analysis_singular_values"], rtol=2e-5)
+    assert chi2 / 2.0 == pytest.approx(case["analysis_chi2_half"], rel=2e-5, abs=1e-12)
 
 
 def test_oracle_line_fit_matches_reference_function(oracle_mod):
@@ -197,6 +202,8 @@ def test_gpu_calibration_matches_reference_function(sv, case):
     assert abs(rep.result.summary.final_cost - case["final_cost"]) <= 1e-8
     assert rep.result.summary.num_iterations == case["num_iterations"]
     assert np.abs(Tcl - np.array(case["Tcl"])).max() <= 1e-10  # what is actually achieved
+    assert np.allclose(rep.singular_values, case["analysis_singular_values"], rtol=2e-5)  # printed with 6 digits
+    assert rep.chi2 / 2.0 == pytest.approx(case["analysis_chi2_half"], rel=2e-5, abs=1e-12)
 
 
 @pytest.mark.gpu
