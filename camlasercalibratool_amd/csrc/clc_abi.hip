@@ -136,12 +136,18 @@ int eval_grid(const clc_handle* h, size_t n) {
   return (int)(want < cap ? want : cap);
 }
 
+// Partial rows.  The capacity is a whole number of 256-row rounds: the controller reads rows in rounds of 256 from
+// unclamped addresses and masks the ones beyond the grid afterwards (clc::lm_tail), so every round must be mapped.
 int ensure_partials(clc_handle* h, int blocks) {
   if (blocks <= h->partials_cap_blocks) return CLC_OK;
+  const int cap = (blocks + clc::BLOCK - 1) / clc::BLOCK * clc::BLOCK;
   if (h->d_partials) CLC_HIP(hipFree(h->d_partials));
   h->d_partials = nullptr;
-  CLC_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)blocks * clc::NACC9));
-  h->partials_cap_blocks = blocks;
+  h->partials_cap_blocks = 0;
+  CLC_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)cap * clc::NACC9));
+  // on the handle's stream: a null-stream memset is not ordered against kernels on a non-blocking stream
+  CLC_HIP(hipMemsetAsync(h->d_partials, 0, sizeof(double) * (size_t)cap * clc::NACC9, h->stream));
+  h->partials_cap_blocks = cap;
   return CLC_OK;
 }
 
@@ -348,7 +354,8 @@ int clc_create(clc_handle** out, int device) {
   CLC_HIP(hipHostMalloc(&h->h_small, sizeof(double) * kSmallDoubles, hipHostMallocDefault));
   CLC_HIP(hipMalloc(&h->d_queue, sizeof(unsigned int)));
   CLC_HIP(hipMalloc(&h->d_ticket, sizeof(unsigned int)));
-  CLC_HIP(hipMemset(h->d_ticket, 0, sizeof(unsigned int)));
+  CLC_HIP(hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned int), h->own_stream));
+  CLC_HIP(hipStreamSynchronize(h->own_stream));  // the caller may switch streams (clc_set_stream) before the first launch
   CLC_HIP(hipHostMalloc(&h->h_mailbox, sizeof(clc::HostMailbox), hipHostMallocCoherent | hipHostMallocMapped));
   CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mailbox), h->h_mailbox, 0));
   std::memset(h->h_mailbox, 0, sizeof(clc::HostMailbox));

@@ -858,28 +858,34 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
   if (helper) {  // wave-uniform
     const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
     const double my_word = reinterpret_cast<const double*>(state)[cw];
+    // thread (c, rg) owns rows rg, rg + 8, ... of column c.  The row buffer is mapped in whole rounds of 256 rows
+    // (ensure_partials), so the addresses need no clamp: one base pointer, constant strides, masked sums.
     const int cc = c < NACC ? c : NACC - 1;
-    const int last = n_blocks - 1;
+    const double* base = partials + (size_t)rg * NACC + cc;
     double v[UNROLL];
 #pragma unroll
-    for (int j = 0; j < UNROLL; ++j) {
-      const int b = rg + RG * j;
-      v[j] = load_partial<COHERENT>(partials + (size_t)(b < last ? b : last) * NACC + cc);
-    }
+    for (int j = 0; j < UNROLL; ++j) v[j] = load_partial<COHERENT>(base + (size_t)(RG * j) * NACC);
     if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = my_word;
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < UNROLL; ++j) s += (c < NACC && rg + RG * j < n_blocks) ? v[j] : 0.0;
     for (int b0 = rg + RG * UNROLL; b0 < n_blocks; b0 += RG * UNROLL) {  // grids beyond 256 workgroups
+      const double* bb = partials + (size_t)b0 * NACC + cc;
 #pragma unroll
-      for (int j = 0; j < UNROLL; ++j) {
-        const int b = b0 + RG * j;
-        v[j] = load_partial<COHERENT>(partials + (size_t)(b < last ? b : last) * NACC + cc);
-      }
+      for (int j = 0; j < UNROLL; ++j) v[j] = load_partial<COHERENT>(bb + (size_t)(RG * j) * NACC);
 #pragma unroll
       for (int j = 0; j < UNROLL; ++j) s += (c < NACC && b0 + RG * j < n_blocks) ? v[j] : 0.0;
     }
     red[rg][c] = s;
+  }
+  __syncthreads();
+  // the 8 row groups are combined in order by 28 lanes in parallel (one column each): done by the controller's
+  // lane alone this was 224 serial FP64 adds behind 134 LDS reads, ~0.4 us of the launch
+  if (threadIdx.x < 32) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) t += red[g][threadIdx.x];
+    red[0][threadIdx.x] = t;  // same wave as the controller's lane: row 0 now holds the totals
   }
   __syncthreads();
   if (threadIdx.x == 64 && mailbox != nullptr)
@@ -888,12 +894,7 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
     const long long c1 = clock64();
     double tot[NACC];
 #pragma unroll
-    for (int cc = 0; cc < NACC; ++cc) {
-      double t = 0.0;
-#pragma unroll
-      for (int g = 0; g < RG; ++g) t += red[g][cc];
-      tot[cc] = t;
-    }
+    for (int cc = 0; cc < NACC; ++cc) tot[cc] = red[0][cc];
     // The LM state is used in place in LDS: copied into registers and back it cost 256 VGPRs + 48 AGPRs
     // (occupancy 1 for the fused kernel); in place 148-162, at the same controller time.
     LmState& st = *reinterpret_cast<LmState*>(sh_state);
