@@ -182,10 +182,14 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
   const bool big = (fl & clc::FLAG_WG512) != 0;
   // Compact layout: the deep pipeline (two tiles of points in flight per wave) pays only when the array streams
   // from HBM, i.e. no longer fits the 256 MiB Infinity Cache (scripts/size_sweep.py: +10 % at 9e8 B, -8 % at 1e8 B).
-  const bool deep = (fl & clc::FLAG_DEEP) != 0 ||
-                    (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
+  // Well beyond the cache (> 1.5x) the streamed tiles are also loaded non-temporally (+5-8 % at 4.5e8-9e8 B; plain
+  // loads win while the array is cache-resident, and at 2.9e8 B — C3 — there is nothing in it).
+  const bool beyond_cache = h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes;
+  const bool deep = (fl & clc::FLAG_DEEP) != 0 || beyond_cache;
   if (cp) {
     const bool pf = deep;
+    const bool nt = (fl & clc::FLAG_NONTEMPORAL) != 0 ||
+                    (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes + kInfinityCacheBytes / 2);
     if (big && pf) { if (nt) CLC_LAUNCH(true, true, true, 512); else CLC_LAUNCH(true, false, true, 512); }
     else if (big) { if (nt) CLC_LAUNCH(false, true, true, 512); else CLC_LAUNCH(false, false, true, 512); }
     else if (pf) { if (nt) CLC_LAUNCH(true, true, true, 256); else CLC_LAUNCH(true, false, true, 256); }
@@ -838,9 +842,11 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
   const int max_evals = opt.max_num_iterations + 1;
   const bool bcompact = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->bcompact_ok;
-  const bool bnt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;
-  const bool bdeep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
-                     (h->launch_auto && h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes);
+  const bool bbeyond = h->launch_auto && h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes;
+  const bool bnt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 ||
+                   (bcompact && h->launch_auto &&
+                    h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes + kInfinityCacheBytes / 2);
+  const bool bdeep = (h->launch_flags & clc::FLAG_DEEP) != 0 || bbeyond;
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
   mb->status = CLC_RUNNING;

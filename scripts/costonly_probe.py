@@ -8,12 +8,12 @@ import camlasercalibratool_amd as clc
 from camlasercalibratool_amd import simdata as sd
 x0 = sd.pose7_from_T(np.eye(4))
 sv = clc.Solver(0)
-for poses in (2000, 32000, 64000):
+for poses in (32000, 64000):
     S = sd.sim_fixed_count(7, poses, 500, noise_sigma=0.01)
     rec = clc.flatten_observations(S, False); n = rec.shape[0]
     sv.upload(rec)
-    for fl in (50, 114, 18, 82):
-        sv.set_launch(0, fl)
+    for fl, grid in ((114, 0), (118, 0), (114, 0), (118, 0), (118, 512), (86, 512), (6, 0)):
+        sv.set_launch(grid, fl)
         for jac in (True, False):
             k = min(sv.time_eval(x0, reps=50, with_jacobian=jac) for _ in range(3)) * 1e3
-            print(f"N={n} flags={fl} jac={int(jac)}: {k:8.2f} us  streamed {28*n/k/1e3:7.0f} GB/s", flush=True)
+            print(f"N={n} flags={fl} grid={grid} jac={int(jac)}: {k:8.2f} us  streamed {28*n/k/1e3:7.0f} GB/s", flush=True)
