@@ -55,7 +55,7 @@ bool all_finite(const double* p, int n) {
 
 constexpr int kDefaultLookahead = 2;
 constexpr size_t kInfinityCacheBytes = 256u << 20;  // MI355X memory-side cache (MI355X_MICROARCH.md)
-constexpr int kDefaultLaunchFlags = 2 | 16 | 32;  // prefetch + compact layout + 512-thread weighted workgroups (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py)
+constexpr int kDefaultLaunchFlags = 2 | 16 | 32 | 128;  // prefetch + compact layout + 512-thread weighted workgroups + step kernel (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py, scripts/step_check.py)
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
 constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
 
@@ -113,6 +113,8 @@ struct clc_handle {
   clc_summary* d_summaries = nullptr;
   unsigned int* d_queue = nullptr;  // small device counter (active problems)
   unsigned int* d_ticket = nullptr; // arrival counter of the fused evaluation+controller launch
+  double* d_partials_b = nullptr;   // second row buffer (inside the d_partials allocation) for the step kernel
+  clc::LmState* d_state_b = nullptr;  // second LM state buffer for the step kernel
   clc::LmState* d_states = nullptr;
   double* d_bpartials = nullptr;
   size_t bpartials_cap_blocks = 0;
@@ -144,10 +146,12 @@ int ensure_partials(clc_handle* h, int blocks) {
   if (h->d_partials) CLC_HIP(hipFree(h->d_partials));
   h->d_partials = nullptr;
   h->partials_cap_blocks = 0;
-  CLC_HIP(hipMalloc(&h->d_partials, sizeof(double) * (size_t)cap * clc::NACC9));
+  // two buffers: the step kernel alternates between them by launch parity
+  CLC_HIP(hipMalloc(&h->d_partials, 2 * sizeof(double) * (size_t)cap * clc::NACC9));
   // on the handle's stream: a null-stream memset is not ordered against kernels on a non-blocking stream
-  CLC_HIP(hipMemsetAsync(h->d_partials, 0, sizeof(double) * (size_t)cap * clc::NACC9, h->stream));
+  CLC_HIP(hipMemsetAsync(h->d_partials, 0, 2 * sizeof(double) * (size_t)cap * clc::NACC9, h->stream));
   h->partials_cap_blocks = cap;
+  h->d_partials_b = h->d_partials + (size_t)cap * clc::NACC9;
   return CLC_OK;
 }
 
@@ -353,7 +357,8 @@ int clc_create(clc_handle** out, int device) {
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CLC_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
-  CLC_HIP(hipMalloc(&h->d_state, sizeof(clc::LmState)));
+  CLC_HIP(hipMalloc(&h->d_state, 2 * sizeof(clc::LmState)));
+  h->d_state_b = h->d_state + 1;
   CLC_HIP(hipMalloc(&h->d_small, sizeof(double) * kSmallDoubles));
   CLC_HIP(hipHostMalloc(&h->h_small, sizeof(double) * kSmallDoubles, hipHostMallocDefault));
   CLC_HIP(hipMalloc(&h->d_queue, sizeof(unsigned int)));
@@ -392,7 +397,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 127)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 255)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
@@ -529,6 +534,91 @@ int clc_eval(clc_handle* h, const double pose[7], int with_loss, double loss_sca
   return CLC_OK;
 }
 
+namespace {
+
+// clc_solve as a chain of step_kernel launches (clc_kernels.hpp "Step kernel"): launch 0 evaluates at the initial
+// pose, launch k >= 1 consumes the rows of launch k-1 in every workgroup and evaluates at the next point.  The
+// host only keeps `lookahead` launches queued beyond the last pass the device reported consumed.
+int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7], clc_summary* summary,
+                  clc_iteration* trace, int trace_cap, std::chrono::steady_clock::time_point t0) {
+  const bool want_trace = trace != nullptr && trace_cap > 0;
+  if (want_trace) {
+    const int rc = ensure_trace(h, opt.max_num_iterations + 8);
+    if (rc != CLC_OK) return rc;
+  }
+  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
+  const int max_launches = opt.max_num_iterations + 2;  // (max_iterations + 1) evaluations + the final controller pass
+  clc::HostMailbox* mb = h->h_mailbox;
+  mb->n_done = 0;
+  mb->status = CLC_RUNNING;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  clc::Pose7 p0;
+  for (int i = 0; i < 7; ++i) p0.v[i] = pose[i];
+  clc_iteration* d_trace = want_trace ? h->d_trace : nullptr;
+  const int d_trace_cap = want_trace ? h->trace_cap : 0;
+  const bool deep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
+                    (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
+  clc::LmState* st[2] = {h->d_state, h->d_state_b};
+  double* rows[2] = {h->d_partials, h->d_partials_b};
+  int launched = 0, status = CLC_RUNNING, last_done = 0;
+  long long spins = 0;
+  auto t_last_progress = std::chrono::steady_clock::now();
+  for (;;) {
+    status = __atomic_load_n(&mb->status, __ATOMIC_ACQUIRE);
+    if (status != CLC_RUNNING) break;
+    const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);  // passes consumed = launches whose rows are used up
+    if (launched < max_launches && launched - done <= lookahead) {
+      const int k = launched;
+      // launch k reads state[(k-1)&1] / rows[(k-1)&1] and writes state[k&1] / rows[k&1]
+      const clc::LmState* s_in = st[(k + 1) & 1];
+      clc::LmState* s_out = st[k & 1];
+      const double* r_in = rows[(k + 1) & 1];
+      double* r_out = rows[k & 1];
+#define CLC_LAUNCH_STEP(LOSS, DEEP, MODE)                                                                     \
+  hipLaunchKernelGGL((clc::step_kernel<LOSS, DEEP, MODE>), dim3(grid), dim3(512), 0, h->stream, h->d_ctiles,    \
+                     h->d_groups, (long long)h->n_obs, s_in, s_out, opt, r_in, r_out, d_trace, d_trace_cap,      \
+                     h->d_mailbox, p0)
+#define CLC_LAUNCH_STEP_M(LOSS, DEEP)                                                                         \
+  do { if (k == 0) CLC_LAUNCH_STEP(LOSS, DEEP, 0); else if (k == 1) CLC_LAUNCH_STEP(LOSS, DEEP, 1);             \
+       else CLC_LAUNCH_STEP(LOSS, DEEP, 2); } while (0)
+      if (opt.use_loss) { if (deep) CLC_LAUNCH_STEP_M(true, true); else CLC_LAUNCH_STEP_M(true, false); }
+      else { if (deep) CLC_LAUNCH_STEP_M(false, true); else CLC_LAUNCH_STEP_M(false, false); }
+#undef CLC_LAUNCH_STEP_M
+#undef CLC_LAUNCH_STEP
+      ++launched;
+      continue;
+    }
+    if (done != last_done) { last_done = done; t_last_progress = std::chrono::steady_clock::now(); spins = 0; }
+    if ((++spins & 0xFFFF) == 0) {
+      hipError_t e = hipStreamQuery(h->stream);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(CLC_ERR_HIP, "clc_solve: stream error", e);
+      if (e == hipSuccess) {
+        status = __atomic_load_n(&mb->status, __ATOMIC_ACQUIRE);
+        if (status != CLC_RUNNING) break;
+        if (launched >= max_launches) return fail(CLC_ERR_HIP, "clc_solve: controller did not terminate");
+      }
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_last_progress).count();
+      if (waited > 30.0) return fail(CLC_ERR_HIP, "clc_solve: no progress from the device for 30 s");
+    }
+  }
+  CLC_HIP(hipGetLastError());
+  std::atomic_thread_fence(std::memory_order_acquire);
+  *summary = mb->summary;
+  for (int i = 0; i < 7; ++i) pose[i] = mb->pose[i];
+  summary->eval_kernel_ms = 0.0;
+  summary->eval_kernel_launches = 0;
+  if (want_trace) {
+    CLC_HIP(hipStreamSynchronize(h->stream));
+    const int n = std::min(std::min(summary->num_iterations + 1, trace_cap), h->trace_cap);
+    if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  summary->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve: non-finite result");
+  return CLC_OK;
+}
+
+}  // namespace
+
 int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summary* summary,
               clc_iteration* trace, int trace_cap) {
   if (!h || !pose || !summary || trace_cap < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve: bad argument");
@@ -545,6 +635,9 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
+  if ((h->launch_flags & clc::FLAG_STEP) != 0 && (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->compact_ok &&
+      (h->launch_flags & clc::FLAG_WG512) != 0 && opt.profile_events != 1)  // 1: HIP events around K1, two-kernel path
+    return solve_stepped(h, opt, grid, pose, summary, trace, trace_cap, t0);
   const int max_evals = opt.max_num_iterations + 1;
   const bool want_trace = trace != nullptr && trace_cap > 0;
   if (want_trace) {
@@ -1071,11 +1164,12 @@ int clc_debug_layout(clc_handle* h, int* compact, long long* n_groups, int* bcom
 }
 
 // Shader-clock stamps of the last lm_kernel launch: [0] kernel entry, [1] after state load +
-// partial reduction, [2] after the LM controller, [3] after publishing to the host mailbox.
-int clc_debug_lm_profile(clc_handle* h, long long out[4]) {
+// partial reduction, [2] after the LM controller, [3] after publishing to the host mailbox;
+// [4] row loads issued, [5] rows landed and summed per thread, [6] row groups combined (all need opt.profile_events).
+int clc_debug_lm_profile(clc_handle* h, long long out[8]) {
   if (!h || !out) return fail(CLC_ERR_INVALID_ARG, "clc_debug_lm_profile: bad argument");
   CLC_HIP(hipStreamSynchronize(h->stream));
-  for (int i = 0; i < 4; ++i) out[i] = h->h_mailbox->prof[i];
+  for (int i = 0; i < 8; ++i) out[i] = h->h_mailbox->prof[i];
   return CLC_OK;
 }
 

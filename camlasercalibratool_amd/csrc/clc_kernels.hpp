@@ -319,7 +319,8 @@ constexpr int FLAG_PREFETCH = 2;        // software-pipelined tile loads (next t
 constexpr int FLAG_NONTEMPORAL = 4;     // nt loads for the streamed tiles
 constexpr int FLAG_FUSED_LM = 8;        // clc_solve: controller in the tail of the evaluation launch
 constexpr int FLAG_DEEP = 64;            // compact layout: two tiles of points in flight per wave (HBM-resident arrays)
-constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 4:3 old/young wave tile weighting
+constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 3:2 old/young wave tile weighting
+constexpr int FLAG_STEP = 128;          // clc_solve: one step_kernel launch per LM iteration (compact layout)
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -832,45 +833,68 @@ __device__ __forceinline__ double load_partial(const double* p) {
   return *p;
 }
 
+// The global loads of the controller, issued as early as possible and consumed later (lm_tail): the thread's
+// word of the LM state, its share of the first 256 partial rows (fixed order: thread (c, rg) owns rows rg, rg + 8, ...
+// of column c) and, for the first lane of wave 1, the pass count.  The row buffer is mapped in whole rounds of 256
+// rows (ensure_partials), so the addresses need no clamp: one base pointer, constant strides; rows beyond the grid are
+// masked when they are summed.  (A "load or 0.0" select on the runtime row count made hipcc branch around every load,
+// cdna_hip_programming.md §5 trap (c).)
+struct LmLoads {
+  double v[32];
+  double my_word;
+  long long passes_before;
+};
+
 template <bool COHERENT, bool FIRST>
-__device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int n_blocks,
-                                        LmState* __restrict__ state, const clc_options& opt,
+__device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partials, const LmState* __restrict__ state,
+                                               LmLoads& L) {
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  constexpr int RG = BLOCK / 32;
+  L.passes_before = 0;
+  L.my_word = 0.0;
+  if (threadIdx.x < BLOCK) {  // wave-uniform: the waves beyond the first 256 threads only take part in the barriers
+    if (!FIRST && threadIdx.x == 64) L.passes_before = state->n_evals;
+    const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
+    L.my_word = reinterpret_cast<const double*>(state)[cw];
+    const int cc = c < NACC ? c : NACC - 1;
+    const double* base = partials + (size_t)rg * NACC + cc;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) L.v[j] = load_partial<COHERENT>(base + (size_t)(RG * j) * NACC);
+  }
+}
+
+// `state` is where the LM state is read from; it is written back to `state_out` (nullptr: not at all — the
+// step kernel's non-leading workgroups run the controller redundantly and keep the result in LDS only).
+// CHECK_STATUS: the staged state is inspected before anything is consumed or published; if the solve had already
+// terminated the function returns false right after the first barrier (state staged in LDS, nothing else done).
+template <bool COHERENT, bool FIRST, bool CHECK_STATUS = false>
+__device__ __forceinline__ bool lm_tail(const double* __restrict__ partials, int n_blocks,
+                                        const LmState* __restrict__ state, LmState* __restrict__ state_out,
+                                        const clc_options& opt,
                                         clc_iteration* __restrict__ trace, int trace_cap,
                                         HostMailbox* mailbox, double (*red)[32], double* sh_state,
-                                        const long long c0, const Pose7* init_pose = nullptr) {
+                                        const long long c0, const Pose7* init_pose, LmLoads& L) {
   static_assert(LM_STATE_WORDS <= BLOCK, "one state word per thread");
   // Called by every thread of the workgroup (it contains barriers); the first BLOCK threads work,
-  // the waves beyond them (512-thread fused launch) only take part in the barriers.
+  // the waves beyond them (512-thread launches) only take part in the barriers.
   const bool helper = threadIdx.x < BLOCK;
   // Progress for the host's launch-ahead metering is published EARLY, by the first lane of wave 1
   // (not the controller's wave): the ~1.5 us a store to pinned host memory needs to be
   // acknowledged then overlaps the controller instead of delaying the end of the launch.
-  long long passes_before = 0;
-  if (!FIRST && threadIdx.x == 64) passes_before = state->n_evals;
-  // Issue every global load before the first use: the thread's word of the LM state and its
-  // share of the block partials (fixed order: thread (c, rg) owns rows rg, rg+8, ... of column
-  // c).  One memory latency instead of several.
+  const long long passes_before = L.passes_before;
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   constexpr int RG = BLOCK / 32, UNROLL = 32;
-  // Loads are UNCONDITIONAL from clamped (always valid) addresses and masked afterwards: a
-  // "load or 0.0" select on a runtime bound makes hipcc branch around every load and wait in
-  // between (cdna_hip_programming.md §5 trap (c)).
   if (helper) {  // wave-uniform
-    const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
-    const double my_word = reinterpret_cast<const double*>(state)[cw];
-    // thread (c, rg) owns rows rg, rg + 8, ... of column c.  The row buffer is mapped in whole rounds of 256 rows
-    // (ensure_partials), so the addresses need no clamp: one base pointer, constant strides, masked sums.
     const int cc = c < NACC ? c : NACC - 1;
-    const double* base = partials + (size_t)rg * NACC + cc;
-    double v[UNROLL];
-#pragma unroll
-    for (int j = 0; j < UNROLL; ++j) v[j] = load_partial<COHERENT>(base + (size_t)(RG * j) * NACC);
-    if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = my_word;
+    const long long ca = clock64();
+    if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = L.my_word;
     double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < UNROLL; ++j) s += (c < NACC && rg + RG * j < n_blocks) ? v[j] : 0.0;
+    for (int j = 0; j < UNROLL; ++j) s += (c < NACC && rg + RG * j < n_blocks) ? L.v[j] : 0.0;
+    if (opt.profile_events && threadIdx.x == 0 && mailbox != nullptr) { mailbox->prof[4] = ca; mailbox->prof[5] = clock64(); }
     for (int b0 = rg + RG * UNROLL; b0 < n_blocks; b0 += RG * UNROLL) {  // grids beyond 256 workgroups
       const double* bb = partials + (size_t)b0 * NACC + cc;
+      double v[UNROLL];
 #pragma unroll
       for (int j = 0; j < UNROLL; ++j) v[j] = load_partial<COHERENT>(bb + (size_t)(RG * j) * NACC);
 #pragma unroll
@@ -879,15 +903,19 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
     red[rg][c] = s;
   }
   __syncthreads();
+  if (CHECK_STATUS && !FIRST && reinterpret_cast<const LmState*>(sh_state)->status != CLC_RUNNING) return false;
   // the 8 row groups are combined in order by 28 lanes in parallel (one column each): done by the controller's
   // lane alone this was 224 serial FP64 adds behind 134 LDS reads, ~0.4 us of the launch
   if (threadIdx.x < 32) {
     double t = 0.0;
 #pragma unroll
     for (int g = 0; g < RG; ++g) t += red[g][threadIdx.x];
-    red[0][threadIdx.x] = t;  // same wave as the controller's lane: row 0 now holds the totals
+    red[0][threadIdx.x] = t;  // row 0 now holds the totals
+    if (opt.profile_events && threadIdx.x == 0 && mailbox != nullptr) mailbox->prof[6] = clock64();
   }
-  __syncthreads();
+  // no workgroup barrier here: the 28 lanes above and the controller's lane below are the same wave, whose LDS
+  // operations execute in program order; the other waves go straight to the barrier at the end
+  __builtin_amdgcn_wave_barrier();
   if (threadIdx.x == 64 && mailbox != nullptr)
     __hip_atomic_store(&mailbox->n_done, (int32_t)(passes_before + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (threadIdx.x == 0) {
@@ -921,7 +949,9 @@ __device__ __forceinline__ void lm_tail(const double* __restrict__ partials, int
     }
   }
   __syncthreads();
-  if (threadIdx.x < LM_STATE_WORDS) reinterpret_cast<double*>(state)[threadIdx.x] = sh_state[threadIdx.x];
+  if (state_out != nullptr && threadIdx.x < LM_STATE_WORDS)
+    reinterpret_cast<double*>(state_out)[threadIdx.x] = sh_state[threadIdx.x];
+  return true;
 }
 
 template <bool FIRST>
@@ -934,7 +964,9 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
   __shared__ double sh_state[LM_STATE_WORDS];
   const long long c0 = clock64();
   if (!FIRST && state->status != CLC_RUNNING) return;
-  lm_tail<false, FIRST>(partials, n_blocks, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, &pose0);
+  LmLoads L;
+  lm_issue_loads<false, FIRST>(partials, state, L);
+  lm_tail<false, FIRST>(partials, n_blocks, state, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, &pose0, L);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1002,7 +1034,80 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
   // ---- last-arriving workgroup: every other row is complete and visible at agent scope ----
   const long long c0 = clock64();
   if (threadIdx.x == 0) __hip_atomic_store(ticket_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  lm_tail<true, false>(partials, (int)gridDim.x, state, opt, trace, trace_cap, mailbox, red, sh_state, c0);
+  LmLoads L;
+  lm_issue_loads<true, false>(partials, state, L);
+  lm_tail<true, false>(partials, (int)gridDim.x, state, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, nullptr, L);
+}
+
+// ---------------------------------------------------------------------------------------
+// Step kernel — ONE launch per LM iteration, no second kernel, no inter-workgroup hand-off.
+// Launch k evaluates at the point x_k and leaves one partial row per workgroup; launch k+1 starts
+// by letting EVERY workgroup read those rows and run the controller redundantly (same inputs, same
+// instruction stream: bit-identical x_{k+1} everywhere), then streams its tiles at x_{k+1}.  That
+// removes the controller's own launch (launch boundary + kernel-argument fetch + its barrier
+// skew, ~4 us of the ~16 us an iteration took at 10^6 observations) and overlaps the controller
+// with the first tile loads, which are issued before it (the streaming loops call `get_pose` after
+// their prologue loads).  Workgroup 0 alone writes the advanced state, the trace and the host
+// mailbox.  LM state and partial rows are double-buffered by launch parity, because a workgroup of
+// launch k+1 may still be reading what another one is already overwriting.
+//   MODE 0: first launch of a solve (pose by value, nothing to consume)
+//   MODE 1: second launch (controller initialises the LM state: lm_init + first rows)
+//   MODE 2: steady state
+// A launch that finds the solve already terminated (queued ahead by the host) copies the state forward, so that
+// the launch queued behind it sees the termination too, and exits without touching the host mailbox.
+// ---------------------------------------------------------------------------------------
+template <bool WITH_LOSS, bool DEEP, int MODE>
+__global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ctiles,
+                                                   const double* __restrict__ groups, const long long n,
+                                                   const LmState* __restrict__ state_in,
+                                                   LmState* __restrict__ state_out, const clc_options opt,
+                                                   const double* __restrict__ rows_in,
+                                                   double* __restrict__ rows_out,
+                                                   clc_iteration* __restrict__ trace, const int trace_cap,
+                                                   HostMailbox* mailbox, const Pose7 pose0) {
+  __shared__ double red[BLOCK / 32][32];
+  __shared__ double sh_state[LM_STATE_WORDS];
+  const long long c0 = clock64();
+  const bool leader = blockIdx.x == 0;
+  // the controller's loads go out first: its chain (rows -> combine -> LM step) is the long pole of the launch, the
+  // tile prologue loads issued next only have to be in flight before it ends
+  LmLoads L;
+  if (MODE != 0) lm_issue_loads<false, MODE == 1>(rows_in, state_in, L);
+  auto get_pose = [&](PoseU& P) -> bool {
+    if (MODE == 0) {
+      load_pose(pose0.v, P);
+      return true;
+    }
+    const bool consumed = lm_tail<false, MODE == 1, true>(rows_in, (int)gridDim.x, state_in,
+                                                           leader ? state_out : nullptr, opt, leader ? trace : nullptr,
+                                                           leader ? trace_cap : 0, leader ? mailbox : nullptr, red,
+                                                           sh_state, c0, &pose0, L);
+    if (!consumed) {
+      // the solve had terminated before this launch: hand the state on (the launch queued behind this one reads
+      // the other buffer) and leave; the host mailbox is NOT touched — it may already belong to the next solve
+      if (leader && threadIdx.x < LM_STATE_WORDS) reinterpret_cast<double*>(state_out)[threadIdx.x] = sh_state[threadIdx.x];
+      return false;
+    }
+    const LmState* st = reinterpret_cast<const LmState*>(sh_state);
+    const bool running = st->status == CLC_RUNNING;
+    double x[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = st->x_eval[i];
+    load_pose(x, P);
+    return running;
+  };
+  const double lf = opt.loss_scale_factor;
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const WaveMap wm = make_wave_map<512>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
+  bool active;
+  if (DEEP) active = stream_ctiles_deep<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
+  else active = stream_ctiles<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
+  if (!active) return;  // the controller terminated the solve: nothing to evaluate
+  block_reduce_store<8>(acc, 0, rows_out + (size_t)blockIdx.x * NACC);
 }
 
 __global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0,

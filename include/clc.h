@@ -81,7 +81,9 @@ typedef struct clc_options {
                              last one the device reported done (pinned mailbox, no blocking
                              sync); 0 = library default (2)                                  */
   int32_t profile_events; /* 1: bracket every evaluation-kernel launch with HIP events on the
-                             handle's stream and report them in clc_summary                  */
+                             handle's stream and report them in clc_summary (the solve then
+                             uses the [evaluation, controller] launch pair, not the one-launch
+                             step kernel); 2: controller cycle stamps only (debug)            */
 } clc_options;
 
 /* ceres::IterationSummary subset, one per recorded iteration (iteration 0 = initial
@@ -130,8 +132,10 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
  * prefetch of the next tile (64-byte layout), 4 = non-temporal loads, 8 = clc_solve runs the LM
  * controller in the tail of the evaluation launch (one launch per iteration), 16 = compact 28-byte
  * layout, 32 = 512-thread workgroups with old/young wave tile weighting, 64 = compact layout with
- * two tiles in flight per wave; -1 = library default (2|16|32, and 64 chosen per launch when the
- * array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
+ * two tiles in flight per wave, 128 = clc_solve issues ONE launch per LM iteration (every workgroup
+ * runs the controller on the previous launch's partial rows before it streams; needs 16 and 32);
+ * -1 = library default (2|16|32|128, and 64 / 4 chosen per launch when the array exceeds the
+ * 256 MiB Infinity Cache).  Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 
 /* ---- problem assembly (host) --------------------------------------------------------

@@ -298,6 +298,39 @@ def test_fused_controller_launch_matches_two_kernel_path(sv, oracle_mod, grid):
     assert first.summary.num_iterations == ref.summary.num_iterations
 
 
+@pytest.mark.parametrize("grid", [0, 1, 7, 256, 300, 1000, 2048])
+@pytest.mark.parametrize("n_poses,noise", [(400, 0.01), (3, 0.03)])
+def test_step_kernel_solve_matches_two_kernel_path(sv, oracle_mod, grid, n_poses, noise):
+    """flags bit 128 (the default): one step_kernel launch per LM iteration, every workgroup running the controller
+    redundantly on the previous launch's rows.  Same grid => bit-identical to the [eval_kernel, lm_kernel] path,
+    including the per-iteration trace, for any number of workgroups (fewer/more than CUs, more than one round of
+    256 rows), repeated back to back (state / row double buffers, launches queued ahead of a finished solve)."""
+    S = sd.sim_fixed_count(77, n_poses, 500, noise_sigma=noise)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    sv.set_launch(grid, 2 | 16 | 32)
+    two = sv.solve(X0)
+    sv.set_launch(grid, 2 | 16 | 32 | 128)
+    for rep in range(25):
+        r = sv.solve(X0)
+        assert np.array_equal(r.pose, two.pose) and r.summary.final_cost == two.summary.final_cost, rep
+        assert r.summary.num_iterations == two.summary.num_iterations and r.summary.termination == two.summary.termination
+        assert r.summary.num_evaluations == two.summary.num_evaluations
+        assert [(t.cost, t.step_is_successful, t.trust_region_radius) for t in r.trace] == \
+               [(t.cost, t.step_is_successful, t.trust_region_radius) for t in two.trace]
+    o = clc.default_options()
+    o.max_num_iterations = 3  # stopped by the iteration cap: NO_CONVERGENCE through the same path
+    a = sv.solve(X0, o)
+    sv.set_launch(grid, 2 | 16 | 32)
+    b = sv.solve(X0, o)
+    sv.set_launch(0, -1)
+    assert a.summary.termination == b.summary.termination == 5  # NO_CONVERGENCE and np.array_equal(a.pose, b.pose)
+    assert a.summary.num_iterations == b.summary.num_iterations == 3
+    assert _dT(two.pose, ref.pose) <= T_TOL and abs(two.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert two.summary.num_iterations == ref.summary.num_iterations
+
+
 def test_c5_boundary_constraint_mixed_terms(sv, oracle_mod):
     """configs[4] (reduced): board-edge residuals (LaseCamCalCeres.cpp:258-294) mixed with the
     point residuals, same record type, same kernel."""
