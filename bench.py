@@ -176,24 +176,39 @@ def main():
             "termination": clc.TERMINATION.get(res.summary.termination),
         }
 
-        # ---- roofline of the dominant kernel (eval_kernel<loss,jac,prefetch,nt>) ----
-        # HIP events on the solver's stream around 200 back-to-back launches of the kernel on the
-        # same resident observation array and pose: this is the measurement that agrees with
-        # rocprofv3's per-dispatch durations.  Event PAIRS around single ~11 us launches inside a
-        # solve add ~3 us of event/dispatch overhead per pair and are reported separately.
+        # ---- roofline of the dominant kernel ----
+        # The timed region consists of step_kernel launches only: one per evaluation pass (every workgroup first runs
+        # the LM controller on the previous launch's partial rows, then streams its share of the observations) plus
+        # one final controller-only launch per solve.  Its launch period is measured with HIP events on the solver's
+        # stream (below); the rocprofv3 average of the streaming launches of step_kernel<...,2> in profiles/ is the
+        # per-dispatch figure it must agree with.  The wall time of the timed region per pass is reported next to it.
+        passes = res.summary.num_evaluations
+        wall_ms_per_pass = (1e3 * elapsed_max / args.steps) / passes
+        # HIP events on the solver's stream right before launch 2 and right after launch passes-1 of a solve: the
+        # steady-state launches, every one of which consumed a pass and streamed the array
+        step_ms = min(solver.time_steps(x0, 2, passes - 1)[0] for _ in range(5)) if passes >= 4 else wall_ms_per_pass
+        # the streaming part alone: HIP events on the solver's stream around 200 back-to-back launches of
+        # eval_kernel (same loop, same layout, no controller prologue) on the same resident array and pose
         b2b = min(solver.time_eval(x0, reps=200) for _ in range(3))
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "kernel": "clc::eval_kernel<loss=1,jac=1,prefetch=1,nt=0,compact=1>",
+                "kernel": "clc::step_kernel<loss=1,deep=0,mode=2> (controller prologue + compact streaming loop)",
                 "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs,
-                "achieved": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9, "avg_kernel_ms": b2b,
-                "timing": "hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)"}
+                "achieved": BYTES_PER_EVAL * n_obs / (step_ms * 1e-3) / 1e9, "avg_kernel_ms": step_ms,
+                "timing": f"hipEvent pair on the solver's stream around launches 2..{passes - 1} (steady state, back to back) of one "
+                          "clc_solve, / number of launches (best of 5)",
+                "timed_region_wall_ms_per_pass": wall_ms_per_pass,
+                "streaming_alone": {"kernel": "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
+                                    "avg_kernel_ms": b2b, "achieved": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9,
+                                    "frac": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "timing": "hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)"}}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         # The default layout is a lossless re-encoding of the 64-byte records (28 B/obs): the bytes
         # actually streamed are fewer than the algorithmic bytes the contract prices the kernel at.
         roof["layout"] = "compact (24 B point + 4 B group id per observation; group table per scan)"
         roof["streamed_bytes_per_launch"] = COMPACT_BYTES_PER_EVAL * n_obs
-        roof["achieved_streamed"] = COMPACT_BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9
+        roof["achieved_streamed"] = COMPACT_BYTES_PER_EVAL * n_obs / (step_ms * 1e-3) / 1e9
         roof["frac_streamed"] = roof["achieved_streamed"] / HBM_PEAK_GBS
+        roof["streaming_alone"]["achieved_streamed"] = COMPACT_BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9
         # same kernel on the 64-byte tiles (clc_set_launch flags = prefetch + non-temporal)
         solver.set_launch(0, 6)
         b2b64 = min(solver.time_eval(x0, reps=200) for _ in range(3))

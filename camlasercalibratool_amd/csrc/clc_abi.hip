@@ -539,8 +539,11 @@ namespace {
 // clc_solve as a chain of step_kernel launches (clc_kernels.hpp "Step kernel"): launch 0 evaluates at the initial
 // pose, launch k >= 1 consumes the rows of launch k-1 in every workgroup and evaluates at the next point.  The
 // host only keeps `lookahead` launches queued beyond the last pass the device reported consumed.
+// win_first/win_last/win_ms (profiling hook clc_time_steps): HIP events are recorded on the stream right before launch
+// `win_first` and right after launch `win_last`; *win_ms receives the elapsed time between them.
 int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7], clc_summary* summary,
-                  clc_iteration* trace, int trace_cap, std::chrono::steady_clock::time_point t0) {
+                  clc_iteration* trace, int trace_cap, std::chrono::steady_clock::time_point t0,
+                  int win_first = -1, int win_last = -1, float* win_ms = nullptr) {
   const bool want_trace = trace != nullptr && trace_cap > 0;
   if (want_trace) {
     const int rc = ensure_trace(h, opt.max_num_iterations + 8);
@@ -569,6 +572,7 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
     const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);  // passes consumed = launches whose rows are used up
     if (launched < max_launches && launched - done <= lookahead) {
       const int k = launched;
+      if (win_ms && k == win_first) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
       // launch k reads state[(k-1)&1] / rows[(k-1)&1] and writes state[k&1] / rows[k&1]
       const clc::LmState* s_in = st[(k + 1) & 1];
       clc::LmState* s_out = st[k & 1];
@@ -585,6 +589,7 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
       else { if (deep) CLC_LAUNCH_STEP_M(false, true); else CLC_LAUNCH_STEP_M(false, false); }
 #undef CLC_LAUNCH_STEP_M
 #undef CLC_LAUNCH_STEP
+      if (win_ms && k == win_last) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
       ++launched;
       continue;
     }
@@ -613,11 +618,45 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
     if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
   }
   summary->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (win_ms) {
+    *win_ms = -1.f;
+    if (launched > win_last && win_first >= 0) {
+      CLC_HIP(hipStreamSynchronize(h->stream));
+      CLC_HIP(hipEventElapsedTime(win_ms, h->ev[0], h->ev[1]));
+    }
+  }
   if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve: non-finite result");
   return CLC_OK;
 }
 
 }  // namespace
+
+// Profiling hook (not part of include/clc.h): one default clc_solve through the step kernel with HIP events on the
+// handle's stream right before launch `first` and right after launch `last`; *avg_ms = elapsed / (last - first + 1),
+// i.e. the mean period of those back-to-back step_kernel launches.  Launch 0 evaluates the start pose, launch k >= 1
+// consumes pass k-1; choose 2 <= first <= last <= passes - 1 to cover steady-state launches that all streamed.
+extern "C" int clc_time_steps(clc_handle* h, const double pose0[7], int first, int last, double* avg_ms, int* passes) {
+  if (!h || !pose0 || !avg_ms || first < 0 || last < first) return fail(CLC_ERR_INVALID_ARG, "clc_time_steps: bad argument");
+  if (!h->d_tiles || !h->compact_ok) return fail(CLC_ERR_NO_DATA, "clc_time_steps: no (compact) observations uploaded");
+  CLC_HIP(hipSetDevice(h->device));
+  int rc = ensure_events(h, 2);
+  if (rc != CLC_OK) return rc;
+  const int grid = eval_grid(h, h->n_obs);
+  rc = ensure_partials(h, grid);
+  if (rc != CLC_OK) return rc;
+  clc_options opt;
+  clc_options_default(&opt);
+  double pose[7];
+  for (int i = 0; i < 7; ++i) pose[i] = pose0[i];
+  clc_summary sm;
+  float ms = -1.f;
+  rc = solve_stepped(h, opt, grid, pose, &sm, nullptr, 0, std::chrono::steady_clock::now(), first, last, &ms);
+  if (rc != CLC_OK) return rc;
+  if (passes) *passes = (int)sm.num_evaluations;
+  if (ms < 0.f) return fail(CLC_ERR_INVALID_ARG, "clc_time_steps: the solve ended before launch `last`");
+  *avg_ms = (double)ms / (double)(last - first + 1);
+  return CLC_OK;
+}
 
 int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summary* summary,
               clc_iteration* trace, int trace_cap) {

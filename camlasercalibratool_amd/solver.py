@@ -192,6 +192,15 @@ class Solver:
         check(self._L.clc_debug_wave_reduce(self._h, dptr(lanes), dptr(out), C.c_int(reduce_mode)), "clc_debug_wave_reduce")
         return out
 
+    def time_steps(self, pose: np.ndarray, first: int, last: int) -> Tuple[float, int]:
+        """Mean period [ms] of the step_kernel launches first..last of one default solve (HIP events on the handle's
+        stream right before launch `first` and right after launch `last`) and the solve's number of passes."""
+        ms = C.c_double()
+        n = C.c_int()
+        check(self._L.clc_time_steps(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(first), C.c_int(last),
+                                     C.byref(ms), C.byref(n)), "clc_time_steps")
+        return ms.value, n.value
+
     def time_eval(self, pose: np.ndarray, reps: int = 20, with_loss: bool = True, loss_scale_factor: float = 0.05,
                   with_jacobian: bool = True) -> float:
         """Mean duration [ms] of `reps` back-to-back evaluation-kernel launches (HIP events on the
