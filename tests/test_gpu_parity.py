@@ -327,6 +327,12 @@ def test_step_kernel_solve_matches_two_kernel_path(sv, oracle_mod, grid, n_poses
     sv.set_launch(0, -1)
     assert a.summary.termination == b.summary.termination == 5  # NO_CONVERGENCE and np.array_equal(a.pose, b.pose)
     assert a.summary.num_iterations == b.summary.num_iterations == 3
+    o.max_num_iterations = 0  # one evaluation, no step
+    sv.set_launch(grid, 2 | 16 | 32 | 128)
+    z = sv.solve(X0, o)
+    sv.set_launch(0, -1)
+    assert z.summary.termination == 5 and z.summary.num_iterations == 0 and z.summary.num_evaluations == 1
+    assert np.array_equal(z.pose, X0) and z.summary.final_cost == z.summary.initial_cost == two.summary.initial_cost
     assert _dT(two.pose, ref.pose) <= T_TOL and abs(two.summary.final_cost - ref.summary.final_cost) <= COST_TOL
     assert two.summary.num_iterations == ref.summary.num_iterations
 
