@@ -9,7 +9,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("CLC_LIBRARY") or os.path.join(CSRC, "libclc_hip.so")  # CLC_LIBRARY: A/B a different build
 SOURCES = ["clc_abi.hip", "clc_kernels.hpp", "clc_lm.hpp", "clc_math.hpp", "clc_host.hpp"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+# -ffp-contract=on: FMA contraction only where the source spells one expression a*b+c (or fma()).  hipcc's default
+# (fast) lets the backend fuse across statements, and it did so differently in different kernels that inline the
+# same device functions — the step kernel and the [eval, lm] launch pair then differed in the last bits on 1 of 60
+# random problems.  With `on` every path computes bit-identical results; same speed.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on"]
 
 
 def _hipcc() -> str:
@@ -23,7 +27,8 @@ def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "clc.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "clc.h"),
+                                                       os.path.abspath(__file__)]  # this file holds the compiler flags
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

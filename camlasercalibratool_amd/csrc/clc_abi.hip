@@ -1,7 +1,7 @@
 // clc_abi.hip — implementation of the C-ABI declared in include/clc.h: HIP host code that
 // owns device memory, the stream and the launch sequence of the kernels in
 // clc_kernels.hpp.  Built for gfx950 only:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC clc_abi.hip -o libclc_hip.so
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=on clc_abi.hip -o libclc_hip.so
 #include <hip/hip_runtime.h>
 
 #include <atomic>

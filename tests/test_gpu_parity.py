@@ -337,6 +337,41 @@ def test_step_kernel_solve_matches_two_kernel_path(sv, oracle_mod, grid, n_poses
     assert two.summary.num_iterations == ref.summary.num_iterations
 
 
+def test_randomized_problems_step_vs_pair_vs_oracle(sv, oracle_mod):
+    """60 random problems (1 ... 3x10^4 observations, ragged scans, noise, random start within the basin, loss on/off):
+    the default step-kernel solve equals the launch-pair solve bit for bit and the oracle within the BASELINE gates,
+    with the same iteration count and termination."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(60):
+        n_poses = int(rng.integers(3, 60))
+        pts = int(rng.integers(2, 500))
+        S = sd.sim_fixed_count(1000 + case, n_poses, pts, noise_sigma=float(rng.choice([0.0, 0.005, 0.02])))
+        rec = clc.flatten_observations(S, False)
+        n = int(rng.integers(max(8, rec.shape[0] // 2), rec.shape[0] + 1))
+        rec = np.ascontiguousarray(rec[:n])
+        gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+        x0 = oracle_mod.pose_plus(gt, rng.normal(size=6) * np.array([0.05, 0.05, 0.05, 0.08, 0.08, 0.08])) if case % 3 else X0
+        o = clc.default_options()
+        o.use_loss = int(case % 5 != 0)
+        oo = _mirror(oracle_mod, o)
+        sv.upload(rec)
+        sv.set_launch(0, 2 | 16 | 32 | 128)
+        a = sv.solve(x0, o)
+        sv.set_launch(0, 2 | 16 | 32)
+        b = sv.solve(x0, o)
+        sv.set_launch(0, -1)  # library default: may pick another layout / workgroup size when the scans are too short
+        d = sv.solve(x0, o)   # for the compact layout — equal to the others up to summation order only
+        ref = oracle_mod.solve(rec, x0, options=oo, linear_solver="qr")
+        assert np.array_equal(a.pose, b.pose) and a.summary.final_cost == b.summary.final_cost, case
+        assert a.summary.termination == b.summary.termination == d.summary.termination == ref.summary.termination, case
+        assert a.summary.num_iterations == b.summary.num_iterations == d.summary.num_iterations == ref.summary.num_iterations, (case, n)
+        assert abs(a.summary.final_cost - ref.summary.final_cost) <= COST_TOL and abs(d.summary.final_cost - ref.summary.final_cost) <= COST_TOL, case
+        worst = max(worst, _dT(a.pose, ref.pose), _dT(d.pose, ref.pose))
+        assert worst <= T_TOL, (case, n, worst)
+    sv.set_launch(0, -1)
+
+
 def test_c5_boundary_constraint_mixed_terms(sv, oracle_mod):
     """configs[4] (reduced): board-edge residuals (LaseCamCalCeres.cpp:258-294) mixed with the
     point residuals, same record type, same kernel."""
