@@ -20,6 +20,22 @@
 
 namespace clc {
 
+// 1/sqrt(x) for x > 0.  Device: v_rsq_f64 seed (~2^-23) + two Newton steps (error ~1 ulp), 9 instructions instead of
+// the ~27 of an IEEE sqrt followed by an IEEE division — the LM controller is a single lane's FP64 issue stream and
+// pays for every one of them (eight reciprocal square roots per step: six Cholesky pivots, two Plus).
+// Host (unit shim, tests only): the plain expression.
+CLC_HD double rsqrt_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 // q = (x,y,z,w) as stored in the 7-vector (src/LaseCamCalCeres.cpp:219); R row-major.
 // No normalisation, like Eigen.
 CLC_HD void quat_to_rot(const double* q, double* R) {
@@ -63,7 +79,7 @@ CLC_HD void pose_plus_rcp(const double* x, const double* delta, double* out) {
   const double qx = aw * bx + ax + ay * bz - az * by;
   const double qy = aw * by + ay + az * bx - ax * bz;
   const double qz = aw * bz + az + ax * by - ay * bx;
-  const double inv = 1.0 / sqrt(qx * qx + qy * qy + qz * qz + w * w);
+  const double inv = rsqrt_pos(qx * qx + qy * qy + qz * qz + w * w);
   out[3] = qx * inv;
   out[4] = qy * inv;
   out[5] = qz * inv;
@@ -92,7 +108,7 @@ CLC_HD bool chol_solve(const double* A, const double* b, double* y, double* L, d
     double d = A[N * j + j];
     CLC_ROLLED for (int k = 0; k < j; ++k) d -= L[N * j + k] * L[N * j + k];
     if (!(d > 0.0)) return false;
-    const double inv = 1.0 / sqrt(d);
+    const double inv = rsqrt_pos(d);
     L[N * j + j] = inv;
     CLC_ROLLED for (int i = j + 1; i < N; ++i) {
       double s = A[N * i + j];
