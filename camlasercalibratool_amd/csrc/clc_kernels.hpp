@@ -834,32 +834,41 @@ __device__ __forceinline__ double load_partial(const double* p) {
 }
 
 // The global loads of the controller, issued as early as possible and consumed later (lm_tail): the thread's
-// word of the LM state, its share of the first 256 partial rows (fixed order: thread (c, rg) owns rows rg, rg + 8, ...
-// of column c) and, for the first lane of wave 1, the pass count.  The row buffer is mapped in whole rounds of 256
-// rows (ensure_partials), so the addresses need no clamp: one base pointer, constant strides; rows beyond the grid are
-// masked when they are summed.  (A "load or 0.0" select on the runtime row count made hipcc branch around every load,
-// cdna_hip_programming.md §5 trap (c).)
+// word of the LM state, its share of the first 256 partial rows and, for the first lane of wave 1, the pass count.
+// Summation tree (the same for every caller, so all solve paths agree bit for bit): 16 row groups, group g = rows
+// g, g + 16, g + 32, ... summed in that order, then the 16 group sums combined in order.  With HT = 512 helper
+// threads, thread (c, g) owns group g of column c (16 loads per round of 256 rows); with HT = 256 it owns groups g and
+// g + 8 (two separate sums of 16).  The row buffer is mapped in whole rounds of 256 rows (ensure_partials), so the
+// addresses need no clamp: one base pointer, constant strides; rows beyond the grid are masked when they are summed.
+// (A "load or 0.0" select on the runtime row count made hipcc branch around every load, cdna_hip_programming.md §5
+// trap (c).)
+constexpr int LM_GROUPS = 16;
+
 struct LmLoads {
-  double v[32];
+  double v[32];  // HT = 256: [0,16) group g, [16,32) group g + 8;  HT = 512: [0,16) group g
   double my_word;
   long long passes_before;
 };
 
-template <bool COHERENT, bool FIRST>
+template <bool COHERENT, bool FIRST, int HT>
 __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partials, const LmState* __restrict__ state,
                                                LmLoads& L) {
-  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  constexpr int RG = BLOCK / 32;
+  static_assert(HT == 256 || HT == 512, "helper threads");
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   L.passes_before = 0;
   L.my_word = 0.0;
-  if (threadIdx.x < BLOCK) {  // wave-uniform: the waves beyond the first 256 threads only take part in the barriers
+  if (threadIdx.x < HT) {  // wave-uniform
     if (!FIRST && threadIdx.x == 64) L.passes_before = state->n_evals;
     const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
     L.my_word = reinterpret_cast<const double*>(state)[cw];
     const int cc = c < NACC ? c : NACC - 1;
-    const double* base = partials + (size_t)rg * NACC + cc;
+    const double* base = partials + (size_t)g * NACC + cc;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) L.v[j] = load_partial<COHERENT>(base + (size_t)(RG * j) * NACC);
+    for (int j = 0; j < 16; ++j) L.v[j] = load_partial<COHERENT>(base + (size_t)(LM_GROUPS * j) * NACC);
+    if (HT == 256) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) L.v[16 + j] = load_partial<COHERENT>(base + (size_t)(8 + LM_GROUPS * j) * NACC);
+    }
   }
 }
 
@@ -867,49 +876,60 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
 // step kernel's non-leading workgroups run the controller redundantly and keep the result in LDS only).
 // CHECK_STATUS: the staged state is inspected before anything is consumed or published; if the solve had already
 // terminated the function returns false right after the first barrier (state staged in LDS, nothing else done).
-template <bool COHERENT, bool FIRST, bool CHECK_STATUS = false>
+// `red` is [LM_GROUPS][32] doubles of LDS.
+template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS = false>
 __device__ __forceinline__ bool lm_tail(const double* __restrict__ partials, int n_blocks,
                                         const LmState* __restrict__ state, LmState* __restrict__ state_out,
                                         const clc_options& opt,
                                         clc_iteration* __restrict__ trace, int trace_cap,
                                         HostMailbox* mailbox, double (*red)[32], double* sh_state,
                                         const long long c0, const Pose7* init_pose, LmLoads& L) {
-  static_assert(LM_STATE_WORDS <= BLOCK, "one state word per thread");
-  // Called by every thread of the workgroup (it contains barriers); the first BLOCK threads work,
-  // the waves beyond them (512-thread launches) only take part in the barriers.
-  const bool helper = threadIdx.x < BLOCK;
+  static_assert(LM_STATE_WORDS <= 256, "one state word per thread");
+  // Called by every thread of the workgroup (it contains barriers); the first HT threads work, any waves beyond
+  // them only take part in the barriers.
+  const bool helper = threadIdx.x < HT;
   // Progress for the host's launch-ahead metering is published EARLY, by the first lane of wave 1
   // (not the controller's wave): the ~1.5 us a store to pinned host memory needs to be
   // acknowledged then overlaps the controller instead of delaying the end of the launch.
   const long long passes_before = L.passes_before;
-  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  constexpr int RG = BLOCK / 32, UNROLL = 32;
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   if (helper) {  // wave-uniform
     const int cc = c < NACC ? c : NACC - 1;
     const long long ca = clock64();
     if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = L.my_word;
-    double s = 0.0;
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < UNROLL; ++j) s += (c < NACC && rg + RG * j < n_blocks) ? L.v[j] : 0.0;
-    if (opt.profile_events && threadIdx.x == 0 && mailbox != nullptr) { mailbox->prof[4] = ca; mailbox->prof[5] = clock64(); }
-    for (int b0 = rg + RG * UNROLL; b0 < n_blocks; b0 += RG * UNROLL) {  // grids beyond 256 workgroups
-      const double* bb = partials + (size_t)b0 * NACC + cc;
-      double v[UNROLL];
+    for (int j = 0; j < 16; ++j) s0 += (c < NACC && g + LM_GROUPS * j < n_blocks) ? L.v[j] : 0.0;
+    if (HT == 256) {
 #pragma unroll
-      for (int j = 0; j < UNROLL; ++j) v[j] = load_partial<COHERENT>(bb + (size_t)(RG * j) * NACC);
-#pragma unroll
-      for (int j = 0; j < UNROLL; ++j) s += (c < NACC && b0 + RG * j < n_blocks) ? v[j] : 0.0;
+      for (int j = 0; j < 16; ++j) s1 += (c < NACC && g + 8 + LM_GROUPS * j < n_blocks) ? L.v[16 + j] : 0.0;
     }
-    red[rg][c] = s;
+    if (opt.profile_events && threadIdx.x == 0 && mailbox != nullptr) { mailbox->prof[4] = ca; mailbox->prof[5] = clock64(); }
+    for (int b0 = 256; b0 < n_blocks; b0 += 256) {  // grids beyond 256 workgroups: further rounds of 256 rows
+      const double* bb = partials + (size_t)(b0 + g) * NACC + cc;
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = load_partial<COHERENT>(bb + (size_t)(LM_GROUPS * j) * NACC);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s0 += (c < NACC && b0 + g + LM_GROUPS * j < n_blocks) ? v[j] : 0.0;
+      if (HT == 256) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = load_partial<COHERENT>(bb + (size_t)(8 + LM_GROUPS * j) * NACC);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s1 += (c < NACC && b0 + g + 8 + LM_GROUPS * j < n_blocks) ? v[j] : 0.0;
+      }
+    }
+    red[g][c] = s0;
+    if (HT == 256) red[g + 8][c] = s1;
   }
   __syncthreads();
   if (CHECK_STATUS && !FIRST && reinterpret_cast<const LmState*>(sh_state)->status != CLC_RUNNING) return false;
-  // the 8 row groups are combined in order by 28 lanes in parallel (one column each): done by the controller's
-  // lane alone this was 224 serial FP64 adds behind 134 LDS reads, ~0.4 us of the launch
+  // the 16 row groups are combined in order by 28 lanes in parallel (one column each): done by the controller's
+  // lane alone this was hundreds of serial FP64 adds behind LDS reads, ~0.4 us of the launch
   if (threadIdx.x < 32) {
     double t = 0.0;
 #pragma unroll
-    for (int g = 0; g < RG; ++g) t += red[g][threadIdx.x];
+    for (int gg = 0; gg < LM_GROUPS; ++gg) t += red[gg][threadIdx.x];
     red[0][threadIdx.x] = t;  // row 0 now holds the totals
     if (opt.profile_events && threadIdx.x == 0 && mailbox != nullptr) mailbox->prof[6] = clock64();
   }
@@ -960,13 +980,13 @@ __global__ __launch_bounds__(BLOCK) void lm_kernel(const double* __restrict__ pa
                                                    const clc_options opt,
                                                    clc_iteration* __restrict__ trace,
                                                    int trace_cap, HostMailbox* mailbox, const Pose7 pose0) {
-  __shared__ double red[BLOCK / 32][32];
+  __shared__ double red[LM_GROUPS][32];
   __shared__ double sh_state[LM_STATE_WORDS];
   const long long c0 = clock64();
   if (!FIRST && state->status != CLC_RUNNING) return;
   LmLoads L;
-  lm_issue_loads<false, FIRST>(partials, state, L);
-  lm_tail<false, FIRST>(partials, n_blocks, state, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, &pose0, L);
+  lm_issue_loads<false, FIRST, BLOCK>(partials, state, L);
+  lm_tail<false, FIRST, BLOCK>(partials, n_blocks, state, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, &pose0, L);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -989,7 +1009,7 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
                                                      unsigned int* __restrict__ ticket_counter,
                                                      clc_iteration* __restrict__ trace, int trace_cap,
                                                      HostMailbox* mailbox) {
-  __shared__ double red[BLOCK / 32][32];
+  __shared__ double red[LM_GROUPS][32];
   __shared__ double sh_state[LM_STATE_WORDS];
   __shared__ double wsum[BT / 64][NACC];
   __shared__ int sh_last;
@@ -1035,8 +1055,8 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
   const long long c0 = clock64();
   if (threadIdx.x == 0) __hip_atomic_store(ticket_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   LmLoads L;
-  lm_issue_loads<true, false>(partials, state, L);
-  lm_tail<true, false>(partials, (int)gridDim.x, state, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, nullptr, L);
+  lm_issue_loads<true, false, BT>(partials, state, L);
+  lm_tail<true, false, BT>(partials, (int)gridDim.x, state, state, opt, trace, trace_cap, mailbox, red, sh_state, c0, nullptr, L);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1065,20 +1085,20 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ct
                                                    double* __restrict__ rows_out,
                                                    clc_iteration* __restrict__ trace, const int trace_cap,
                                                    HostMailbox* mailbox, const Pose7 pose0) {
-  __shared__ double red[BLOCK / 32][32];
+  __shared__ double red[LM_GROUPS][32];
   __shared__ double sh_state[LM_STATE_WORDS];
   const long long c0 = clock64();
   const bool leader = blockIdx.x == 0;
   // the controller's loads go out first: its chain (rows -> combine -> LM step) is the long pole of the launch, the
   // tile prologue loads issued next only have to be in flight before it ends
   LmLoads L;
-  if (MODE != 0) lm_issue_loads<false, MODE == 1>(rows_in, state_in, L);
+  if (MODE != 0) lm_issue_loads<false, MODE == 1, 512>(rows_in, state_in, L);
   auto get_pose = [&](PoseU& P) -> bool {
     if (MODE == 0) {
       load_pose(pose0.v, P);
       return true;
     }
-    const bool consumed = lm_tail<false, MODE == 1, true>(rows_in, (int)gridDim.x, state_in,
+    const bool consumed = lm_tail<false, MODE == 1, 512, true>(rows_in, (int)gridDim.x, state_in,
                                                            leader ? state_out : nullptr, opt, leader ? trace : nullptr,
                                                            leader ? trace_cap : 0, leader ? mailbox : nullptr, red,
                                                            sh_state, c0, &pose0, L);
