@@ -1,7 +1,7 @@
 // clc_abi.hip — implementation of the C-ABI declared in include/clc.h: HIP host code that
 // owns device memory, the stream and the launch sequence of the kernels in
 // clc_kernels.hpp.  Built for gfx950 only:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=on clc_abi.hip -o libclc_hip.so
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=on -mllvm -amdgpu-kernarg-preload-count=8 clc_abi.hip -o libclc_hip.so
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -579,9 +579,9 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
       const double* r_in = rows[(k + 1) & 1];
       double* r_out = rows[k & 1];
 #define CLC_LAUNCH_STEP(LOSS, DEEP, MODE)                                                                     \
-  hipLaunchKernelGGL((clc::step_kernel<LOSS, DEEP, MODE>), dim3(grid), dim3(512), 0, h->stream, h->d_ctiles,    \
-                     h->d_groups, (long long)h->n_obs, s_in, s_out, opt, r_in, r_out, d_trace, d_trace_cap,      \
-                     h->d_mailbox, p0)
+  hipLaunchKernelGGL((clc::step_kernel<LOSS, DEEP, MODE>), dim3(grid), dim3(512), 0, h->stream, r_in, s_in,      \
+                     h->d_ctiles, h->d_groups, (long long)h->n_obs, r_out, s_out, d_trace, h->d_mailbox,         \
+                     d_trace_cap, opt, p0)
 #define CLC_LAUNCH_STEP_M(LOSS, DEEP)                                                                         \
   do { if (k == 0) CLC_LAUNCH_STEP(LOSS, DEEP, 0); else if (k == 1) CLC_LAUNCH_STEP(LOSS, DEEP, 1);             \
        else CLC_LAUNCH_STEP(LOSS, DEEP, 2); } while (0)

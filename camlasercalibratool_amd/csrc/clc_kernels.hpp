@@ -1077,14 +1077,17 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
 // the launch queued behind it sees the termination too, and exits without touching the host mailbox.
 // ---------------------------------------------------------------------------------------
 template <bool WITH_LOSS, bool DEEP, int MODE>
-__global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ctiles,
-                                                   const double* __restrict__ groups, const long long n,
+__global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ rows_in,
                                                    const LmState* __restrict__ state_in,
-                                                   LmState* __restrict__ state_out, const clc_options opt,
-                                                   const double* __restrict__ rows_in,
+                                                   const double* __restrict__ ctiles,
+                                                   const double* __restrict__ groups, const long long n,
                                                    double* __restrict__ rows_out,
-                                                   clc_iteration* __restrict__ trace, const int trace_cap,
-                                                   HostMailbox* mailbox, const Pose7 pose0) {
+                                                   LmState* __restrict__ state_out,
+                                                   clc_iteration* __restrict__ trace, HostMailbox* mailbox,
+                                                   const int trace_cap, const clc_options opt, const Pose7 pose0) {
+  // Argument order matters: the build preloads the first kernel arguments into SGPRs (-amdgpu-kernarg-preload-count),
+  // so what the first loads need — the row buffer, the state, the tiles — comes first and the wave does not start
+  // with a ~1 us kernel-argument fetch in front of them.
   __shared__ double red[LM_GROUPS][32];
   __shared__ double sh_state[LM_STATE_WORDS];
   const long long c0 = clock64();

@@ -18,7 +18,7 @@ def usage(tmp_path_factory):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     out = tmp_path_factory.mktemp("res") / "x.so"
-    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on", SRC, "-o", str(out),
+    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on", "-mllvm", "-amdgpu-kernarg-preload-count=8", SRC, "-o", str(out),
                         "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     res, cur = {}, None
