@@ -325,6 +325,28 @@ def main():
             "ne_openmp_evals_per_s": _time_ne(nthr, 20), "ne_openmp_threads": nthr,
             "note": "residual+Jacobian+6x6 accumulation passes only (no QR, no LM control)",
         }
+        # the reference's OWN sources (oracle/_ref/libref.so, built against stand-in Eigen/Ceres headers) on the
+        # reference's own problem size (C1): reported for transparency, not used as the baseline — the stand-in
+        # matrices live on the heap, which makes this several times slower than real Eigen would be
+        try:
+            import oracle.ref as oref
+            if os.path.exists(oref.LIB_PATH):
+                S1 = sd.GenerateSimData(1, noise_sigma=0.01)
+                rec1 = clc.flatten_observations(S1, False)
+                passes1 = oracle.solve(rec1, x0, linear_solver="qr").summary.num_residual_evaluations
+                t1 = time.perf_counter()
+                n1 = 0
+                while time.perf_counter() - t1 < 1.0:
+                    oref.calibration(S1, np.eye(4), False, False)
+                    n1 += 1
+                out["cpu_baseline"]["variants"]["reference_sources_standin_eigen_c1_evals_per_s"] = \
+                    passes1 * rec1.shape[0] * n1 / (time.perf_counter() - t1)
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    oracle.solve(rec1, x0, linear_solver="qr")
+                out["cpu_baseline"]["variants"]["port_c1_evals_per_s"] = passes1 * rec1.shape[0] * 20 / (time.perf_counter() - t1)
+        except Exception as e:  # the library is test infrastructure and may be absent
+            out["cpu_baseline"]["variants"]["reference_sources_note"] = f"oracle/_ref not available: {e}"
         dT = float(np.abs(sd.T_from_pose7(res.pose) - sd.T_from_pose7(ref.pose)).max())
         out["parity"] = {
             "T_cl_max_abs_err_vs_oracle": dT,
