@@ -17,6 +17,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 echo "pmc fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write_bench.log 2>&1
 echo "pmc write rc=$?"
+# 2b) instruction mix of the dominant kernel (own run, --kernel-trace only): FP64 issue is what bounds the streaming loop
+# while the array is cache-resident
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/pmc_valu -o pmc -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-batched --large-obs 0 > $OUT/pmc_valu_bench.log 2>&1
+echo "pmc valu rc=$?"
 # 3) plain run of the same command for the bench line that goes with these profiles
 $CMD > $OUT/bench_plain.log 2>&1
 echo "plain rc=$?"

@@ -70,6 +70,25 @@ for (k, cname), v in fetch.items():
         lines.append(f"| `{k}` | {cls}, {'compact 28 B/obs' if compact else 'tiles 64 B/obs'} | {len(g)} | {statistics.median(g):.1f} | {rd:.4g} | {statistics.median(wv):.1f} | {alg:.4g} | {(rd + wr) / alg:.3f} (vs layout bytes {layout:.3g}: {(rd + wr) / layout:.3f}) |")
         traffic[(cls, compact, "step" if step else ("batched" if batched else "eval"))] = {
             "read_bytes": rd, "write_bytes": wr, "algorithmic_bytes": alg, "layout_bytes": layout}
+# instruction mix (optional pass)
+vp = os.path.join(src, "pmc_valu", "pmc_counter_collection.csv")
+if os.path.exists(vp):
+    mix = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(vp)):
+        mix[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    lines += ["", "## Instruction mix per launch (`--pmc SQ_INSTS_VALU ..._FMA_F64 ..._ADD_F64 ..._MUL_F64 SQ_INSTS_SALU SQ_INSTS_LDS`, own pass)", "",
+              "Wave-level instruction counts, median over the launches that streamed 10^6 observations (15 625 wave-tiles of 64 lanes x 2",
+              "observations); `FP64 / obs` = (FMA + ADD + MUL F64) x 64 lanes / (2 x 10^6 observation slots) ... i.e. per observation and lane.", "",
+              "| kernel | launches | VALU | FMA F64 | ADD F64 | MUL F64 | SALU | LDS | FP64 instructions per observation |", "|---|---|---|---|---|---|---|---|---|"]
+    for kname, c in mix.items():
+        if "step_kernel<true, false, 2>" not in kname and "eval_kernel<true, true, false, false, true, 512>" not in kname:
+            continue
+        valu = c.get("SQ_INSTS_VALU", [])
+        big = [i for i, v in enumerate(valu) if v > 0.5 * max(valu)]  # launches that streamed (not the no-op / controller-only ones)
+        med = lambda name: statistics.median([c[name][i] for i in big]) if c.get(name) else float("nan")
+        f64 = med("SQ_INSTS_VALU_FMA_F64") + med("SQ_INSTS_VALU_ADD_F64") + med("SQ_INSTS_VALU_MUL_F64")
+        lines.append(f"| `{kname}` | {len(big)} | {med('SQ_INSTS_VALU'):.4g} | {med('SQ_INSTS_VALU_FMA_F64'):.4g} | {med('SQ_INSTS_VALU_ADD_F64'):.4g} | "
+                     f"{med('SQ_INSTS_VALU_MUL_F64'):.4g} | {med('SQ_INSTS_SALU'):.4g} | {med('SQ_INSTS_LDS'):.4g} | {f64 * 64 / 1e6 / 1.0:.1f} |")
 bl = [l for l in open(os.path.join(src, "bench_plain.log")) if l.startswith("{")]
 if bl:
     d = json.loads(bl[-1])
