@@ -324,31 +324,34 @@ constexpr int FLAG_STEP = 128;          // clc_solve: one step_kernel launch per
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-// Static tile -> wave map.  A wave owns `vw` of V weight units starting at unit `vbase`, and
-// with T tiles in the array it streams the CONTIGUOUS run [T*vbase/V, T*(vbase+vw)/V): shares
-// are proportional to the weights and differ from the ideal by less than one tile.  In a
-// 512-thread workgroup the four first-launched waves (one per SIMD) win the issue arbitration
-// against the four younger ones sharing their SIMDs (measured: 8.0k vs 11.5k cycles for equal
-// work, 99 % repeatable), so the older slots get W_OLD = 3 and the younger W_YOUNG = 2 units:
-// both finish together instead of leaving the tail of the launch at half occupancy.  The map is a
-// pure function of (array length, grid, block size), so the summation order — and the result,
-// bit for bit — stays fixed.
+// Static tile -> wave map, two levels, no division by a run-time weight total.  The T tiles of the array are dealt to the
+// workgroups as evenly as integers allow (workgroup b gets q or q + 1 consecutive tiles, q = T / n_blocks, the first
+// T % n_blocks workgroups the extra one); inside a workgroup the waves take consecutive sub-runs proportional to their
+// weights.  In a 512-thread workgroup the four first-launched waves (one per SIMD) win the issue arbitration against
+// the four younger ones sharing their SIMDs (measured: 8.0k vs 11.5k cycles for equal work, 99 % repeatable), so the
+// older slots get W_OLD = 3 and the younger W_YOUNG = 2 units: both finish together instead of leaving the tail of the
+// launch at half occupancy.  The map is a pure function of (array length, grid, block size), so the summation order —
+// and the result, bit for bit — stays fixed.  (An earlier single-level form, floor(T * unit / total_units), cost two
+// 64-bit or three 32-bit per-lane divisions per wave in front of its first load, ~250 instructions in each of 2 048
+// waves; here the one division is wave-uniform and runs on the scalar unit.  No measurable change in solve time — in
+// the step kernel the controller chain hides the prologue — but a tenth fewer VALU instructions per launch.)
 struct WaveMap {
-  long long vbase, V;
-  int vw;
-  // floor(T * u / V) for 0 <= u <= V.  A 64-bit division expands to ~150 instructions and two of them
-  // sat in front of the wave's first load (~0.5 us of an 8-us launch); with T = q V + r the same
-  // value is q u + floor(u r / V), three 32-bit divisions, whenever T < 2^32 and V < 2^16 (always,
-  // short of 5x10^11 observations or 3 000 workgroups).
-  __device__ __forceinline__ long long scaled(long long T, long long u) const {
-    if (T < (1LL << 32) && V < 65536) {
-      const unsigned int v = (unsigned int)V, q = (unsigned int)T / v, r = (unsigned int)T - q * v;
-      return (long long)q * u + (long long)(((unsigned int)u * r) / v);
+  unsigned int block, n_blocks;
+  int cw0, cw1, cwt;  // this wave owns weight units [cw0, cw1) of the workgroup's cwt
+  __device__ __forceinline__ long long bound(long long T, int cw) const {
+    if (T < (1LL << 26)) {  // always, short of 8.6e9 observations: 32-bit arithmetic, one division by the grid size
+      const unsigned int t = (unsigned int)T, q = t / n_blocks, r = t - q * n_blocks;
+      const unsigned int wg0 = block * q + (block < r ? block : r);
+      const unsigned int wgn = q + (block < r ? 1u : 0u);
+      return (long long)(wg0 + (wgn * (unsigned int)cw) / (unsigned int)cwt);
     }
-    return T * u / V;
+    const long long q = T / n_blocks, r = T - q * n_blocks;
+    const long long wg0 = (long long)block * q + ((long long)block < r ? (long long)block : r);
+    const long long wgn = q + ((long long)block < r ? 1 : 0);
+    return wg0 + wgn * cw / cwt;
   }
-  __device__ __forceinline__ long long begin(long long T) const { return scaled(T, vbase); }
-  __device__ __forceinline__ long long end(long long T) const { return scaled(T, vbase + vw); }
+  __device__ __forceinline__ long long begin(long long T) const { return bound(T, cw0); }
+  __device__ __forceinline__ long long end(long long T) const { return bound(T, cw1); }
 };
 
 constexpr int W_OLD = 3, W_YOUNG = 2;
@@ -356,15 +359,16 @@ constexpr int W_OLD = 3, W_YOUNG = 2;
 template <int BT>
 __device__ __forceinline__ WaveMap make_wave_map(int block, int n_blocks, int wave) {
   WaveMap m;
+  m.block = (unsigned int)block;
+  m.n_blocks = (unsigned int)n_blocks;
   if (BT == 512) {
-    constexpr int per_block = 4 * W_OLD + 4 * W_YOUNG;
-    m.V = (long long)n_blocks * per_block;
-    m.vw = wave < 4 ? W_OLD : W_YOUNG;
-    m.vbase = (long long)block * per_block + (wave < 4 ? wave * W_OLD : 4 * W_OLD + (wave - 4) * W_YOUNG);
+    m.cwt = 4 * W_OLD + 4 * W_YOUNG;
+    m.cw0 = wave < 4 ? wave * W_OLD : 4 * W_OLD + (wave - 4) * W_YOUNG;
+    m.cw1 = m.cw0 + (wave < 4 ? W_OLD : W_YOUNG);
   } else {
-    m.V = (long long)n_blocks * (BT / 64);
-    m.vw = 1;
-    m.vbase = (long long)block * (BT / 64) + wave;
+    m.cwt = BT / 64;
+    m.cw0 = wave;
+    m.cw1 = wave + 1;
   }
   return m;
 }
