@@ -208,16 +208,13 @@ def _plane_in_laser(Rlc, tlc, Rca, tca):
     return n, d
 
 
-def GenerateSimData(seed: int, n_poses: int = 50, n_rays: int = 180, noise_sigma: float = 0.0,
-                    Rlc: np.ndarray = GT_RLC, tlc: np.ndarray = GT_TLC) -> ObservationSet:
-    """C1 — literal restatement of GenerateSimData, main/calibr_simulation.cpp:10-108.
-
-    n_rays rays at theta = -pi/2 + j*pi/180 (:81), depth = -d/(ray.n) (:83), keep
-    depth >= 0 and |x|<5 and |y|<5 (:85-94); points_on_line = points (:101-102).
-    A pose may legitimately contribute zero points.  noise_sigma adds N(0,sigma) range
-    noise (the reference is noise-free)."""
-    rng = np.random.default_rng(seed)
-    Rca, tca = _draw_tag_poses(rng, n_poses)
+def points_from_tag_poses(Rca: np.ndarray, tca: np.ndarray, n_rays: int = 180, noise_sigma: float = 0.0,
+                          rng: Optional[np.random.Generator] = None, Rlc: np.ndarray = GT_RLC,
+                          tlc: np.ndarray = GT_TLC) -> ObservationSet:
+    """The deterministic part of GenerateSimData (main/calibr_simulation.cpp:60-104): tag plane in the laser frame,
+    n_rays rays at theta = -pi/2 + j*pi/180 (:81), depth = -d/(ray.n) (:83), keep depth >= 0 and |x|<5 and |y|<5
+    (:85-94); points_on_line = points (:101-102).  A pose may legitimately contribute zero points."""
+    n_poses = Rca.shape[0]
     n, d = _plane_in_laser(Rlc, tlc, Rca, tca)
     theta = -np.pi / 2 + np.arange(n_rays) * (np.pi / 180.0)
     ray = np.stack([np.cos(theta), np.sin(theta), np.zeros_like(theta)], axis=1)  # [K,3]
@@ -232,7 +229,18 @@ def GenerateSimData(seed: int, n_poses: int = 50, n_rays: int = 180, noise_sigma
     off[1:] = np.cumsum(counts)
     pts = np.ascontiguousarray(p[valid])  # row-major boolean mask keeps pose order
     tag_q = rot_to_quat_wxyz(Rca)
-    return ObservationSet(tag_q, tca.copy(), off, pts, off.copy(), pts.copy())
+    return ObservationSet(tag_q, np.array(tca, dtype=np.float64).copy(), off, pts, off.copy(), pts.copy())
+
+
+def GenerateSimData(seed: int, n_poses: int = 50, n_rays: int = 180, noise_sigma: float = 0.0,
+                    Rlc: np.ndarray = GT_RLC, tlc: np.ndarray = GT_TLC) -> ObservationSet:
+    """C1 — restatement of GenerateSimData, main/calibr_simulation.cpp:10-108: tag poses drawn from the reference's
+    distributions (with numpy's generator — the reference seeds its engine from std::random_device, so there is no
+    stream to reproduce), then `points_from_tag_poses`, which tests/test_ref_pin.py checks against the reference's own
+    function on the reference's own poses.  noise_sigma adds N(0,sigma) range noise (the reference is noise-free)."""
+    rng = np.random.default_rng(seed)
+    Rca, tca = _draw_tag_poses(rng, n_poses)
+    return points_from_tag_poses(Rca, tca, n_rays, noise_sigma, rng, Rlc, tlc)
 
 
 def _valid_interval(n, d):

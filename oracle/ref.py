@@ -1,5 +1,5 @@
 """ctypes binding of oracle/_ref/libref.so — the REFERENCE'S OWN translation units
-(src/LaseCamCalCeres.cpp, src/pose_local_parameterization.cpp, src/utilities.cpp) compiled from where
+(src/LaseCamCalCeres.cpp, src/pose_local_parameterization.cpp, src/utilities.cpp, main/calibr_simulation.cpp) compiled from where
 they lie under /root/reference against the stand-in Eigen / Ceres / sensor_msgs headers of
 oracle/ref_shim/ (neither library is installed here; see oracle/ref_shim/mini_eigen.hpp).
 
@@ -170,3 +170,32 @@ def parse_analysis(text: str):
     sv = [float(lines[i + 1 + k]) for k in range(6)]
     chi_half = float(next(l for l in lines if l.startswith("recover chi2:")).split(":")[1])
     return np.array(sv), chi_half
+
+
+def generate_sim_data(seed: int):
+    """GenerateSimData (main/calibr_simulation.cpp:8-108) with std::random_device pinned to `seed` ->
+    (tag_q_wxyz [50,4], tag_t [50,3], counts [50], points [n,3])."""
+    L = lib()
+    L.ref_generate_sim_data.restype = C.c_longlong
+    q = np.empty((50, 4)); t = np.empty((50, 3)); cnt = np.zeros(50, dtype=np.int64)
+    cap = 50 * 180
+    pts = np.empty((cap, 3))
+    n = L.ref_generate_sim_data(C.c_uint(seed), _p(q), _p(t), _pl(cnt), _p(pts), C.c_longlong(cap))
+    return q, t, cnt, pts[:n].copy()
+
+
+def simulation_program(seed: int) -> str:
+    """The reference's whole simulation node (its main(), main/calibr_simulation.cpp:110-165) on the pinned seed;
+    returns everything it printed."""
+    rc = lib().ref_simulation_program(C.c_uint(seed))
+    if rc != 0:
+        raise RuntimeError(f"reference main returned {rc}")
+    return last_stdout()
+
+
+def parse_simulation_tlc(text: str) -> np.ndarray:
+    """The 4x4 the program prints after '----- Transform from Camera to Laser Tlc is: -----' (6 significant digits)."""
+    lines = text.splitlines()
+    i = next(k for k, l in enumerate(lines) if "Transform from Camera to Laser Tlc is" in l)
+    rows = [l for l in lines[i + 1:] if l.strip()][:4]
+    return np.array([[float(v) for v in r.split()] for r in rows])

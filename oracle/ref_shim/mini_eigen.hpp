@@ -35,6 +35,7 @@ template <typename Derived> class MatrixBase;
 template <typename Xpr, int R, int C> class Block;
 template <typename Plain> class Map;
 template <typename T> class Quaternion;
+template <typename D, typename T> class QuaternionBase;
 template <typename M> class LDLT;
 
 template <typename D> struct traits;
@@ -450,6 +451,15 @@ class Matrix : public MatrixBase<Matrix<T, R, C, Opt>> {
   static Matrix Identity() { Matrix m; m.setIdentity(); return m; }
   static Matrix Identity(Index r, Index c) { Matrix m(r, c, internal::Sized()); m.setIdentity(); return m; }
   static Matrix Ones() { Matrix m; for (auto& v : m.d_) v = T(1); return m; }
+  static Matrix Unit(Index k) { Matrix m; m.d_[(size_t)k] = T(1); return m; }
+  static Matrix UnitX() { return Unit(0); }
+  static Matrix UnitY() { return Unit(1); }
+  static Matrix UnitZ() { return Unit(2); }
+  // rotation (quaternion / angle-axis product) -> 3x3 matrix, as Eigen's RotationBase assignment
+  template <typename QD>
+  Matrix(const QuaternionBase<QD, T>& q) { init_from(q.toRotationMatrix()); }
+  template <typename QD>
+  Matrix& operator=(const QuaternionBase<QD, T>& q) { return *this = q.toRotationMatrix(); }
 
  private:
   template <typename OD>
@@ -879,6 +889,26 @@ class Quaternion : public QuaternionBase<Quaternion<T>, T> {
   T q_[4];
 };
 typedef Quaternion<double> Quaterniond;
+
+// Rotation by `angle` about the unit vector `axis`; products compose as quaternions (like Eigen's RotationBase).
+template <typename T>
+class AngleAxis {
+ public:
+  template <typename OD>
+  AngleAxis(const T& angle, const MatrixBase<OD>& axis) : angle_(angle), axis_(axis) {}
+  Quaternion<T> toQuaternion() const {
+    const T s = std::sin(angle_ * T(0.5)), c = std::cos(angle_ * T(0.5));
+    return Quaternion<T>(c, s * axis_(0), s * axis_(1), s * axis_(2));
+  }
+  Matrix<T, 3, 3> toRotationMatrix() const { return toQuaternion().toRotationMatrix(); }
+  Quaternion<T> operator*(const AngleAxis& o) const { return toQuaternion() * o.toQuaternion(); }
+  friend Quaternion<T> operator*(const Quaternion<T>& q, const AngleAxis& a) { return q * a.toQuaternion(); }
+
+ private:
+  T angle_;
+  Matrix<T, 3, 1> axis_;
+};
+typedef AngleAxis<double> AngleAxisd;
 
 template <typename T>
 class Map<Quaternion<T>> : public QuaternionBase<Map<Quaternion<T>>, T> {

@@ -19,6 +19,22 @@
 #include "pose_local_parameterization.cpp"   // reference: src/pose_local_parameterization.cpp
 #include "utilities.cpp"                     // reference: src/utilities.cpp
 
+// The reference's simulation node, main/calibr_simulation.cpp: GenerateSimData (:8-108) and main (:110-165).  Its
+// generator seeds std::default_random_engine from std::random_device (:27-28), i.e. differently on every run; here the
+// device is replaced by a fixed value so that a run can be repeated, and main is renamed so that it can be called.
+#include <random>
+static unsigned int g_ref_seed = 1;
+namespace std {
+struct clc_fixed_random_device {
+  unsigned int operator()() const { return g_ref_seed; }
+};
+}  // namespace std
+#define random_device clc_fixed_random_device
+#define main ref_simulation_main
+#include "calibr_simulation.cpp"             // reference: main/calibr_simulation.cpp
+#undef main
+#undef random_device
+
 namespace {
 
 struct CoutSilencer {  // the reference reports on std::cout (:175-177, :202, :309, :365-381): capture it
@@ -121,6 +137,41 @@ int ref_calibration(int n_poses, const double* tag_q_wxyz, const double* tag_t, 
 }
 
 // LineFittingCeres, src/LaseCamCalCeres.cpp:401-433.  pts = n x 3, line in/out.
+// GenerateSimData, main/calibr_simulation.cpp:8-108, with the random device pinned to `seed`.  Outputs for 50 poses:
+// tag_q_wxyz[50*4], tag_t[50*3], counts[50] and the points (up to cap, 3 doubles each).  Returns the number of points.
+long long ref_generate_sim_data(unsigned int seed, double* tag_q_wxyz, double* tag_t, long long* counts, double* pts,
+                                long long cap) {
+  CoutSilencer quiet;
+  g_ref_seed = seed;
+  std::vector<Oberserve> obs;
+  GenerateSimData(obs);
+  long long n = 0;
+  for (size_t i = 0; i < obs.size(); ++i) {
+    tag_q_wxyz[4 * i] = obs[i].tagPose_Qca.w(); tag_q_wxyz[4 * i + 1] = obs[i].tagPose_Qca.x();
+    tag_q_wxyz[4 * i + 2] = obs[i].tagPose_Qca.y(); tag_q_wxyz[4 * i + 3] = obs[i].tagPose_Qca.z();
+    for (int c = 0; c < 3; ++c) tag_t[3 * i + c] = obs[i].tagPose_tca[c];
+    counts[i] = (long long)obs[i].points.size();
+    for (size_t j = 0; j < obs[i].points.size(); ++j, ++n)
+      if (n < cap) for (int c = 0; c < 3; ++c) pts[3 * n + c] = obs[i].points[j][c];
+  }
+  return n;
+}
+
+// The reference's whole simulation program (its main(), :110-165) with the random device pinned to `seed`; what it
+// prints is available through ref_last_stdout().
+int ref_simulation_program(unsigned int seed) {
+  CoutSilencer quiet(&g_last_stdout_storage);
+  g_ref_seed = seed;
+  int argc = 1;
+  char arg0[] = "simulation_lasercamcal_node";
+  char* argv[] = {arg0, nullptr};
+  try {
+    return ref_simulation_main(argc, argv);  // early exits of the program ("Valid Calibra Data Less")
+  } catch (const ros::SpinCalled&) {
+    return 0;  // reached ros::spin(): the program ran to its end
+  }
+}
+
 // What the last ref_calibration / ref_closed_solution call printed on std::cout (the reference reports the
 // analysis pass — H singular values, null space, chi2 — only there, :365-381).  Returns the length.
 long long ref_last_stdout(char* buf, long long cap) {

@@ -13,6 +13,8 @@ this container (`make -C oracle ref`, oracle/ref.py).  They pin what the referen
   * CamLaserCalibration / LineFittingCeres  whole function (+ the printed analysis pass, 6 digits): the reference's assembly loop, factor,
                                             loss objects and parameterisation drive the stand-in
                                             ceres::Solve, i.e. the oracle's LM restatement.
+  * GenerateSimData + the simulation node's main()   (main/calibr_simulation.cpp, std::random_device pinned): the
+                                            ray/plane geometry of the test-input generator, and the program end to end.
 
 What they do NOT pin is Ceres' own minimiser (absent here): iteration counts and termination in this
 file are those of the restated LM.  /root/reference does not exist on the GPU box, so the vectors are
@@ -111,6 +113,17 @@ a0, da, rmin = -1.57, 0.00873, 0.1
 P = ref.scan_to_points(r, a0, da, rmin)
 G["scan_to_points"].append(dict(ranges=[float(v) if np.isfinite(v) else str(v) for v in r], angle_min=a0, angle_increment=da, range_min=rmin,
                                 points=[[float(v) if np.isfinite(v) else str(v) for v in row] for row in P]))
+
+# the reference's simulation node: GenerateSimData (main/calibr_simulation.cpp:8-108) on a pinned random device, and its
+# whole main() (:110-165) — what it prints is all it outputs (default ostream precision: 6 significant digits)
+G["simulation"] = []
+for seed in (1, 12345):
+    q, t, cnt, pts = ref.generate_sim_data(seed)
+    off = np.r_[0, np.cumsum(cnt)]
+    sums = np.array([pts[off[i]:off[i + 1]].sum(axis=0) for i in range(50)])
+    Tlc = ref.parse_simulation_tlc(ref.simulation_program(seed))
+    G["simulation"].append(dict(seed=seed, tag_q_wxyz=q.tolist(), tag_t=t.tolist(), counts=cnt.tolist(), point_sums=sums.tolist(),
+                                first_point=pts[0].tolist(), last_point=pts[-1].tolist(), program_Tlc_printed=Tlc.tolist()))
 
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.json")
 json.dump(G, open(out, "w"), indent=0)

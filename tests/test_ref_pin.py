@@ -107,6 +107,24 @@ def test_oracle_line_fit_matches_reference_function(oracle_mod):
         assert r.summary.final_cost == pytest.approx(c["final_cost"], rel=1e-11)
 
 
+@pytest.mark.parametrize("case", G["simulation"], ids=lambda c: f"seed{c['seed']}")
+def test_sim_generator_and_whole_reference_program(oracle_mod, case):
+    """The reference's GenerateSimData on its own (pinned) tag poses vs simdata.points_from_tag_poses, and the reference's
+    whole simulation node — its main(): generate, CamLaserCalibration from the identity, print Tlc — vs oracle.solve on
+    the same observations (the program prints with 6 significant digits)."""
+    q, t = np.array(case["tag_q_wxyz"]), np.array(case["tag_t"])
+    S = sd.points_from_tag_poses(sd.quat_wxyz_to_rot(q), t)
+    assert np.array_equal(np.diff(S.pts_off), np.array(case["counts"]))
+    sums = np.array([S.pts[S.pts_off[i]:S.pts_off[i + 1]].sum(axis=0) for i in range(50)])
+    assert np.abs(sums - np.array(case["point_sums"])).max() < 1e-10
+    assert np.abs(S.pts[0] - np.array(case["first_point"])).max() < 1e-12 and np.abs(S.pts[-1] - np.array(case["last_point"])).max() < 1e-12
+    r = oracle_mod.solve(oracle_mod.flatten(S, False, False), sd.pose7_from_T(np.eye(4)))
+    Tlc = np.linalg.inv(sd.T_from_pose7(r.pose))
+    P = np.array(case["program_Tlc_printed"])
+    assert np.abs(Tlc - P).max() < 1e-5 * max(1.0, np.abs(P).max())
+    assert np.abs(P[:3, :3] - sd.GT_RLC).max() < 1e-5 and np.abs(P[:3, 3] - sd.GT_TLC).max() < 1e-5  # it finds the ground truth
+
+
 # ------------------------------------------------------------------------------------------
 # oracle vs the reference library, live (fresh inputs)
 # ------------------------------------------------------------------------------------------
@@ -167,6 +185,17 @@ def test_live_reference_whole_functions(oracle_mod, ref_mod):
     assert np.abs(Tb - sd.T_from_pose7(rb.pose)).max() < 1e-12, f"seed {seed}"
 
 
+def test_live_reference_simulation_program(oracle_mod, ref_mod):
+    seed = int.from_bytes(os.urandom(3), "little") + 1
+    q, t, cnt, pts = ref_mod.generate_sim_data(seed)
+    S = sd.points_from_tag_poses(sd.quat_wxyz_to_rot(q), t)
+    assert np.array_equal(np.diff(S.pts_off), cnt), f"seed {seed}"
+    assert np.abs(S.pts - pts).max() < 1e-12, f"seed {seed}"
+    P = ref_mod.parse_simulation_tlc(ref_mod.simulation_program(seed))
+    r = oracle_mod.solve(oracle_mod.flatten(S, False, False), sd.pose7_from_T(np.eye(4)))
+    assert np.abs(np.linalg.inv(sd.T_from_pose7(r.pose)) - P).max() < 1e-5, f"seed {seed}"
+
+
 # ------------------------------------------------------------------------------------------
 # HIP path vs the committed reference vectors (through the C-ABI; no oracle involved)
 # ------------------------------------------------------------------------------------------
@@ -222,3 +251,15 @@ def test_gpu_closed_form_line_fit_scan_match_reference_functions(sv):
         r = np.array([_f(v) for v in c["ranges"]], dtype=np.float32)
         P = sv.scan_to_points(r, np.array([0, r.shape[0]]), c["angle_min"], c["angle_increment"], c["range_min"])
         assert np.abs(P - np.array([[_f(v) for v in row] for row in c["points"]])).max() < 2e-14  # device cos/sin
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G["simulation"], ids=lambda c: f"seed{c['seed']}")
+def test_gpu_dropin_matches_whole_reference_program(sv, case):
+    """The reference's simulation node end to end (what its main() printed) vs the drop-in flow of
+    main/calibr_simulation.cpp:126-133 on the HIP backend, same observations."""
+    S = sd.points_from_tag_poses(sd.quat_wxyz_to_rot(np.array(case["tag_q_wxyz"])), np.array(case["tag_t"]))
+    Tcl = np.linalg.inv(np.eye(4))
+    clc.CamLaserCalibration(S, Tcl, False, solver=sv, verbose=False)
+    P = np.array(case["program_Tlc_printed"])
+    assert np.abs(np.linalg.inv(Tcl) - P).max() < 1e-5 * max(1.0, np.abs(P).max())
