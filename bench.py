@@ -9,9 +9,16 @@ point-to-plane observations (2000 board poses x 500 scan points, range noise sig
 seeded restatement of simulation_lasercamcal_node's generator), initial guess Tcl = I,
 Cauchy loss, Ceres-default LM options — exactly what CamLaserCalibration() runs.
 A "step" is one complete solve (clc_solve) with the observation array already resident in HBM.
-With N GPUs every rank solves its own independent 10^6-observation problem (problems shard
-across GPUs, no data-path collective) and the result records are gathered once with RCCL
-(torch.distributed all_gather) inside the timed region: weak scaling.
+This is the N=1 line: BASELINE.json quotes the metric on C2, and C2 is a single problem — it does not shard
+("replicas only").
+
+N>1 (BASELINE.json configs[3], "C4"): 65 536 independent T_cl problems x 10^4 observations sharded over
+8 GPUs, i.e. 8 192 problems per GPU — weak scaling, so --gpus N runs 8 192 x N problems.  Every rank GENERATES
+ONLY ITS OWN contiguous shard (problem k is a pure function of (seed, k)), keeps it resident in HBM
+(clc_upload_batched), and a step is: clc_solve_batched of the shard + ONE RCCL all-gather over xGMI of the
+12-double result records of all 8 192 x N problems (clc_gather_results, include/clc.h), inside the timed region.
+No collective on the data path.  At N=1 the same shard workload (with a world-size-1 RCCL communicator) is reported
+as the `batched_c4_shard` sub-object, the like-for-like base of the 1 -> 8 curve.
 
 value = residual+Jacobian evaluations per second, whole job:
         sum over ranks of (observations x evaluation passes) / max-over-ranks wall time.
@@ -51,11 +58,108 @@ def parse():
                     help="extra >Infinity-Cache evaluation-kernel measurement (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-batched", action="store_true", help="skip the extra C3 (1024 problems x 1e4 obs) measurement")
+    ap.add_argument("--problems-per-gpu", type=int, default=8192, help="C4 shard: independent problems per GPU (N>1 workload)")
+    ap.add_argument("--shard-poses", type=int, default=20)
+    ap.add_argument("--shard-pts", type=int, default=500)
+    ap.add_argument("--shard-steps", type=int, default=20, help="timed steps of the batched_c4_shard sub-object at N=1")
+    ap.add_argument("--no-c4-shard", action="store_true", help="N=1: skip the batched_c4_shard sub-object")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N>1 (nccl = RCCL over xGMI; gloo only for dry runs)")
+                    help="process group for N>1 (nccl = RCCL; gloo only for dry runs: the result records are then gathered "
+                         "with torch.distributed instead of clc_gather_results)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: map ranks onto the visible GPUs modulo their count (with --backend gloo)")
     return ap.parse_args()
+
+
+C4_SEED = 65536
+
+
+def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_rccl=True):
+    """BASELINE.json configs[3] on this rank: generate problems [lo, hi) of the 8 192 x world batch, keep them resident,
+    then time `steps` x (clc_solve_batched + RCCL all-gather of every rank's result records).
+    Returns the dict rank 0 reports (None on other ranks)."""
+    import camlasercalibratool_amd as clc
+    from camlasercalibratool_amd import dist as cdist, simdata as sd
+
+    n_total = args.problems_per_gpu * world
+    t_gen0 = time.perf_counter()
+    ss = cdist.ShardSolver(n_total, device_index=local_rank, rank=rank, world=world, use_rccl=use_rccl)
+    rec, off, x0, gt = sd.sim_shard_records(C4_SEED, ss.lo, ss.hi, args.shard_poses, args.shard_pts, 0.01)
+    t_gen = time.perf_counter() - t_gen0
+    t_up0 = time.perf_counter()
+    ss.upload(rec, off)
+    t_up = time.perf_counter() - t_up0
+    n_obs_local = int(off[-1])
+    keep = {k: rec[off[k]:off[k + 1]].copy() for k in (0, len(off) - 2)} if rank == 0 else {}
+    del rec
+    dev_name, n_cus = ss.solver.device_info()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        ss.solve(x0, ordered=False, copy=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = ss.solve(x0, ordered=False, copy=False)  # solve this shard + all-gather of all ranks' records
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sms = ss.last_summaries
+    per = args.shard_poses * args.shard_pts
+    evals_step = float(sum(sms[k].num_evaluations for k in range(len(sms)))) * per
+    iters_step = float(sum(sms[k].num_iterations for k in range(len(sms))))
+    if dist is not None:
+        cdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed, evals_step, iters_step], dtype=torch.float64, device=cdev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, evals_step, iters_step = float(tmax[0]), float(t[1]), float(t[2])
+    res = None
+    if rank == 0:
+        full = cdist.order_records(np.array(out), n_total)
+        dt = elapsed / steps
+        its = full[:, 9]
+        res = {
+            "workload": f"C4 shard: {args.problems_per_gpu} independent T_cl problems x {per} observations per GPU "
+                        f"({args.shard_poses} poses x {args.shard_pts} pts, sigma=0.01 m, start 5 cm / 3 deg off the truth), "
+                        f"x{world} GPUs = {n_total} problems; step = clc_solve_batched + RCCL all-gather of all {n_total} result records",
+            "problems": n_total, "problems_per_gpu": args.problems_per_gpu, "observations_per_gpu": n_obs_local,
+            "record_bytes_per_gpu": 64 * n_obs_local,
+            "ms_per_step": 1e3 * dt, "problems_per_s": n_total / dt, "evals_per_s": evals_step / dt,
+            "lm_iters_per_s": iters_step / dt,
+            "lm_iterations_min_max": [int(its.min()), int(its.max())],
+            "terminations": {clc.TERMINATION.get(int(c), str(int(c))): int((full[:, 10] == c).sum()) for c in np.unique(full[:, 10])},
+            "gather": {"collective": "ncclAllGather via clc_gather_results" if use_rccl else "torch.distributed all_gather (dry run)",
+                       "library": ss.comm.library if ss.comm is not None else None,
+                       "bytes_per_rank": 96 * ss.cap, "bytes_total": 96 * ss.cap * world},
+            "setup_s": {"generate_shard": t_gen, "upload_shard": t_up},
+            "device": dev_name, "compute_units": n_cus,
+            "first_and_last_record": [full[0].tolist(), full[-1].tolist()],
+        }
+        # ground truth recovery of this rank's problems (sanity, outside the timed region)
+        mine = full[ss.lo:ss.hi]
+        err = max(float(np.abs(sd.T_from_pose7(mine[k, :7]) - gt[k]).max()) for k in range(0, ss.hi - ss.lo, max(1, (ss.hi - ss.lo) // 256)))
+        res["max_abs_T_err_vs_ground_truth_sampled"] = err
+        # dominant kernel of the step: batched_eval_kernel over the whole shard (all problems active)
+        kms = min(ss.solver.time_batched_eval(x0, reps=10) for _ in range(3))
+        res["roofline"] = {"bound": "hbm", "kernel": "clc::batched_eval_kernel (all problems of the shard active)",
+                           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs_local, "avg_kernel_ms": kms,
+                           "achieved": BYTES_PER_EVAL * n_obs_local / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": BYTES_PER_EVAL * n_obs_local / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "timing": "hipEvent pair around 10 back-to-back launches on the solver's stream (best of 3)"}
+        if not args.no_cpu_baseline:
+            import oracle as _o
+            w = 0.0
+            for k, r_k in keep.items():
+                rk = _o.solve(r_k, x0[k], linear_solver="qr")
+                w = max(w, float(np.abs(sd.T_from_pose7(mine[k, :7]) - sd.T_from_pose7(rk.pose)).max()))
+            res["T_cl_max_abs_err_vs_oracle_sample"] = w
+    ss.close()
+    return res
 
 
 def main():
@@ -74,7 +178,6 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    coll_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist_mod
 
@@ -88,8 +191,30 @@ def main():
     import camlasercalibratool_amd as clc
     from camlasercalibratool_amd import simdata as sd
 
-    # ---- synthetic input (one independent problem per rank), resident in HBM before timing ----
-    S = sd.sim_fixed_count(1000 + rank, args.poses, args.pts, noise_sigma=args.noise)
+    if world > 1:
+        # ---- N>1: the C4 workload (sharded batch + RCCL gather); see run_c4_shard ----
+        c4 = run_c4_shard(args, torch, dist, rank, world, local_rank, args.steps, args.warmup, use_rccl=(args.backend == "nccl"))
+        if rank == 0:
+            out = {
+                "metric": "residual+Jacobian evals/s (batched LM solves, 8192 independent 1e4-obs point-to-plane problems per GPU, RCCL gather)",
+                "value": c4["evals_per_s"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": c4["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": c4["workload"], "step": "clc_solve_batched of the rank's resident shard + one RCCL all-gather of all result records",
+                           "problems": c4["problems"], "observations_per_gpu": c4["observations_per_gpu"],
+                           "parallelism": f"problem-sharded x{world} (contiguous shards, no data-path collective), clc_gather_results",
+                           "device": c4["device"], "compute_units": c4["compute_units"]},
+                "problems_per_s": c4["problems_per_s"], "lm_iters_per_s": c4["lm_iters_per_s"],
+                "roofline": c4.pop("roofline"),
+                "batched_c4_shard": c4,
+                "single_gpu_base": "run `bench.py --gpus 1`: its `batched_c4_shard` sub-object is this workload on one GPU",
+            }
+            print(json.dumps(out))
+        dist.destroy_process_group()
+        return
+
+    # ---- N=1: C2, the configuration the metric is quoted on ----
+    S = sd.sim_fixed_count(1000, args.poses, args.pts, noise_sigma=args.noise)
     rec = clc.flatten_observations(S, use_linefitting_data=False)  # calibr_simulation.cpp:130 flags
     n_obs = rec.shape[0]
     x0 = sd.pose7_from_T(np.eye(4))
@@ -107,11 +232,6 @@ def main():
 
     for _ in range(args.warmup):
         res = solver.solve(x0, opt, trace_cap=0)
-    result_rec = torch.zeros(12, dtype=torch.float64, device=coll_dev)
-    gathered = torch.zeros(12 * world, dtype=torch.float64, device=coll_dev) if dist is not None else None
-    if dist is not None:
-        dist.all_gather_into_tensor(gathered, result_rec)  # warm up the RCCL communicator
-
     barrier()
     t0 = time.perf_counter()
     evals = 0
@@ -124,24 +244,10 @@ def main():
         iters += res.summary.num_iterations
         k_ms += res.summary.eval_kernel_ms
         k_launches += res.summary.eval_kernel_launches
-    if dist is not None:  # final gather of the per-problem result records over xGMI
-        s = res.summary
-        result_rec.copy_(torch.tensor(list(res.pose) + [s.final_cost, s.initial_cost, float(s.num_iterations),
-                                                        float(s.termination), float(rank)], dtype=torch.float64))
-        dist.all_gather_into_tensor(gathered, result_rec)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # max time over ranks, summed work
-    if dist is not None:
-        t = torch.tensor([elapsed, float(evals), float(iters)], dtype=torch.float64, device=coll_dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed_max = float(tmax[0])
-        evals_total, iters_total = float(t[1]), float(t[2])
-    else:
-        elapsed_max, evals_total, iters_total = elapsed, float(evals), float(iters)
+    elapsed_max, evals_total, iters_total = elapsed, float(evals), float(iters)  # one rank
 
     out = None
     if rank == 0:
@@ -164,11 +270,10 @@ def main():
                             f"sigma={args.noise} m), init Tcl=I, Cauchy loss, Ceres-default LM; one independent problem per GPU",
                 "step": "one complete clc_solve (observations resident in HBM)",
                 "observations": n_obs,
-                "parallelism": f"problem-sharded x{world}, RCCL all_gather of result records" if world > 1 else "single GPU",
+                "parallelism": "single GPU (a single problem does not shard: replicas only; --gpus N>1 runs the C4 sharded batch)",
                 "device": dev_name,
                 "compute_units": n_cus,
             },
-            "gathered_result_records": (gathered.view(world, 12).cpu().tolist() if gathered is not None else None),
             "lm_iters_per_s": iters_total / elapsed_max,
             "lm_iterations_per_solve": res.summary.num_iterations,
             "evaluation_passes_per_solve": res.summary.num_evaluations,
@@ -287,6 +392,10 @@ def main():
                 w = max(w, float(np.abs(sd.T_from_pose7(pb[k]) - sd.T_from_pose7(rk.pose)).max()))
             out["batched_c3"]["T_cl_max_abs_err_vs_oracle_sample"] = w
 
+    # ---- BASELINE.json configs[3] (C4), one GPU's share: the N=1 base of the multi-GPU curve ----
+    if rank == 0 and world == 1 and not args.no_c4_shard:
+        out["batched_c4_shard"] = run_c4_shard(args, torch, None, 0, 1, local_rank, args.shard_steps, 2)
+
     # ---- CPU baseline + parity (rank 0, N=1): the oracle's DENSE_QR Ceres restatement, 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
@@ -359,8 +468,6 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     solver.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ from . import _build
 CLC_OK = 0
 ERRORS = {
     -1: "CLC_ERR_INVALID_ARG", -2: "CLC_ERR_HIP", -3: "CLC_ERR_NONFINITE", -4: "CLC_ERR_EMPTY_SCAN",
-    -5: "CLC_ERR_NO_DATA", -6: "CLC_ERR_LINALG", -7: "CLC_ERR_NO_DEVICE",
+    -5: "CLC_ERR_NO_DATA", -6: "CLC_ERR_LINALG", -7: "CLC_ERR_NO_DEVICE", -8: "CLC_ERR_COMM",
 }
 TERMINATION = {
     0: "RUNNING", 1: "CONVERGENCE(gradient)", 2: "CONVERGENCE(parameter)", 3: "CONVERGENCE(function)",
@@ -28,6 +28,8 @@ EXPORTED = [
     "clc_factor_evaluate", "clc_pose_plus", "clc_pose_plus_jacobian", "clc_eval", "clc_solve",
     "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
     "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",
+    "clc_comm_unique_id", "clc_comm_create", "clc_comm_destroy", "clc_comm_rank", "clc_comm_world",
+    "clc_gather_results", "clc_comm_records",
 ]
 
 
@@ -136,6 +138,13 @@ def lib():
         L.clc_num_problems.argtypes = [C.c_void_p]
         L.clc_destroy.argtypes = [C.c_void_p]
         L.clc_destroy.restype = None
+        L.clc_comm_destroy.argtypes = [C.c_void_p]
+        L.clc_comm_destroy.restype = None
+        L.clc_comm_rank.argtypes = [C.c_void_p]
+        L.clc_comm_world.argtypes = [C.c_void_p]
+        L.clc_comm_library.restype = C.c_char_p
+        L.clc_comm_records.argtypes = [C.c_void_p]
+        L.clc_comm_records.restype = C.POINTER(C.c_double)
         _lib = L
     return _lib
 

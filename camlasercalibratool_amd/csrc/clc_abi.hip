@@ -4,11 +4,16 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -ffp-contract=on -mllvm -amdgpu-kernarg-preload-count=8 clc_abi.hip -o libclc_hip.so
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <link.h>
+
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -111,6 +116,8 @@ struct clc_handle {
   double* d_poses = nullptr;            // device view of the same allocation
   clc_summary* h_summaries = nullptr;
   clc_summary* d_summaries = nullptr;
+  double* d_results = nullptr;      // clc_result_record per problem of the last clc_solve_batched (device; clc_gather_results)
+  size_t results_valid = 0;         // number of valid records in d_results
   unsigned int* d_queue = nullptr;  // small device counter (active problems)
   unsigned int* d_ticket = nullptr; // arrival counter of the fused evaluation+controller launch
   double* d_partials_b = nullptr;   // second row buffer (inside the d_partials allocation) for the step kernel
@@ -313,6 +320,70 @@ int compress_records(clc_handle* h, const double* d_aos, size_t n_total, const s
   return CLC_OK;
 }
 
+
+// Launch geometry of the batched solver (shared by clc_solve_batched and the timing hook).
+struct BatchedLaunch {
+  int bpp = 1;            // workgroups per problem
+  size_t n_blocks = 0;
+  int lm_threads = 64;
+  unsigned lm_blocks = 0;
+  bool compact = false, deep = false, nt = false;
+};
+
+int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunch* bl) {
+  const size_t P = h->n_problems;
+  // enough workgroups to fill the chip: >= 2 per CU in total, never more than one per 4 tiles
+  const size_t target_blocks = h->grid_override > 0 ? (size_t)h->grid_override : 4 * (size_t)h->num_cus;
+  int bpp = (int)((target_blocks + P - 1) / P);
+  const long long max_tiles = h->batch_max_tiles;
+  const int bpp_cap = (int)std::max<long long>(1, max_tiles / 4);
+  bpp = std::max(1, std::min(bpp, bpp_cap));
+  const size_t n_blocks = P * (size_t)bpp;
+  if (n_blocks > h->bpartials_cap_blocks) {
+    if (h->d_bpartials) CLC_HIP(hipFree(h->d_bpartials));
+    h->d_bpartials = nullptr; h->bpartials_cap_blocks = 0;
+    CLC_HIP(hipMalloc(&h->d_bpartials, sizeof(double) * n_blocks * clc::NACC));
+    h->bpartials_cap_blocks = n_blocks;
+  }
+  bl->bpp = bpp;
+  bl->n_blocks = n_blocks;
+  bl->lm_threads = 64;
+  bl->lm_blocks = (unsigned)((P + bl->lm_threads - 1) / bl->lm_threads);
+  bl->compact = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->bcompact_ok;
+  const bool bbeyond = h->launch_auto && h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes;
+  bl->nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 ||
+           (bl->compact && h->launch_auto &&
+            h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes + kInfinityCacheBytes / 2);
+  bl->deep = (h->launch_flags & clc::FLAG_DEEP) != 0 || bbeyond;
+  return CLC_OK;
+}
+
+void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl) {
+  const size_t n_blocks = bl.n_blocks;
+  const int bpp = bl.bpp;
+  const bool bcompact = bl.compact, bdeep = bl.deep, bnt = bl.nt;
+#define CLC_LAUNCH_B(LOSS, CP, NT)                                                                          \
+  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, CP, NT, false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
+                     h->stream, (CP) ? h->d_bctiles : h->d_btiles, h->d_bgroups, h->d_tile_off, h->d_nobs,    \
+                     h->d_states, bpp, opt.loss_scale_factor, h->d_bpartials)
+#define CLC_LAUNCH_BD(LOSS, NT)                                                                             \
+  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, true, NT, true>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
+                     h->stream, h->d_bctiles, h->d_bgroups, h->d_tile_off, h->d_nobs, h->d_states, bpp,           \
+                     opt.loss_scale_factor, h->d_bpartials)
+  if (bcompact && bdeep) {
+    if (opt.use_loss) { if (bnt) CLC_LAUNCH_BD(true, true); else CLC_LAUNCH_BD(true, false); }
+    else { if (bnt) CLC_LAUNCH_BD(false, true); else CLC_LAUNCH_BD(false, false); }
+  } else if (bcompact) {
+    if (opt.use_loss) { if (bnt) CLC_LAUNCH_B(true, true, true); else CLC_LAUNCH_B(true, true, false); }
+    else { if (bnt) CLC_LAUNCH_B(false, true, true); else CLC_LAUNCH_B(false, true, false); }
+  } else {
+    if (opt.use_loss) { if (bnt) CLC_LAUNCH_B(true, false, true); else CLC_LAUNCH_B(true, false, false); }
+    else { if (bnt) CLC_LAUNCH_B(false, false, true); else CLC_LAUNCH_B(false, false, false); }
+  }
+#undef CLC_LAUNCH_B
+#undef CLC_LAUNCH_BD
+}
+
 }  // namespace
 
 extern "C" {
@@ -379,7 +450,7 @@ void clc_destroy(clc_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_state, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
-                  h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups};
+                  h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -392,7 +463,13 @@ void clc_destroy(clc_handle* h) {
 
 int clc_set_stream(clc_handle* h, void* hip_stream) {
   if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_set_stream: NULL handle");
-  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  hipStream_t next = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  if (next == h->stream) return CLC_OK;
+  // A finished solve may still have up to launch_ahead + 1 no-op launches queued on the old stream; they forward the
+  // terminated LM state into the buffers the next solve initialises.  Drain them before anything runs elsewhere.
+  CLC_HIP(hipSetDevice(h->device));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  h->stream = next;
   return CLC_OK;
 }
 
@@ -887,13 +964,13 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
     h->btiles_cap_bytes = bytes;
   }
   if (P > h->problems_cap) {
-    void* olds[] = {h->d_tile_off, h->d_nobs, h->d_states};
+    void* olds[] = {h->d_tile_off, h->d_nobs, h->d_states, h->d_results};
     for (void* p : olds) if (p) CLC_HIP(hipFree(p));
     if (h->h_poses) CLC_HIP(hipHostFree(h->h_poses));
     if (h->h_summaries) CLC_HIP(hipHostFree(h->h_summaries));
     h->h_poses = nullptr; h->h_summaries = nullptr;
     h->d_tile_off = nullptr; h->d_nobs = nullptr; h->d_poses = nullptr; h->d_summaries = nullptr;
-    h->d_states = nullptr;
+    h->d_states = nullptr; h->d_results = nullptr; h->results_valid = 0;
     h->problems_cap = 0;
     CLC_HIP(hipMalloc(&h->d_tile_off, sizeof(long long) * (P + 1)));
     CLC_HIP(hipMalloc(&h->d_nobs, sizeof(long long) * P));
@@ -902,6 +979,7 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
     CLC_HIP(hipHostMalloc(&h->h_summaries, sizeof(clc_summary) * P, hipHostMallocMapped));
     CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_summaries), h->h_summaries, 0));
     CLC_HIP(hipMalloc(&h->d_states, sizeof(clc::LmState) * P));
+    CLC_HIP(hipMalloc(&h->d_results, sizeof(clc_result_record) * P));
     h->problems_cap = P;
   }
   if (P == 0) { h->n_problems = 0; return CLC_OK; }
@@ -927,6 +1005,7 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   int crc = CLC_OK;
   h->bcompact_ok = false;
+  h->results_valid = 0;
   if (e == hipSuccess && d_aos)
     crc = compress_records(h, d_aos, n_total, rel, tile_off, &h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups,
                            &h->bgroups_cap_bytes, &h->bn_groups, &h->bcompact_ok);
@@ -951,34 +1030,21 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     if (!std::isfinite(poses[i])) return fail(CLC_ERR_NONFINITE, "clc_solve_batched: non-finite initial pose");
   CLC_HIP(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
-  // enough workgroups to fill the chip: >= 2 per CU in total, never more than one per 4 tiles
-  const size_t target_blocks = h->grid_override > 0 ? (size_t)h->grid_override : 4 * (size_t)h->num_cus;
-  int bpp = (int)((target_blocks + P - 1) / P);
-  const long long max_tiles = h->batch_max_tiles;
-  const int bpp_cap = (int)std::max<long long>(1, max_tiles / 4);
-  bpp = std::max(1, std::min(bpp, bpp_cap));
-  const size_t n_blocks = P * (size_t)bpp;
-  if (n_blocks > h->bpartials_cap_blocks) {
-    if (h->d_bpartials) CLC_HIP(hipFree(h->d_bpartials));
-    h->d_bpartials = nullptr; h->bpartials_cap_blocks = 0;
-    CLC_HIP(hipMalloc(&h->d_bpartials, sizeof(double) * n_blocks * clc::NACC));
-    h->bpartials_cap_blocks = n_blocks;
+  BatchedLaunch bl;
+  {
+    const int rc = batched_launch_setup(h, opt, &bl);
+    if (rc != CLC_OK) return rc;
   }
+  const int bpp = bl.bpp;
   // (the previous batch ended with a stream synchronisation: nothing still reads or writes the staging buffers)
   std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
-  const int lm_threads = 64;
-  const unsigned lm_blocks = (unsigned)((P + lm_threads - 1) / lm_threads);
+  const int lm_threads = bl.lm_threads;
+  const unsigned lm_blocks = bl.lm_blocks;
   hipLaunchKernelGGL(clc::batched_init_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
                      opt, h->d_poses, (int)P);
   CLC_HIP(hipGetLastError());
   const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
   const int max_evals = opt.max_num_iterations + 1;
-  const bool bcompact = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->bcompact_ok;
-  const bool bbeyond = h->launch_auto && h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes;
-  const bool bnt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 ||
-                   (bcompact && h->launch_auto &&
-                    h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes + kInfinityCacheBytes / 2);
-  const bool bdeep = (h->launch_flags & clc::FLAG_DEEP) != 0 || bbeyond;
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
   mb->status = CLC_RUNNING;
@@ -993,26 +1059,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     if (__atomic_load_n(&mb->status, __ATOMIC_ACQUIRE) != CLC_RUNNING) break;
     const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
     if (launched < max_evals && launched - done < lookahead) {
-#define CLC_LAUNCH_B(LOSS, CP, NT)                                                                          \
-  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, CP, NT, false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
-                     h->stream, (CP) ? h->d_bctiles : h->d_btiles, h->d_bgroups, h->d_tile_off, h->d_nobs,    \
-                     h->d_states, bpp, opt.loss_scale_factor, h->d_bpartials)
-#define CLC_LAUNCH_BD(LOSS, NT)                                                                             \
-  hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, true, NT, true>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
-                     h->stream, h->d_bctiles, h->d_bgroups, h->d_tile_off, h->d_nobs, h->d_states, bpp,           \
-                     opt.loss_scale_factor, h->d_bpartials)
-      if (bcompact && bdeep) {
-        if (opt.use_loss) { if (bnt) CLC_LAUNCH_BD(true, true); else CLC_LAUNCH_BD(true, false); }
-        else { if (bnt) CLC_LAUNCH_BD(false, true); else CLC_LAUNCH_BD(false, false); }
-      } else if (bcompact) {
-        if (opt.use_loss) { if (bnt) CLC_LAUNCH_B(true, true, true); else CLC_LAUNCH_B(true, true, false); }
-        else { if (bnt) CLC_LAUNCH_B(false, true, true); else CLC_LAUNCH_B(false, true, false); }
-      } else {
-        if (opt.use_loss) { if (bnt) CLC_LAUNCH_B(true, false, true); else CLC_LAUNCH_B(true, false, false); }
-        else { if (bnt) CLC_LAUNCH_B(false, false, true); else CLC_LAUNCH_B(false, false, false); }
-      }
-#undef CLC_LAUNCH_B
-#undef CLC_LAUNCH_BD
+      launch_batched_eval(h, opt, bl);
       hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
                          h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue, h->d_ticket, launched,
                          h->d_mailbox);
@@ -1030,9 +1077,10 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   }
   CLC_HIP(hipGetLastError());
   hipLaunchKernelGGL(clc::batched_finish_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
-                     (int)P, h->d_poses, h->d_summaries);
+                     (int)P, h->d_poses, h->d_summaries, h->d_results);
   CLC_HIP(hipGetLastError());
   CLC_HIP(hipStreamSynchronize(h->stream));
+  h->results_valid = P;
   std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
   std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1144,6 +1192,179 @@ int clc_scan_to_points(clc_handle* h, const float* ranges, const int64_t* offset
   return CLC_OK;
 }
 
+// ---- multi-GPU: RCCL gather of the sharded batch's result records ------------------------------
+}  // extern "C"
+
+#include <rccl/rccl.h>  // types and prototypes only: the functions are bound at run time (no link dependency)
+
+namespace {
+
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string origin;
+  std::string error;
+};
+
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
+  const char* name = info->dlpi_name;
+  if (name && std::strstr(name, "librccl")) {
+    *static_cast<std::string*>(data) = name;
+    return 1;
+  }
+  return 0;
+}
+
+// One RCCL per process: reuse the copy that is already mapped (PyTorch bundles its own), else load the system one.
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<std::string> candidates;
+    if (const char* env = std::getenv("CLC_RCCL_LIBRARY")) candidates.push_back(env);
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    if (!loaded.empty()) candidates.push_back(loaded);
+    candidates.push_back("librccl.so.1");
+    candidates.push_back("librccl.so");
+    candidates.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& c : candidates) {
+      api.lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) { api.origin = c; break; }
+      const char* why = dlerror();
+      api.error += c + ": " + (why ? why : "?") + "; ";
+    }
+    if (!api.lib) return;
+#define CLC_BIND(field, sym)                                                   \
+  api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym));      \
+  if (!api.field) { api.error += std::string("missing symbol ") + sym + "; "; }
+    CLC_BIND(GetUniqueId, "ncclGetUniqueId")
+    CLC_BIND(CommInitRank, "ncclCommInitRank")
+    CLC_BIND(CommDestroy, "ncclCommDestroy")
+    CLC_BIND(AllGather, "ncclAllGather")
+    CLC_BIND(GetErrorString, "ncclGetErrorString")
+#undef CLC_BIND
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
+      api.lib = nullptr;
+    }
+  });
+  return api;
+}
+
+int rccl_fail(const char* what, ncclResult_t r) {
+  char buf[512];
+  std::snprintf(buf, sizeof(buf), "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error");
+  g_last_error = buf;
+  return CLC_ERR_COMM;
+}
+
+}  // namespace
+
+struct clc_comm {
+  clc_handle* h = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  double* d_send = nullptr;
+  double* d_recv = nullptr;
+  double* h_recv = nullptr;  // pinned
+  size_t cap = 0;            // records per rank the buffers hold
+};
+
+extern "C" {
+
+int clc_comm_unique_id(char id[CLC_COMM_ID_BYTES]) {
+  if (!id) return fail(CLC_ERR_INVALID_ARG, "clc_comm_unique_id: NULL id");
+  static_assert(sizeof(ncclUniqueId) == CLC_COMM_ID_BYTES, "ncclUniqueId size");
+  RcclApi& api = rccl();
+  if (!api.lib) return fail(CLC_ERR_COMM, ("clc_comm_unique_id: RCCL not available: " + api.error).c_str());
+  ncclUniqueId u;
+  ncclResult_t r = api.GetUniqueId(&u);
+  if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+  std::memcpy(id, u.internal, CLC_COMM_ID_BYTES);
+  return CLC_OK;
+}
+
+int clc_comm_create(clc_comm** out, clc_handle* h, const char id[CLC_COMM_ID_BYTES], int rank, int world) {
+  if (!out || !h || !id || world < 1 || rank < 0 || rank >= world)
+    return fail(CLC_ERR_INVALID_ARG, "clc_comm_create: bad argument");
+  *out = nullptr;
+  RcclApi& api = rccl();
+  if (!api.lib) return fail(CLC_ERR_COMM, ("clc_comm_create: RCCL not available: " + api.error).c_str());
+  CLC_HIP(hipSetDevice(h->device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, CLC_COMM_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = api.CommInitRank(&comm, world, u, rank);
+  if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+  clc_comm* c = new clc_comm();
+  c->h = h;
+  c->comm = comm;
+  c->rank = rank;
+  c->world = world;
+  *out = c;
+  return CLC_OK;
+}
+
+void clc_comm_destroy(clc_comm* c) {
+  if (!c) return;
+  if (c->h) {
+    (void)hipSetDevice(c->h->device);
+    (void)hipStreamSynchronize(c->h->stream);
+  }
+  if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+  if (c->d_send) (void)hipFree(c->d_send);
+  if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->h_recv) (void)hipHostFree(c->h_recv);
+  delete c;
+}
+
+int clc_comm_rank(const clc_comm* c) { return c ? c->rank : -1; }
+int clc_comm_world(const clc_comm* c) { return c ? c->world : 0; }
+// which RCCL was bound ("" before the first comm call) — diagnostics / tests
+const char* clc_comm_library(void) { return rccl().origin.c_str(); }
+
+int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_rank, clc_result_record* all_records) {
+  if (!c || cap_per_rank == 0 || first_global_index < 0)
+    return fail(CLC_ERR_INVALID_ARG, "clc_gather_results: bad argument");
+  clc_handle* h = c->h;
+  const size_t n_local = h->results_valid;
+  if (n_local > cap_per_rank) return fail(CLC_ERR_INVALID_ARG, "clc_gather_results: cap_per_rank < local problems");
+  if (n_local > 0 && !h->d_results) return fail(CLC_ERR_NO_DATA, "clc_gather_results: no solved batch on the handle");
+  CLC_HIP(hipSetDevice(h->device));
+  if (cap_per_rank > c->cap) {
+    if (c->d_send) CLC_HIP(hipFree(c->d_send));
+    if (c->d_recv) CLC_HIP(hipFree(c->d_recv));
+    if (c->h_recv) CLC_HIP(hipHostFree(c->h_recv));
+    c->d_send = c->d_recv = c->h_recv = nullptr;
+    c->cap = 0;
+    CLC_HIP(hipMalloc(&c->d_send, sizeof(clc_result_record) * cap_per_rank));
+    CLC_HIP(hipMalloc(&c->d_recv, sizeof(clc_result_record) * cap_per_rank * (size_t)c->world));
+    CLC_HIP(hipHostMalloc(&c->h_recv, sizeof(clc_result_record) * cap_per_rank * (size_t)c->world, hipHostMallocDefault));
+    c->cap = cap_per_rank;
+  }
+  const int threads = 256;
+  hipLaunchKernelGGL(clc::pack_results_kernel, dim3((unsigned)((cap_per_rank + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, h->d_results, (long long)n_local, (long long)cap_per_rank, (double)first_global_index,
+                     c->d_send);
+  CLC_HIP(hipGetLastError());
+  const size_t count = cap_per_rank * (sizeof(clc_result_record) / sizeof(double));
+  ncclResult_t r = rccl().AllGather(c->d_send, c->d_recv, count, ncclDouble, c->comm, h->stream);
+  if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+  const size_t bytes = sizeof(clc_result_record) * cap_per_rank * (size_t)c->world;
+  CLC_HIP(hipMemcpyAsync(c->h_recv, c->d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  if (all_records) std::memcpy(all_records, c->h_recv, bytes);
+  return CLC_OK;
+}
+
+const clc_result_record* clc_comm_records(const clc_comm* c) {
+  return c ? reinterpret_cast<const clc_result_record*>(c->h_recv) : nullptr;
+}
+
 // ---- test hooks --------------------------------------------------------------------------
 // Runs only the wavefront reduction on in[64*28] -> out[28] (reduce_mode 0 butterfly, 1 shuffle).
 int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int reduce_mode) {
@@ -1209,6 +1430,35 @@ int clc_debug_lm_profile(clc_handle* h, long long out[8]) {
   if (!h || !out) return fail(CLC_ERR_INVALID_ARG, "clc_debug_lm_profile: bad argument");
   CLC_HIP(hipStreamSynchronize(h->stream));
   for (int i = 0; i < 8; ++i) out[i] = h->h_mailbox->prof[i];
+  return CLC_OK;
+}
+
+// Times `reps` back-to-back launches of batched_eval_kernel over ALL uploaded problems at the poses given
+// (poses[P*7]; every problem active, as in the first LM iteration of a batch) with HIP events on the handle's stream.
+int clc_time_batched_eval(clc_handle* h, const double* poses, int reps, double* avg_ms) {
+  if (!h || !poses || !avg_ms || reps < 1) return fail(CLC_ERR_INVALID_ARG, "clc_time_batched_eval: bad argument");
+  if (!h->d_btiles || h->n_problems == 0) return fail(CLC_ERR_NO_DATA, "clc_time_batched_eval: no problems uploaded");
+  CLC_HIP(hipSetDevice(h->device));
+  int rc = ensure_events(h, 2);
+  if (rc != CLC_OK) return rc;
+  clc_options opt;
+  clc_options_default(&opt);
+  BatchedLaunch bl;
+  rc = batched_launch_setup(h, opt, &bl);
+  if (rc != CLC_OK) return rc;
+  const size_t P = h->n_problems;
+  std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
+  hipLaunchKernelGGL(clc::batched_init_kernel, dim3(bl.lm_blocks), dim3(bl.lm_threads), 0, h->stream, h->d_states, opt,
+                     h->d_poses, (int)P);
+  for (int w = 0; w < 2; ++w) launch_batched_eval(h, opt, bl);
+  CLC_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int r = 0; r < reps; ++r) launch_batched_eval(h, opt, bl);
+  CLC_HIP(hipEventRecord(h->ev[1], h->stream));
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  CLC_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  *avg_ms = (double)ms / reps;
   return CLC_OK;
 }
 

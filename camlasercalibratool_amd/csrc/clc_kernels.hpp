@@ -1383,8 +1383,12 @@ __global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict
   }
 }
 
+// poses / summaries: pinned host memory (what clc_solve_batched returns); results: the same outcome as one
+// clc_result_record per problem in DEVICE memory, where clc_gather_results picks it up for the RCCL all-gather
+// (global_index holds the local index here; the gather adds the shard's first global index).
 __global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_problems,
-                                      double* __restrict__ poses, clc_summary* __restrict__ summaries) {
+                                      double* __restrict__ poses, clc_summary* __restrict__ summaries,
+                                      double* __restrict__ results) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_problems) return;
   const LmState* s = states + p;
@@ -1395,6 +1399,30 @@ __global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_
   sm.eval_kernel_ms = 0.0;
   sm.eval_kernel_launches = 0;
   summaries[p] = sm;
+  double* r = results + 12 * (size_t)p;
+  for (int i = 0; i < 7; ++i) r[i] = s->x_out[i];
+  r[7] = sm.final_cost;
+  r[8] = sm.initial_cost;
+  r[9] = (double)sm.num_iterations;
+  r[10] = (double)(sm.termination == CLC_RUNNING ? CLC_FAILURE : sm.termination);
+  r[11] = (double)p;
+}
+
+// Send buffer of the all-gather: cap records per rank, the first n_local real (global index = base + local index),
+// the rest padding (global_index = -1, everything else 0).
+__global__ void pack_results_kernel(const double* __restrict__ results, long long n_local, long long cap,
+                                    double base_index, double* __restrict__ send) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cap) return;
+  double* o = send + 12 * k;
+  if (k < n_local) {
+    const double* r = results + 12 * k;
+    for (int i = 0; i < 11; ++i) o[i] = r[i];
+    o[11] = base_index + (double)k;
+  } else {
+    for (int i = 0; i < 11; ++i) o[i] = 0.0;
+    o[11] = -1.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------

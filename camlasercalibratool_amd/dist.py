@@ -1,9 +1,15 @@
-"""Multi-GPU layer: independent T_cl problems shard across the GPUs of a node (one process
-per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for
-tests).  There is no data-path collective: every rank solves its contiguous shard on its own
-GPU, and the fixed-size result records are gathered once at the end.
+"""Multi-GPU layer (BASELINE.json configs[3]): independent T_cl problems shard across the GPUs of a
+node, one process per GPU.  There is no collective on the data path: every rank LOADS ONLY ITS OWN
+contiguous shard, keeps it resident in its GPU's HBM and solves it with clc_solve_batched; the
+fixed-size result records are gathered once per solve over xGMI.
 
-Result record (12 doubles per problem):
+The gather is a C-ABI entry point (clc_gather_results, include/clc.h): ncclAllGather on the solver's own
+stream, straight from the device buffer the batched solver leaves its results in.  torch.distributed is
+used for what it is here for — process rendezvous (rank / world size, distributing the 128-byte RCCL
+unique id).  With a CPU process group (gloo; tests, dry runs) the same records are gathered with
+torch.distributed.all_gather_into_tensor instead.
+
+Result record (12 doubles per problem, clc_result_record):
     pose[7], final_cost, initial_cost, num_iterations, termination, global_problem_index
 """
 from __future__ import annotations
@@ -23,6 +29,11 @@ def shard_problems(n_problems: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def shard_capacity(n_problems: int, world: int) -> int:
+    """Records every rank contributes to the all-gather (the largest shard; smaller ones are padded)."""
+    return max(1, (n_problems + world - 1) // world)
+
+
 def pack_records(poses: np.ndarray, summaries, lo: int) -> np.ndarray:
     p = len(summaries)
     out = np.zeros((p, RECORD))
@@ -33,17 +44,39 @@ def pack_records(poses: np.ndarray, summaries, lo: int) -> np.ndarray:
     return out
 
 
+def order_records(gathered: np.ndarray, n_problems: int) -> np.ndarray:
+    """Rank-major gathered records (padding has global index -1) -> [n_problems, 12] by global index."""
+    out = np.asarray(gathered, dtype=np.float64).reshape(-1, RECORD)
+    if out.shape[0] == n_problems and np.array_equal(out[:, 11], np.arange(n_problems)):
+        return out  # equal contiguous shards in rank order: already the global order, no padding
+    out = out[out[:, 11] >= 0]
+    out = out[np.argsort(out[:, 11], kind="stable")]
+    if out.shape[0] != n_problems or not np.array_equal(out[:, 11], np.arange(n_problems)):
+        raise RuntimeError(f"gather returned {out.shape[0]} records for {n_problems} problems (or indices not 0..P-1)")
+    return out
+
+
+def _rank_world() -> Tuple[int, int]:
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
 def gather_result_records(local: np.ndarray, n_problems: int, device: Optional[str] = None) -> np.ndarray:
-    """all_gather of the per-problem result records -> [n_problems, 12] on every rank, ordered
-    by global problem index.  Shards may differ in size by one; they are padded to equal
-    length for the collective."""
+    """torch.distributed path (any backend; what the CPU/gloo tests run): all_gather of the per-problem
+    result records -> [n_problems, 12] on every rank, ordered by global problem index."""
     import torch
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.asarray(local, dtype=np.float64).reshape(-1, RECORD)
+        return order_records(local, n_problems)
     world = dist.get_world_size()
-    cap = (n_problems + world - 1) // world
+    cap = shard_capacity(n_problems, world)
     buf = torch.full((cap, RECORD), -1.0, dtype=torch.float64)
     loc = torch.as_tensor(np.asarray(local, dtype=np.float64).reshape(-1, RECORD))
     buf[: loc.shape[0]] = loc
@@ -51,46 +84,93 @@ def gather_result_records(local: np.ndarray, n_problems: int, device: Optional[s
         buf = buf.to(device)
     out = torch.empty((world * cap, RECORD), dtype=torch.float64, device=buf.device)
     dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy()
-    out = out[out[:, 11] >= 0]
-    order = np.argsort(out[:, 11], kind="stable")
-    out = out[order]
-    assert out.shape[0] == n_problems, (out.shape, n_problems)
-    return out
+    return order_records(out.cpu().numpy(), n_problems)
 
 
-def solve_sharded(records: np.ndarray, offsets: np.ndarray, poses0: np.ndarray, options=None,
-                  solve_fn: Optional[Callable] = None, device_index: Optional[int] = None) -> np.ndarray:
-    """Solve P independent problems across all ranks.  `records`/`offsets`/`poses0` describe
-    the FULL batch on every rank (each rank touches only its shard).  Returns the gathered
-    [P,12] result records on every rank.
+def exchange_unique_id(rank: int, world: int) -> bytes:
+    """Rank 0 draws the RCCL unique id (clc_comm_unique_id); the 128 bytes travel over the process group's store."""
+    from .solver import comm_unique_id
 
-    solve_fn(records_shard, offsets_shard, poses_shard, options) -> (poses, summaries) defaults
-    to the GPU batched solver; tests inject a stub to exercise the sharding on CPU/gloo."""
+    if world == 1:
+        return comm_unique_id()
     import torch.distributed as dist
 
-    P = len(offsets) - 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    lo, hi = shard_problems(P, rank, world)
-    off = np.ascontiguousarray(offsets[lo : hi + 1] - offsets[lo], dtype=np.int64)
-    rec = np.ascontiguousarray(records[offsets[lo] : offsets[hi]])
-    p0 = np.ascontiguousarray(np.asarray(poses0).reshape(P, 7)[lo:hi])
-    device = None
-    if solve_fn is None:
-        from .solver import Solver
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
-        dev = device_index if device_index is not None else rank
 
-        def solve_fn(r, o, p, opt):  # noqa: E306
-            with Solver(dev) as sv:
-                sv.upload_batched(r, o)
-                return sv.solve_batched(p, opt)
+class ShardSolver:
+    """One rank's share of a sharded batch of `n_problems` independent problems: a Solver on this rank's GPU with
+    the shard resident, plus the RCCL communicator for the result gather.  Construct once, solve many times."""
 
-        device = f"cuda:{dev}"
-    if hi > lo:
-        poses, sms = solve_fn(rec, off, p0, options)
-        local = pack_records(poses, sms, lo)
-    else:
+    def __init__(self, n_problems: int, device_index: Optional[int] = None, rank: Optional[int] = None,
+                 world: Optional[int] = None, use_rccl: bool = True):
+        """use_rccl=False (dry runs on a CPU process group, e.g. two ranks sharing one GPU, which RCCL refuses):
+        the records are gathered with torch.distributed instead of clc_gather_results."""
+        from .solver import Comm, Solver
+
+        r, w = _rank_world()
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.n_problems = n_problems
+        self.lo, self.hi = shard_problems(n_problems, self.rank, self.world)
+        self.cap = shard_capacity(n_problems, self.world)
+        self.solver = Solver(self.rank if device_index is None else device_index)
+        self.comm = Comm(self.solver, exchange_unique_id(self.rank, self.world), self.rank, self.world) if use_rccl else None
+
+    def upload(self, records: np.ndarray, offsets: np.ndarray):
+        """This rank's shard only: records of problems [lo, hi), offsets relative to the shard."""
+        assert len(offsets) - 1 == self.hi - self.lo, "upload() takes exactly this rank's shard"
+        self.solver.upload_batched(records, offsets)
+
+    def solve(self, poses0: np.ndarray, options=None, ordered: bool = True, copy: bool = True) -> np.ndarray:
+        """clc_solve_batched on the shard + clc_gather_results: [n_problems, 12] on every rank (ordered=False:
+        the raw rank-major [world * cap, 12] buffer, padding records with global index -1 included)."""
+        self.last_poses, self.last_summaries = None, None
+        if self.hi > self.lo:
+            self.last_poses, self.last_summaries = self.solver.solve_batched(poses0, options)
+        if self.comm is None:
+            local = pack_records(self.last_poses, self.last_summaries, self.lo) if self.hi > self.lo else np.zeros((0, RECORD))
+            return gather_result_records(local, self.n_problems)
+        out = self.comm.gather_results(self.lo, self.cap, copy=copy)
+        return order_records(out, self.n_problems) if ordered else out
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        self.solver.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def solve_sharded(load_shard: Callable[[int, int], Tuple[np.ndarray, np.ndarray, np.ndarray]], n_problems: int,
+                  options=None, solve_fn: Optional[Callable] = None, device_index: Optional[int] = None) -> np.ndarray:
+    """Solve `n_problems` independent problems across all ranks, one shot.
+
+    load_shard(lo, hi) -> (records [N,8], offsets [hi-lo+1] relative to the shard, poses0 [hi-lo,7]) is called
+    with THIS rank's block only: no rank ever materialises the full batch (C4 is 42 GB of records).
+    Returns the gathered [n_problems, 12] result records on every rank.
+
+    solve_fn(records, offsets, poses0, options) -> (poses, summaries), if given, replaces the GPU solver and the
+    records are gathered with torch.distributed (how the CPU/gloo tests exercise the sharding); otherwise the shard is
+    solved by clc_solve_batched on this rank's GPU and gathered by clc_gather_results (RCCL)."""
+    rank, world = _rank_world()
+    lo, hi = shard_problems(n_problems, rank, world)
+    if solve_fn is not None:
         local = np.zeros((0, RECORD))
-    return gather_result_records(local, P, device)
+        if hi > lo:
+            rec, off, p0 = load_shard(lo, hi)
+            poses, sms = solve_fn(rec, off, p0, options)
+            local = pack_records(poses, sms, lo)
+        return gather_result_records(local, n_problems)
+    with ShardSolver(n_problems, device_index, rank, world) as ss:
+        p0 = np.zeros((0, 7))
+        if hi > lo:
+            rec, off, p0 = load_shard(lo, hi)
+            ss.upload(rec, off)
+        return ss.solve(p0, options)

@@ -343,6 +343,163 @@ def sim_batch(seed: int, n_problems: int, n_poses: int, pts_per_pose: int,
     return probs, gts
 
 
+# ----------------------------------------------------------------------------------
+# C3/C4 shards: problem k is a pure function of (seed, k), vectorised over problems
+# ----------------------------------------------------------------------------------
+def _rot_to_quat_wxyz_vec(R: np.ndarray) -> np.ndarray:
+    """Vectorised `rot_to_quat_wxyz` (same branches, same operation order -> same bits)."""
+    R = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
+    N = R.shape[0]
+    q = np.empty((N, 4))
+    d = np.stack([R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]], axis=1)
+    tr = d[:, 0] + d[:, 1] + d[:, 2]
+    pos = tr > 0.0
+    if pos.any():
+        m = R[pos]
+        t = np.sqrt(tr[pos] + 1.0)
+        w = 0.5 * t
+        t = 0.5 / t
+        q[pos] = np.stack([w, (m[:, 2, 1] - m[:, 1, 2]) * t, (m[:, 0, 2] - m[:, 2, 0]) * t, (m[:, 1, 0] - m[:, 0, 1]) * t], axis=1)
+    if (~pos).any():
+        idx = np.nonzero(~pos)[0]
+        q[idx] = rot_to_quat_wxyz(R[idx]).reshape(-1, 4)
+    return q
+
+
+@dataclass
+class ProblemShard:
+    """Problems [lo, hi) of a seeded batch in pose-major form (every scan has exactly K points)."""
+
+    lo: int
+    hi: int
+    tag_q: np.ndarray   # [P, n_poses, 4] (w,x,y,z)
+    tag_t: np.ndarray   # [P, n_poses, 3]
+    pts: np.ndarray     # [P, n_poses, K, 3]
+    gt_Tcl: np.ndarray  # [P, 4, 4]
+
+    @property
+    def n_problems(self) -> int:
+        return self.hi - self.lo
+
+    def problem(self, k: int) -> ObservationSet:
+        """Problem with LOCAL index k as an ObservationSet (what the reference's call surface takes)."""
+        n_poses, K = self.pts.shape[1], self.pts.shape[2]
+        off = np.arange(n_poses + 1, dtype=np.int64) * K
+        flat = np.ascontiguousarray(self.pts[k].reshape(-1, 3))
+        return ObservationSet(self.tag_q[k].copy(), self.tag_t[k].copy(), off, flat, off.copy(), flat.copy())
+
+    def records(self) -> Tuple[np.ndarray, np.ndarray]:
+        """The flat clc_observation records of the whole shard + CSR problem offsets: the vectorised equivalent of
+        the reference's residual-block loop (src/LaseCamCalCeres.cpp:222-257; plane :227-231, scale :239-240) for
+        (use_linefitting_data = anything, use_boundary_constraint = false) — bitwise what
+        clc_flatten_observations produces problem by problem (tests/test_simdata_shard.py)."""
+        P, n_poses, K = self.pts.shape[0], self.pts.shape[1], self.pts.shape[2]
+        R = quat_wxyz_to_rot(self.tag_q.reshape(-1, 4))  # Eigen: Quaterniond -> toRotationMatrix, as flatten does
+        n = R[:, :, 2]
+        t = self.tag_t.reshape(-1, 3)
+        d = -((n[:, 0] * t[:, 0] + n[:, 1] * t[:, 1]) + n[:, 2] * t[:, 2])
+        rec = np.empty((P * n_poses, K, 8))
+        rec[:, :, 0:3] = n[:, None, :]
+        rec[:, :, 3] = d[:, None]
+        rec[:, :, 4:7] = self.pts.reshape(P * n_poses, K, 3)
+        rec[:, :, 7] = 1.0 / np.sqrt(float(K))
+        off = np.arange(P + 1, dtype=np.int64) * (n_poses * K)
+        return rec.reshape(-1, 8), off
+
+    def start_poses(self, sigma: float = 0.05) -> np.ndarray:
+        """Initial guesses: the ground truth moved by a seeded N(0, sigma) tangent step (first order in the
+        rotation: q <- normalize(q (x) [1, dtheta/2]), PoseLocalParameterization::Plus), [P,7]."""
+        x = np.empty((self.n_problems, 7))
+        for k in range(self.n_problems):
+            g = pose7_from_T(self.gt_Tcl[k])
+            dl = np.random.default_rng([977, self.lo + k]).normal(size=6) * sigma
+            b = dl[3:] * 0.5
+            ax, ay, az, aw = g[3], g[4], g[5], g[6]
+            w = aw - ax * b[0] - ay * b[1] - az * b[2]
+            qx = aw * b[0] + ax + ay * b[2] - az * b[1]
+            qy = aw * b[1] + ay + az * b[0] - ax * b[2]
+            qz = aw * b[2] + az + ax * b[1] - ay * b[0]
+            nrm = np.sqrt(qx * qx + qy * qy + qz * qz + w * w)
+            x[k] = (g[0] + dl[0], g[1] + dl[1], g[2] + dl[2], qx / nrm, qy / nrm, qz / nrm, w / nrm)
+        return x
+
+
+def sim_shard(seed: int, lo: int, hi: int, n_poses: int, pts_per_pose: int, noise_sigma: float = 0.0,
+              candidates: int = 64) -> ProblemShard:
+    """C3/C4 — problems [lo, hi) of a batch of independent T_cl problems (own ground truth drawn around the
+    simulation's, own board poses, own range noise; same distributions as `sim_batch` / main/calibr_simulation.cpp).
+    Problem k depends on (seed, k) only, so every rank of a sharded job generates exactly its own shard and any
+    single problem can be regenerated for a check.  Vectorised over the problems of the shard."""
+    P, K = hi - lo, pts_per_pose
+    u_gt = np.empty((P, 6)); u_pose = np.empty((P, candidates, 6)); noise = np.zeros((P, n_poses, K))
+    rngs = []
+    for i in range(P):
+        rng = np.random.default_rng([seed, lo + i])
+        u_gt[i] = rng.random(6)
+        u_pose[i] = rng.random((candidates, 6))
+        if noise_sigma > 0.0:
+            noise[i] = rng.normal(0.0, noise_sigma, size=(n_poses, K))
+        rngs.append(rng)
+    # ground truths (perturbed_gt)
+    a = (u_gt[:, :3] * 2 - 1) * 0.2
+    Rlc = rot_zyx(a[:, 0], a[:, 1], a[:, 2]) @ GT_RLC
+    tlc = GT_TLC + (u_gt[:, 3:] * 2 - 1) * 0.3
+    # candidate board poses (_draw_tag_poses) and the first n_poses whose board line crosses the lidar's field
+    ang = (u_pose[:, :, :3] * 2.0 - 1.0) * (np.pi / 6.0)
+    Rca = rot_zyx(ang[..., 0], ang[..., 1], ang[..., 2])                      # [P,C,3,3]
+    tca = np.stack([u_pose[..., 3] * 6.0 - 3.0, u_pose[..., 4] * 6.0 - 3.0, 1.0 + u_pose[..., 5] * 4.0], axis=-1)
+    n, d = _plane_in_laser(Rlc[:, None], tlc[:, None], Rca, tca)             # [P,C,3], [P,C]
+    lo_t, hi_t, ok = _valid_interval(n.reshape(-1, 3), d.reshape(-1))
+    ok = ok.reshape(P, candidates)
+    order = np.argsort(~ok, axis=1, kind="stable")[:, :n_poses]              # first valid candidates, in draw order
+    enough = ok.sum(axis=1) >= n_poses
+    rows = np.arange(P)[:, None]
+    Rca, tca, n, d = Rca[rows, order], tca[rows, order], n[rows, order], d[rows, order]
+    lo_t, hi_t = lo_t.reshape(P, candidates)[rows, order], hi_t.reshape(P, candidates)[rows, order]
+    for i in np.nonzero(~enough)[0]:  # rare: keep drawing from the problem's own stream
+        have = int(ok[i].sum())
+        while have < n_poses:
+            Rc, tc = _draw_tag_poses(rngs[i], candidates)
+            nn, dd = _plane_in_laser(Rlc[i], tlc[i], Rc, tc)
+            l2, h2, o2 = _valid_interval(nn, dd)
+            for j in np.nonzero(o2)[0][: n_poses - have]:
+                Rca[i, have], tca[i, have], n[i, have], d[i, have] = Rc[j], tc[j], nn[j], dd[j]
+                lo_t[i, have], hi_t[i, have] = l2[j], h2[j]
+                have += 1
+    frac = (np.arange(K) + 0.5) / K
+    theta = lo_t[..., None] + (hi_t - lo_t)[..., None] * frac                # [P,n_poses,K]
+    cx, sy = np.cos(theta), np.sin(theta)
+    depth = -d[..., None] / (cx * n[..., 0:1] + sy * n[..., 1:2])
+    if noise_sigma > 0.0:
+        depth = depth + noise
+    pts = np.stack([depth * cx, depth * sy, np.zeros_like(depth)], axis=-1)
+    gt = np.empty((P, 4, 4))
+    for i in range(P):
+        gt[i] = tlc_to_tcl(Rlc[i], tlc[i])
+    tag_q = _rot_to_quat_wxyz_vec(Rca.reshape(-1, 3, 3)).reshape(P, n_poses, 4)
+    return ProblemShard(lo, hi, tag_q, np.ascontiguousarray(tca), np.ascontiguousarray(pts), gt)
+
+
+def sim_shard_records(seed: int, lo: int, hi: int, n_poses: int, pts_per_pose: int, noise_sigma: float = 0.0,
+                      chunk: int = 256):
+    """Records, offsets, start poses and ground truths of problems [lo, hi), generated in chunks of `chunk` problems
+    so the temporaries stay small (a C4 shard is 8 192 problems x 10^4 records = 5.2 GB of records).
+    -> (records [N,8], offsets [P+1], x0 [P,7], gt_Tcl [P,4,4])"""
+    P = hi - lo
+    per = n_poses * pts_per_pose
+    rec = np.empty((P * per, 8))
+    x0 = np.empty((P, 7)); gt = np.empty((P, 4, 4))
+    for c0 in range(0, P, chunk):
+        c1 = min(P, c0 + chunk)
+        sh = sim_shard(seed, lo + c0, lo + c1, n_poses, pts_per_pose, noise_sigma)
+        r, _ = sh.records()
+        rec[c0 * per : c1 * per] = r
+        x0[c0:c1] = sh.start_poses()
+        gt[c0:c1] = sh.gt_Tcl
+    off = np.arange(P + 1, dtype=np.int64) * per
+    return rec, off, x0, gt
+
+
 # Board geometry of the boundary terms, LaseCamCalCeres.cpp:262-268.
 BOARD_ORIG = 0.0265 + 0.0165
 BOARD_SIZE = 0.5

@@ -37,6 +37,66 @@ def flatten_observations(obs_set, use_linefitting_data: bool = True, use_boundar
     return rec
 
 
+RESULT_RECORD = 12  # doubles per clc_result_record: pose[7], final_cost, initial_cost, iterations, termination, global index
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C-ABI: called by ONE rank, distributed to the others out of band."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(_capi.lib().clc_comm_unique_id(buf), "clc_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator bound to one Solver (clc_comm): collectives run on the solver's stream.
+    Creating it is a collective call — every rank of the job must do so with the same id."""
+
+    def __init__(self, solver: "Solver", uid: bytes, rank: int, world: int):
+        assert len(uid) == COMM_ID_BYTES
+        self._L = _capi.lib()
+        self._c = C.c_void_p()
+        self._solver = solver  # keep the handle alive
+        check(self._L.clc_comm_create(C.byref(self._c), solver._h, C.c_char_p(uid), C.c_int(rank), C.c_int(world)),
+              "clc_comm_create")
+        self.rank, self.world = rank, world
+
+    @property
+    def library(self) -> str:
+        return self._L.clc_comm_library().decode()
+
+    def gather_results(self, first_global_index: int, cap_per_rank: int, copy: bool = True) -> np.ndarray:
+        """ncclAllGather of the result records of the solver's last solve_batched -> [world*cap_per_rank, 12]
+        (rank-major; padding records have global index -1).  copy=False returns a view of the communicator's
+        pinned host buffer (valid until the next gather) instead of a fresh array."""
+        n = self.world * cap_per_rank
+        if copy:
+            out = np.empty((n, RESULT_RECORD))
+            check(self._L.clc_gather_results(self._c, C.c_int64(first_global_index), C.c_size_t(cap_per_rank), dptr(out)),
+                  "clc_gather_results")
+            return out
+        check(self._L.clc_gather_results(self._c, C.c_int64(first_global_index), C.c_size_t(cap_per_rank), None),
+              "clc_gather_results")
+        return np.ctypeslib.as_array(self._L.clc_comm_records(self._c), shape=(n, RESULT_RECORD))
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c:
+            self._L.clc_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class Solver:
     """One solver context on one GPU (one HIP stream).  Not thread-safe per instance."""
 
@@ -200,6 +260,14 @@ class Solver:
         check(self._L.clc_time_steps(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(first), C.c_int(last),
                                      C.byref(ms), C.byref(n)), "clc_time_steps")
         return ms.value, n.value
+
+    def time_batched_eval(self, poses: np.ndarray, reps: int = 20) -> float:
+        """Mean duration [ms] of `reps` back-to-back batched_eval_kernel launches over all uploaded problems at `poses`."""
+        ms = C.c_double()
+        P = self.num_problems
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(P, 7))
+        check(self._L.clc_time_batched_eval(self._h, dptr(poses), C.c_int(reps), C.byref(ms)), "clc_time_batched_eval")
+        return ms.value
 
     def time_eval(self, pose: np.ndarray, reps: int = 20, with_loss: bool = True, loss_scale_factor: float = 0.05,
                   with_jacobian: bool = True) -> float:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLC_VERSION 100
+#define CLC_VERSION 200
 
 /* status codes */
 #define CLC_OK 0
@@ -35,6 +35,7 @@ extern "C" {
 #define CLC_ERR_NO_DATA (-5)    /* solve/eval before upload                                 */
 #define CLC_ERR_LINALG (-6)     /* 9x9 closed-form solve failed (rank deficient)             */
 #define CLC_ERR_NO_DEVICE (-7)  /* no gfx950 device / HIP runtime unavailable                */
+#define CLC_ERR_COMM (-8)       /* RCCL unavailable or a collective failed: see clc_last_error() */
 
 /* termination codes of clc_summary.termination (ceres::TerminationType + which test) */
 #define CLC_RUNNING 0
@@ -125,7 +126,10 @@ void clc_options_default(clc_options* opt);
 int clc_create(clc_handle** out, int device);
 void clc_destroy(clc_handle* h);
 /* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the handle's own stream. */
+ * NULL restores the handle's own stream.  The switch drains the previous stream first (a finished
+ * solve may still have a few no-op launches queued on it), so work on the new stream never overlaps
+ * work of this handle on the old one.  Device pointers handed to this library (clc_upload_device,
+ * the *_device entry points) must be ready on the handle's CURRENT stream. */
 int clc_set_stream(clc_handle* h, void* hip_stream);
 /* Tuning of the evaluation launch: grid_blocks = number of 256-thread workgroups (0 = library
  * default); flags: 1 = reference shuffle reduction instead of the butterfly, 2 = software
@@ -232,6 +236,46 @@ int clc_line_fit_batched(clc_handle* h, const clc_options* opt, const double* xy
 int clc_scan_to_points(clc_handle* h, const float* ranges, const int64_t* offsets, size_t n_scans,
                        const float* angle_min, const float* angle_increment, const float* range_min,
                        double* points);
+
+/* ---- multi-GPU: sharded batches + RCCL gather ------------------------------------------------
+ * BASELINE.json configs[3]: independent T_cl problems shard across the GPUs of a node, one process
+ * per GPU, no collective on the data path; the fixed-size result records of all ranks are gathered
+ * once over xGMI.  The reference has no counterpart (single-threaded Ceres, src/LaseCamCalCeres.cpp
+ * :302-304); the record is what its caller keeps of a solve: the pose written back at :311-314 and the
+ * Solver::Summary fields printed at :309.
+ *
+ * RCCL is bound at run time (dlopen): the copy already loaded into the process (e.g. PyTorch's) is
+ * reused, else librccl.so.1; CLC_RCCL_LIBRARY overrides.  Only these entry points need it. */
+typedef struct clc_result_record {
+  double pose[7];         /* [tx,ty,tz,qx,qy,qz,qw] */
+  double final_cost;
+  double initial_cost;
+  double num_iterations;
+  double termination;     /* CLC_CONVERGENCE_* ... as a double */
+  double global_index;    /* global problem index; -1 marks a padding record */
+} clc_result_record;      /* 12 doubles = 96 bytes */
+
+#define CLC_COMM_ID_BYTES 128
+typedef struct clc_comm clc_comm;
+/* ncclGetUniqueId: called by ONE rank; the caller distributes the 128 bytes to the other ranks out of
+ * band (torch.distributed store, MPI, a file). */
+int clc_comm_unique_id(char id[CLC_COMM_ID_BYTES]);
+/* ncclCommInitRank on the handle's device; collectives run on the handle's stream.  Collective call:
+ * every rank of the job must enter it. */
+int clc_comm_create(clc_comm** out, clc_handle* h, const char id[CLC_COMM_ID_BYTES], int rank, int world);
+void clc_comm_destroy(clc_comm* c);
+int clc_comm_rank(const clc_comm* c);
+int clc_comm_world(const clc_comm* c);
+/* ncclAllGather of the result records the LAST clc_solve_batched on the comm's handle left in device
+ * memory.  This rank owns global problem indices [first_global_index, first_global_index + P_local);
+ * every rank contributes exactly cap_per_rank records (P_local <= cap_per_rank, the rest padded with
+ * global_index = -1).  all_records (host, world * cap_per_rank records, rank-major; contiguous shards in
+ * rank order make that the global problem order) is filled on every rank that passes one; NULL skips
+ * the copy — the gathered records then stay readable in the communicator's pinned host buffer,
+ * clc_comm_records(), until the next gather.  Collective call. */
+int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_rank,
+                       clc_result_record* all_records);
+const clc_result_record* clc_comm_records(const clc_comm* c);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = _capi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/clc.h but not exported"
-    assert L.clc_version() == 100
+    assert L.clc_version() == 200
 
 
 def test_struct_layouts_match_header():
@@ -29,6 +29,16 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Options) == 4 * 4 + 10 * 8 + 2 * 4
     assert C.sizeof(_capi.Iteration) == 16 + 6 * 8
     assert C.sizeof(_capi.Summary) == 16 + 8 + 4 * 8 + 8
+
+
+def test_result_record_is_twelve_doubles():
+    hdr = open(os.path.join(ROOT, "include", "clc.h")).read()
+    body = re.search(r"typedef struct clc_result_record \{(.*?)\} clc_result_record;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    n = sum(int(m.group(2) or 1) * len(m.group(1).split(",")) if not m.group(2) else int(m.group(2))
+            for m in re.finditer(r"double\s+([a-z_, ]+?)(?:\[(\d+)\])?;", body))
+    from camlasercalibratool_amd import dist, solver
+    assert n == 12 == dist.RECORD == solver.RESULT_RECORD
 
 
 def test_host_side_flatten_needs_no_gpu_and_matches_oracle(oracle_mod):

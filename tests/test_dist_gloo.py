@@ -35,11 +35,11 @@ def _worker(rank, world, port, P, q):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        probs, gts = sd.sim_batch(5, n_problems=P, n_poses=8, pts_per_pose=40, noise_sigma=0.01)
-        recs = [oracle.flatten(p, False, False) for p in probs]
-        off = np.zeros(P + 1, dtype=np.int64)
-        off[1:] = np.cumsum([r.shape[0] for r in recs])
-        x0 = np.stack([oracle.pose_plus(sd.pose7_from_T(g), np.full(6, 0.05)) for g in gts])
+        loaded = []
+
+        def load_shard(lo, hi):  # every rank generates ONLY its own problems (pure function of the global index)
+            loaded.append((lo, hi))
+            return sd.sim_shard_records(5, lo, hi, 8, 40, 0.01)[:3]
 
         def stub(r, o, p, opt):  # stands in for Solver.solve_batched on this rank's shard
             poses, sms = [], []
@@ -49,7 +49,8 @@ def _worker(rank, world, port, P, q):
                 sms.append(res.summary)
             return np.array(poses), sms
 
-        out = cdist.solve_sharded(np.concatenate(recs), off, x0, None, solve_fn=stub)
+        out = cdist.solve_sharded(load_shard, P, None, solve_fn=stub)
+        assert loaded == [cdist.shard_problems(P, rank, world)]
         if rank == 0:
             q.put(out)
         else:
@@ -83,9 +84,10 @@ def test_sharded_solve_and_gather_world2(P):
     import oracle
     from camlasercalibratool_amd import simdata as sd
 
-    probs, gts = sd.sim_batch(5, n_problems=P, n_poses=8, pts_per_pose=40, noise_sigma=0.01)
+    sh = sd.sim_shard(5, 0, P, 8, 40, 0.01)
+    x0 = sh.start_poses()
     for k in range(P):
-        rec = oracle.flatten(probs[k], False, False)
-        ref = oracle.solve(rec, oracle.pose_plus(sd.pose7_from_T(gts[k]), np.full(6, 0.05)), linear_solver="ne")
+        rec = oracle.flatten(sh.problem(k), False, False)
+        ref = oracle.solve(rec, x0[k], linear_solver="ne")
         assert np.array_equal(full[k, :7], ref.pose)
         assert full[k, 7] == ref.summary.final_cost and full[k, 9] == ref.summary.num_iterations

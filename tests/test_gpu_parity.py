@@ -623,23 +623,98 @@ def test_scan_to_points_matches_oracle(sv, oracle_mod):
 
 
 def test_bench_two_rank_path_dry_run():
-    """bench.py's N>1 code path (per-rank problem, gather of result records, max-over-ranks
-    timing) with 2 ranks oversubscribing the one visible GPU and gloo standing in for RCCL."""
+    """bench.py's N>1 code path (every rank generates and solves only its own shard of the batch, gather of all result
+    records, max-over-ranks timing) with 2 ranks oversubscribing the one visible GPU; gloo stands in for the process
+    group and the records travel through torch.distributed (RCCL refuses two ranks on one GPU)."""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
-           "--backend", "gloo", "--oversubscribe", "--poses", "200", "--pts", "100"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--oversubscribe", "--problems-per-gpu", "96", "--shard-poses", "6", "--shard-pts", "100"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 prints ONE JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    recs = d["gathered_result_records"]
-    assert len(recs) == 2 and [r[11] for r in recs] == [0.0, 1.0]
-    assert recs[0][:7] != recs[1][:7]  # two different problems
-    assert all(abs(sum(x * x for x in r[3:7]) - 1) < 1e-12 for r in recs)
+    c4 = d["batched_c4_shard"]
+    assert c4["problems"] == 192 and c4["problems_per_gpu"] == 96
+    first, last = c4["first_and_last_record"]
+    assert first[11] == 0.0 and last[11] == 191.0 and first[:7] != last[:7]
+    assert all(abs(sum(x * x for x in r[3:7]) - 1) < 1e-12 for r in (first, last))
+    assert c4["max_abs_T_err_vs_ground_truth_sampled"] < 0.05 and c4["T_cl_max_abs_err_vs_oracle_sample"] <= T_TOL
+    assert d["roofline"]["frac"] > 0
+
+
+def test_rccl_world1_sharded_solve_through_the_c_abi(sv, oracle_mod):
+    """RCCL for real on the one GPU: clc_comm_create (ncclCommInitRank, world size 1) + clc_gather_results
+    (ncclAllGather from the device buffer of clc_solve_batched) through dist.solve_sharded / ShardSolver; the gathered
+    records equal what clc_solve_batched returned and the oracle's solves."""
+    from camlasercalibratool_amd import dist as cdist
+
+    P = 37
+    calls = []
+
+    def load_shard(lo, hi):
+        calls.append((lo, hi))
+        return sd.sim_shard_records(11, lo, hi, 6, 64, 0.01)[:3]
+
+    full = cdist.solve_sharded(load_shard, P, device_index=0)
+    assert calls == [(0, P)] and full.shape == (P, 12)
+    assert np.array_equal(full[:, 11], np.arange(P))
+    rec, off, x0, gt = sd.sim_shard_records(11, 0, P, 6, 64, 0.01)
+    for k in range(P):
+        ref = oracle_mod.solve(rec[off[k]:off[k + 1]], x0[k], linear_solver="qr")
+        assert _dT(full[k, :7], ref.pose) <= T_TOL and abs(full[k, 7] - ref.summary.final_cost) <= COST_TOL, k
+        assert full[k, 9] == ref.summary.num_iterations and full[k, 10] == ref.summary.termination, k
+    # persistent form with padding: capacity larger than the shard, raw rank-major buffer
+    with cdist.ShardSolver(P, device_index=0, rank=0, world=1) as ss:
+        assert "rccl" in ss.comm.library
+        ss.upload(rec, off)
+        raw = ss.solve(x0, ordered=False)
+        poses, sms = ss.last_poses, ss.last_summaries
+        assert np.array_equal(raw[:, :7], poses) and np.array_equal(raw, full)
+        big = ss.comm.gather_results(1000, P + 5)  # padding records carry global index -1
+        assert big.shape == (P + 5, 12) and np.array_equal(big[:P, 11], 1000 + np.arange(P))
+        assert np.all(big[P:, 11] == -1) and np.all(big[P:, :11] == 0) and np.array_equal(big[:P, :11], full[:, :11])
+        view = ss.comm.gather_results(0, P, copy=False)  # zero-copy view of the pinned buffer
+        assert np.array_equal(view, full)
+        with pytest.raises(clc.ClcError):
+            ss.comm.gather_results(0, P - 1)  # capacity below the shard size
+
+
+def test_c4_full_size_shard(sv, oracle_mod):
+    """configs[3], one GPU's share at full size: 8 192 independent T_cl problems x 10^4 observations (5.2 GB of
+    records), solved by clc_solve_batched and gathered through RCCL.  Size-independent properties on ALL problems
+    (termination by convergence at a cost no higher than the start, unit quaternions, own ground truth recovered to the
+    noise level, solving twice is bitwise repeatable) + oracle parity (DENSE_QR Ceres restatement) on 64 sampled
+    problems regenerated one by one from (seed, global index)."""
+    from camlasercalibratool_amd import dist as cdist
+
+    P, n_poses, K, seed, lo = 8192, 20, 500, 65536, 3 * 8192  # the shard rank 3 of 8 would own
+    rec, off, x0, gt = sd.sim_shard_records(seed, lo, lo + P, n_poses, K, 0.01)
+    assert rec.shape == (P * n_poses * K, 8)
+    with cdist.ShardSolver(P, device_index=0, rank=0, world=1) as ss:  # one rank standing in for rank 3 of 8
+        ss.upload(rec, off)
+        del rec
+        ss.solver.solve_batched(x0)
+        raw = ss.comm.gather_results(lo, P)
+        ss.solver.solve_batched(x0)
+        raw2 = ss.comm.gather_results(lo, P)
+    assert np.array_equal(raw, raw2)
+    assert np.array_equal(raw[:, 11], lo + np.arange(P))
+    assert np.isin(raw[:, 10], (1, 2, 3)).all()
+    assert np.all(raw[:, 7] <= raw[:, 8])
+    assert np.abs(np.linalg.norm(raw[:, 3:7], axis=1) - 1).max() < 1e-14
+    worst = max(np.abs(sd.T_from_pose7(raw[k, :7]) - gt[k]).max() for k in range(P))
+    assert worst < 0.02, worst
+    for k in range(0, P, 128):  # 64 problems
+        one = sd.sim_shard(seed, lo + k, lo + k + 1, n_poses, K, 0.01)
+        r1, _ = one.records()
+        ref = oracle_mod.solve(r1, x0[k], linear_solver="qr")
+        assert np.array_equal(one.start_poses()[0], x0[k])
+        assert raw[k, 9] == ref.summary.num_iterations and raw[k, 10] == ref.summary.termination, k
+        assert _dT(raw[k, :7], ref.pose) <= T_TOL and abs(raw[k, 7] - ref.summary.final_cost) <= COST_TOL, k
