@@ -60,7 +60,7 @@ bool all_finite(const double* p, int n) {
 
 constexpr int kDefaultLookahead = 2;
 constexpr size_t kInfinityCacheBytes = 256u << 20;  // MI355X memory-side cache (MI355X_MICROARCH.md)
-constexpr int kDefaultLaunchFlags = 2 | 16 | 32 | 128;  // prefetch + compact layout + 512-thread weighted workgroups + step kernel (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py, scripts/step_check.py)
+constexpr int kDefaultLaunchFlags = 2 | 16 | 32 | 128 | 256;  // prefetch + compact layout + 512-thread weighted workgroups + step kernel (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py, scripts/step_check.py)
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
 constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
 
@@ -82,6 +82,13 @@ struct clc_handle {
   size_t groups_cap_bytes = 0;
   long long n_groups = 0;
   bool compact_ok = false;
+  // row layout of the same observations (clc_rows.hpp): xy rows + row descriptors
+  double* d_rxy = nullptr;
+  size_t rxy_cap_bytes = 0;
+  double* d_rdesc = nullptr;
+  size_t rdesc_cap_bytes = 0;
+  long long n_rows = 0;
+  bool rows_ok = false;
   // launch geometry
   int grid_override = 0;
   int launch_flags = kDefaultLaunchFlags;
@@ -107,6 +114,13 @@ struct clc_handle {
   size_t bgroups_cap_bytes = 0;
   long long bn_groups = 0;
   bool bcompact_ok = false;
+  double* d_brxy = nullptr;
+  size_t brxy_cap_bytes = 0;
+  double* d_brdesc = nullptr;
+  size_t brdesc_cap_bytes = 0;
+  long long bn_rows = 0;
+  bool brows_ok = false;
+  long long* d_prob_row = nullptr;  // [P+1] first row of every problem
   long long* d_tile_off = nullptr;
   long long* d_nobs = nullptr;
   // batched poses / summaries live in pinned, device-mapped host memory: the init kernel reads the start poses and the
@@ -180,6 +194,15 @@ int ensure_events(clc_handle* h, size_t n) {
   return CLC_OK;
 }
 
+// Row layout in use for the single-problem array?
+bool use_rows(const clc_handle* h) { return (h->launch_flags & clc::FLAG_ROWS) != 0 && h->rows_ok; }
+bool use_brows(const clc_handle* h) { return (h->launch_flags & clc::FLAG_ROWS) != 0 && h->brows_ok; }
+// Rows streamed from HBM rather than the Infinity Cache (> 1.5x its size) are loaded non-temporally.
+bool rows_nontemporal(const clc_handle* h, long long n_rows) {
+  const size_t bytes = (size_t)n_rows * (clc::ROW_DOUBLES * sizeof(double) + sizeof(clc::RowDesc));
+  return (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 || (h->launch_auto && bytes > kInfinityCacheBytes + kInfinityCacheBytes / 2);
+}
+
 template <bool WITH_LOSS, bool WITH_JAC>
 void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t* d_status, double lf,
                    const clc::Pose7& pose_arg, int use_pose_arg) {
@@ -191,6 +214,22 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
   const bool pf = (fl & clc::FLAG_PREFETCH) != 0, nt = (fl & clc::FLAG_NONTEMPORAL) != 0;
   const bool cp = (fl & clc::FLAG_COMPACT) != 0 && h->compact_ok;
   const bool big = (fl & clc::FLAG_WG512) != 0;
+  if (use_rows(h)) {  // row layout: the Jacobian comes with the moments, a cost-only pass would save nothing
+    const bool rnt = rows_nontemporal(h, h->n_rows);
+    const bool eq = (fl & clc::FLAG_EQUAL_WAVES) != 0;
+#define CLC_LAUNCH_R(NT, BT, WG)                                                                              \
+  hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, NT, BT, WG>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy, \
+                     reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl,       \
+                     h->d_partials, pose_arg, use_pose_arg)
+    if (big) {
+      if (eq) { if (rnt) CLC_LAUNCH_R(true, 512, false); else CLC_LAUNCH_R(false, 512, false); }
+      else { if (rnt) CLC_LAUNCH_R(true, 512, true); else CLC_LAUNCH_R(false, 512, true); }
+    } else {
+      if (rnt) CLC_LAUNCH_R(true, 256, true); else CLC_LAUNCH_R(false, 256, true);
+    }
+#undef CLC_LAUNCH_R
+    return;
+  }
   // Compact layout: the deep pipeline (two tiles of points in flight per wave) pays only when the array streams
   // from HBM, i.e. no longer fits the 256 MiB Infinity Cache (scripts/size_sweep.py: +10 % at 9e8 B, -8 % at 1e8 B).
   // Well beyond the cache (> 1.5x) the streamed tiles are also loaded non-temporally (+5-8 % at 4.5e8-9e8 B; plain
@@ -244,10 +283,13 @@ int retile_into(clc_handle* h, const double* d_aos, size_t n, double** d_tiles, 
   return CLC_OK;
 }
 
-// Lossless compression of staged AoS records into the compact layout (clc_kernels.hpp): runs of
-// records with bit-identical (n, d, scale) become one group-table entry.  rec_off/tile_off
-// describe P problems (P = 1 for the single-problem array).  *ok = false (and nothing kept) when
-// the records do not compress at least 4:1 in groups, e.g. hand-made arrays without scan structure.
+// Upload-time re-encoding of staged AoS records, entirely on the device (O(1) host work, a few words copied back):
+//   * scans = runs of records with bit-identical (n, d, scale) (and never across two problems): flags, prefix sum ->
+//     scan index per record, scan starts;
+//   * compact layout (clc_kernels.hpp "Compact layout"): group table + 28-byte tiles, bitwise lossless;
+//   * row layout (clc_rows.hpp): every scan padded to whole rows of 64 points, (x, y) rows + one descriptor per row —
+//     only when every record has p.z == 0 and the padding at most doubles the array.
+// Nothing is kept when the records do not group at least 4:1 (hand-made arrays without scan structure).
 int ensure_bytes(double** p, size_t* cap, size_t bytes) {
   if (bytes <= *cap && *p) return CLC_OK;
   if (*p) CLC_HIP(hipFree(*p));
@@ -257,69 +299,125 @@ int ensure_bytes(double** p, size_t* cap, size_t bytes) {
   return CLC_OK;
 }
 
-int compress_records(clc_handle* h, const double* d_aos, size_t n_total, const std::vector<long long>& rec_off,
-                     const std::vector<long long>& tile_off, double** d_ct, size_t* ct_cap, double** d_gr,
-                     size_t* gr_cap, long long* n_groups_out, bool* ok) {
-  *ok = false;
-  *n_groups_out = 0;
-  const size_t P = rec_off.size() - 1;
-  if (n_total == 0 || P == 0) return CLC_OK;
-  DevBuf<unsigned char> bflag;
-  CLC_HIP(bflag.alloc(n_total));
-  unsigned char* d_flag = bflag.p;
-  const int threads = 256;
-  hipLaunchKernelGGL(clc::group_flag_kernel, dim3((unsigned)((n_total + threads - 1) / threads)), dim3(threads), 0,
-                     h->stream, d_aos, (long long)n_total, d_flag);
-  std::vector<unsigned char> flag(n_total);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(flag.data(), d_flag, n_total, hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  if (e != hipSuccess) return fail(CLC_ERR_HIP, "compress_records: flags", e);
-  for (size_t k = 0; k < P; ++k)
-    if ((size_t)rec_off[k] < n_total) flag[(size_t)rec_off[k]] = 1;  // a problem never shares a group
-  std::vector<unsigned int> gid(n_total);
-  std::vector<long long> starts;
-  starts.reserve(n_total / 64 + 16);
-  for (size_t i = 0; i < n_total; ++i) {
-    if (flag[i]) starts.push_back((long long)i);
-    gid[i] = (unsigned int)(starts.size() - 1);
-  }
-  const size_t G = starts.size();
-  if (G * 4 > n_total || G > 0xFFFFFFF0ull) return CLC_OK;  // not worth it / does not fit u32
-  const size_t total_tiles = (size_t)tile_off[P];
-  int rc = ensure_bytes(d_ct, ct_cap, std::max<size_t>(total_tiles, 1) * clc::CTILE_DOUBLES * sizeof(double));
-  if (rc != CLC_OK) return rc;
-  rc = ensure_bytes(d_gr, gr_cap, G * clc::GROUP_DOUBLES * sizeof(double));
-  if (rc != CLC_OK) return rc;
-  DevBuf<unsigned int> bgid;
-  DevBuf<long long> bstarts, broff, btoff;
-  CLC_HIP(bgid.alloc(n_total));
-  CLC_HIP(bstarts.alloc(G));
-  CLC_HIP(broff.alloc(P + 1));
-  CLC_HIP(btoff.alloc(P + 1));
-  unsigned int* d_gid = bgid.p;
-  long long *d_starts = bstarts.p, *d_roff = broff.p, *d_toff = btoff.p;
-  e = hipMemcpy(d_gid, gid.data(), n_total * sizeof(unsigned int), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_starts, starts.data(), G * sizeof(long long), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_roff, rec_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_toff, tile_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(clc::build_groups_kernel, dim3((unsigned)((G + threads - 1) / threads)), dim3(threads), 0,
-                       h->stream, d_aos, d_starts, (long long)G, *d_gr);
-    long long max_padded = 0;
-    for (size_t k = 0; k < P; ++k) max_padded = std::max(max_padded, (tile_off[k + 1] - tile_off[k]) * clc::TILE);
-    const unsigned ydim = (unsigned)std::min<long long>(4096, std::max<long long>(1, (max_padded + threads - 1) / threads));
-    hipLaunchKernelGGL(clc::build_ctiles_kernel, dim3((unsigned)P, ydim), dim3(threads), 0, h->stream, d_aos, d_gid,
-                       d_roff, d_toff, *d_ct);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  }
-  if (e != hipSuccess) return fail(CLC_ERR_HIP, "compress_records: build", e);
-  *n_groups_out = (long long)G;
-  *ok = true;
+template <class TIn>
+int device_scan(clc_handle* h, const TIn* d_in, long long n, unsigned int minus_one, unsigned int* d_out,
+                unsigned long long* d_totals /* [blocks + 1] */) {
+  const long long blocks = (n + clc::SCAN_CHUNK - 1) / clc::SCAN_CHUNK;
+  hipLaunchKernelGGL((clc::scan_block_totals_kernel<TIn>), dim3((unsigned)blocks), dim3(clc::SCAN_THREADS), 0, h->stream,
+                     d_in, n, d_totals);
+  hipLaunchKernelGGL(clc::scan_totals_kernel, dim3(1), dim3(clc::SCAN_THREADS), 0, h->stream, d_totals, blocks);
+  hipLaunchKernelGGL((clc::scan_apply_kernel<TIn>), dim3((unsigned)blocks), dim3(clc::SCAN_THREADS), 0, h->stream, d_in, n,
+                     d_totals, minus_one, d_out);
+  CLC_HIP(hipGetLastError());
   return CLC_OK;
 }
 
+struct LayoutTargets {
+  double** d_ct; size_t* ct_cap; double** d_gr; size_t* gr_cap; long long* n_groups; bool* compact_ok;
+  double** d_rxy; size_t* rxy_cap; double** d_rdesc; size_t* rdesc_cap; long long* n_rows; bool* rows_ok;
+  long long** d_prob_row;  // nullptr for the single-problem array
+};
+
+int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std::vector<long long>& rec_off,
+                  const std::vector<long long>& tile_off, const LayoutTargets& T) {
+  *T.compact_ok = false;
+  *T.rows_ok = false;
+  *T.n_groups = 0;
+  *T.n_rows = 0;
+  const size_t P = rec_off.size() - 1;
+  if (n_total == 0 || P == 0) return CLC_OK;
+  if (n_total >= 0xFFFFFFF0ull) return CLC_OK;  // scan indices are 32-bit; such arrays keep the 64-byte tiles
+  const long long n = (long long)n_total;
+  const int threads = 256;
+  const long long scan_blocks = (n + clc::SCAN_CHUNK - 1) / clc::SCAN_CHUNK;
+  DevBuf<unsigned char> bflag;
+  DevBuf<unsigned int> bgid, bzflag;
+  DevBuf<unsigned long long> btotals;
+  DevBuf<long long> broff, btoff;
+  CLC_HIP(bflag.alloc(n_total));
+  CLC_HIP(bgid.alloc(n_total));
+  CLC_HIP(bzflag.alloc(1));
+  CLC_HIP(btotals.alloc((size_t)scan_blocks + 1));
+  CLC_HIP(broff.alloc(P + 1));
+  CLC_HIP(btoff.alloc(P + 1));
+  CLC_HIP(hipMemcpyAsync(broff.p, rec_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemcpyAsync(btoff.p, tile_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemsetAsync(bzflag.p, 0, sizeof(unsigned int), h->stream));
+  hipLaunchKernelGGL(clc::scan_flag_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, h->stream, d_aos,
+                     n, bflag.p, bzflag.p);
+  hipLaunchKernelGGL(clc::mark_problem_starts_kernel, dim3((unsigned)((P + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, broff.p, (long long)P, n, bflag.p);
+  CLC_HIP(hipGetLastError());
+  int rc = device_scan<unsigned char>(h, bflag.p, n, 1u, bgid.p, btotals.p);
+  if (rc != CLC_OK) return rc;
+  unsigned int last_gid = 0, any_z = 0;
+  CLC_HIP(hipMemcpyAsync(&last_gid, bgid.p + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipMemcpyAsync(&any_z, bzflag.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  const size_t G = (size_t)last_gid + 1;
+  if (G * 4 > n_total) return CLC_OK;  // does not group: not worth it
+  DevBuf<long long> bstarts;
+  CLC_HIP(bstarts.alloc(G + 1));
+  hipLaunchKernelGGL(clc::scan_starts_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                     bflag.p, bgid.p, n, (long long)G, bstarts.p);
+  CLC_HIP(hipGetLastError());
+  // ---- compact layout ----
+  const size_t total_tiles = (size_t)tile_off[P];
+  rc = ensure_bytes(T.d_ct, T.ct_cap, std::max<size_t>(total_tiles, 1) * clc::CTILE_DOUBLES * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  rc = ensure_bytes(T.d_gr, T.gr_cap, G * clc::GROUP_DOUBLES * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  hipLaunchKernelGGL(clc::build_groups_dev_kernel, dim3((unsigned)((G + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                     d_aos, bstarts.p, (long long)G, *T.d_gr);
+  {
+    long long max_padded = 0;
+    for (size_t k = 0; k < P; ++k) max_padded = std::max(max_padded, (tile_off[k + 1] - tile_off[k]) * clc::TILE);
+    const unsigned ydim = (unsigned)std::min<long long>(4096, std::max<long long>(1, (max_padded + threads - 1) / threads));
+    hipLaunchKernelGGL(clc::build_ctiles_kernel, dim3((unsigned)P, ydim), dim3(threads), 0, h->stream, d_aos, bgid.p, broff.p,
+                       btoff.p, *T.d_ct);
+  }
+  CLC_HIP(hipGetLastError());
+  // ---- row layout ----
+  bool rows_ok = false;
+  long long R = 0;
+  DevBuf<unsigned int> brows, brbeg;
+  DevBuf<unsigned long long> btot2;
+  if (!any_z) {
+    const long long gblocks = ((long long)G + clc::SCAN_CHUNK - 1) / clc::SCAN_CHUNK;
+    CLC_HIP(brows.alloc(G));
+    CLC_HIP(brbeg.alloc(G + 1));
+    CLC_HIP(btot2.alloc((size_t)gblocks + 1));
+    hipLaunchKernelGGL(clc::scan_rows_kernel, dim3((unsigned)((G + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                       bstarts.p, (long long)G, brows.p);
+    CLC_HIP(hipMemsetAsync(brbeg.p, 0, sizeof(unsigned int), h->stream));
+    rc = device_scan<unsigned int>(h, brows.p, (long long)G, 0u, brbeg.p + 1, btot2.p);
+    if (rc != CLC_OK) return rc;
+    unsigned int total_rows = 0;
+    CLC_HIP(hipMemcpyAsync(&total_rows, brbeg.p + G, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    CLC_HIP(hipStreamSynchronize(h->stream));
+    R = (long long)total_rows;
+    rows_ok = R > 0 && (size_t)R * clc::ROW <= 2 * n_total + 64 * P;  // padding at most doubles the array
+  }
+  if (rows_ok) {
+    rc = ensure_bytes(T.d_rxy, T.rxy_cap, (size_t)R * clc::ROW_DOUBLES * sizeof(double));
+    if (rc != CLC_OK) return rc;
+    rc = ensure_bytes(T.d_rdesc, T.rdesc_cap, (size_t)R * sizeof(clc::RowDesc));
+    if (rc != CLC_OK) return rc;
+    const long long slots = R * clc::ROW;
+    hipLaunchKernelGGL(clc::build_rows_kernel, dim3((unsigned)((slots + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                       d_aos, bstarts.p, brbeg.p, (long long)G, R, *T.d_rxy, reinterpret_cast<clc::RowDesc*>(*T.d_rdesc));
+    if (T.d_prob_row)
+      hipLaunchKernelGGL(clc::problem_rows_kernel, dim3((unsigned)((P + 1 + threads - 1) / threads)), dim3(threads), 0,
+                         h->stream, broff.p, bgid.p, brbeg.p, (long long)P, n, R, *T.d_prob_row);
+    CLC_HIP(hipGetLastError());
+  }
+  CLC_HIP(hipStreamSynchronize(h->stream));  // the temporaries above are freed on return
+  *T.n_groups = (long long)G;
+  *T.compact_ok = true;
+  *T.n_rows = R;
+  *T.rows_ok = rows_ok;
+  return CLC_OK;
+}
 
 // Launch geometry of the batched solver (shared by clc_solve_batched and the timing hook).
 struct BatchedLaunch {
@@ -328,6 +426,7 @@ struct BatchedLaunch {
   int lm_threads = 64;
   unsigned lm_blocks = 0;
   bool compact = false, deep = false, nt = false;
+  bool rows = false, rows_nt = false;
 };
 
 int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunch* bl) {
@@ -355,12 +454,24 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
            (bl->compact && h->launch_auto &&
             h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes + kInfinityCacheBytes / 2);
   bl->deep = (h->launch_flags & clc::FLAG_DEEP) != 0 || bbeyond;
+  bl->rows = use_brows(h);
+  bl->rows_nt = bl->rows && rows_nontemporal(h, h->bn_rows);
   return CLC_OK;
 }
 
 void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl) {
   const size_t n_blocks = bl.n_blocks;
   const int bpp = bl.bpp;
+  if (bl.rows) {
+#define CLC_LAUNCH_BR(LOSS, NT)                                                                                \
+  hipLaunchKernelGGL((clc::batched_rows_eval_kernel<LOSS, NT>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, h->stream, \
+                     h->d_brxy, reinterpret_cast<const clc::RowDesc*>(h->d_brdesc), h->d_prob_row, h->d_states, bpp,     \
+                     opt.loss_scale_factor, h->d_bpartials)
+    if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_BR(true, true); else CLC_LAUNCH_BR(true, false); }
+    else { if (bl.rows_nt) CLC_LAUNCH_BR(false, true); else CLC_LAUNCH_BR(false, false); }
+#undef CLC_LAUNCH_BR
+    return;
+  }
   const bool bcompact = bl.compact, bdeep = bl.deep, bnt = bl.nt;
 #define CLC_LAUNCH_B(LOSS, CP, NT)                                                                          \
   hipLaunchKernelGGL((clc::batched_eval_kernel<LOSS, CP, NT, false>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, \
@@ -450,7 +561,8 @@ void clc_destroy(clc_handle* h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_state, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
-                  h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results};
+                  h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results,
+                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->d_prob_row};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -474,7 +586,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 255)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 1023)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
@@ -509,15 +621,16 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
   if (!h || (n > 0 && !records_dev)) return fail(CLC_ERR_INVALID_ARG, "clc_upload_device: bad argument");
   CLC_HIP(hipSetDevice(h->device));
   h->compact_ok = false;
+  h->rows_ok = false;
   int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
   if (rc != CLC_OK) return rc;
   CLC_HIP(hipStreamSynchronize(h->stream));
   h->n_obs = n;
   const std::vector<long long> rec_off = {0, (long long)n};
   const std::vector<long long> tile_off = {0, (long long)((n + clc::TILE - 1) / clc::TILE)};
-  rc = compress_records(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, &h->d_ctiles,
-                        &h->ctiles_cap_bytes, &h->d_groups, &h->groups_cap_bytes, &h->n_groups, &h->compact_ok);
-  return rc;
+  const LayoutTargets T = {&h->d_ctiles, &h->ctiles_cap_bytes, &h->d_groups, &h->groups_cap_bytes, &h->n_groups, &h->compact_ok,
+                           &h->d_rxy, &h->rxy_cap_bytes, &h->d_rdesc, &h->rdesc_cap_bytes, &h->n_rows, &h->rows_ok, nullptr};
+  return build_layouts(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, T);
 }
 
 int clc_upload(clc_handle* h, const clc_observation* records, size_t n) {
@@ -638,8 +751,11 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
   const int d_trace_cap = want_trace ? h->trace_cap : 0;
   const bool deep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
                     (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
+  const bool rows = use_rows(h);
+  const bool rows_nt = rows && rows_nontemporal(h, h->n_rows);
+  const bool rows_eq = (h->launch_flags & clc::FLAG_EQUAL_WAVES) != 0;
   clc::LmState* st[2] = {h->d_state, h->d_state_b};
-  double* rows[2] = {h->d_partials, h->d_partials_b};
+  double* rows_buf[2] = {h->d_partials, h->d_partials_b};
   int launched = 0, status = CLC_RUNNING, last_done = 0;
   long long spins = 0;
   auto t_last_progress = std::chrono::steady_clock::now();
@@ -653,18 +769,35 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
       // launch k reads state[(k-1)&1] / rows[(k-1)&1] and writes state[k&1] / rows[k&1]
       const clc::LmState* s_in = st[(k + 1) & 1];
       clc::LmState* s_out = st[k & 1];
-      const double* r_in = rows[(k + 1) & 1];
-      double* r_out = rows[k & 1];
+      const double* r_in = rows_buf[(k + 1) & 1];
+      double* r_out = rows_buf[k & 1];
 #define CLC_LAUNCH_STEP(LOSS, DEEP, MODE)                                                                     \
   hipLaunchKernelGGL((clc::step_kernel<LOSS, DEEP, MODE>), dim3(grid), dim3(512), 0, h->stream, r_in, s_in,      \
                      h->d_ctiles, h->d_groups, (long long)h->n_obs, r_out, s_out, d_trace, h->d_mailbox,         \
                      d_trace_cap, opt, p0)
+#define CLC_LAUNCH_STEP_R(LOSS, NT, MODE, WG)                                                                 \
+  hipLaunchKernelGGL((clc::step_kernel<LOSS, NT, MODE, 1, WG>), dim3(grid), dim3(512), 0, h->stream, r_in, s_in, \
+                     h->d_rxy, h->d_rdesc, h->n_rows, r_out, s_out, d_trace, h->d_mailbox, d_trace_cap, opt, p0)
 #define CLC_LAUNCH_STEP_M(LOSS, DEEP)                                                                         \
   do { if (k == 0) CLC_LAUNCH_STEP(LOSS, DEEP, 0); else if (k == 1) CLC_LAUNCH_STEP(LOSS, DEEP, 1);             \
        else CLC_LAUNCH_STEP(LOSS, DEEP, 2); } while (0)
-      if (opt.use_loss) { if (deep) CLC_LAUNCH_STEP_M(true, true); else CLC_LAUNCH_STEP_M(true, false); }
+#define CLC_LAUNCH_STEP_RM(LOSS, NT, WG)                                                                      \
+  do { if (k == 0) CLC_LAUNCH_STEP_R(LOSS, NT, 0, WG); else if (k == 1) CLC_LAUNCH_STEP_R(LOSS, NT, 1, WG);     \
+       else CLC_LAUNCH_STEP_R(LOSS, NT, 2, WG); } while (0)
+      if (rows) {
+        if (opt.use_loss) {
+          if (rows_eq) { if (rows_nt) CLC_LAUNCH_STEP_RM(true, true, false); else CLC_LAUNCH_STEP_RM(true, false, false); }
+          else { if (rows_nt) CLC_LAUNCH_STEP_RM(true, true, true); else CLC_LAUNCH_STEP_RM(true, false, true); }
+        } else {
+          if (rows_eq) { if (rows_nt) CLC_LAUNCH_STEP_RM(false, true, false); else CLC_LAUNCH_STEP_RM(false, false, false); }
+          else { if (rows_nt) CLC_LAUNCH_STEP_RM(false, true, true); else CLC_LAUNCH_STEP_RM(false, false, true); }
+        }
+      }
+      else if (opt.use_loss) { if (deep) CLC_LAUNCH_STEP_M(true, true); else CLC_LAUNCH_STEP_M(true, false); }
       else { if (deep) CLC_LAUNCH_STEP_M(false, true); else CLC_LAUNCH_STEP_M(false, false); }
 #undef CLC_LAUNCH_STEP_M
+#undef CLC_LAUNCH_STEP_RM
+#undef CLC_LAUNCH_STEP_R
 #undef CLC_LAUNCH_STEP
       if (win_ms && k == win_last) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
       ++launched;
@@ -714,7 +847,7 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
 // consumes pass k-1; choose 2 <= first <= last <= passes - 1 to cover steady-state launches that all streamed.
 extern "C" int clc_time_steps(clc_handle* h, const double pose0[7], int first, int last, double* avg_ms, int* passes) {
   if (!h || !pose0 || !avg_ms || first < 0 || last < first) return fail(CLC_ERR_INVALID_ARG, "clc_time_steps: bad argument");
-  if (!h->d_tiles || !h->compact_ok) return fail(CLC_ERR_NO_DATA, "clc_time_steps: no (compact) observations uploaded");
+  if (!h->d_tiles || !(h->compact_ok || h->rows_ok)) return fail(CLC_ERR_NO_DATA, "clc_time_steps: no (compact / row) observations uploaded");
   CLC_HIP(hipSetDevice(h->device));
   int rc = ensure_events(h, 2);
   if (rc != CLC_OK) return rc;
@@ -751,7 +884,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
-  if ((h->launch_flags & clc::FLAG_STEP) != 0 && (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->compact_ok &&
+  if ((h->launch_flags & clc::FLAG_STEP) != 0 && (((h->launch_flags & clc::FLAG_COMPACT) != 0 && h->compact_ok) || use_rows(h)) &&
       (h->launch_flags & clc::FLAG_WG512) != 0 && opt.profile_events != 1)  // 1: HIP events around K1, two-kernel path
     return solve_stepped(h, opt, grid, pose, summary, trace, trace_cap, t0);
   const int max_evals = opt.max_num_iterations + 1;
@@ -771,7 +904,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // Controller in the tail of the evaluation launch (one launch per LM iteration) vs its own launch: fused saves a
   // launch boundary (~1 us per iteration) when the evaluation is short, and loses a little when many workgroups
   // queue for the ticket (scripts/size_sweep.py: 0.178 vs 0.193 ms at 5 500 obs, 0.222 vs 0.213 at 1e5, equal at 1e6).
-  const bool fused = (h->launch_flags & clc::FLAG_FUSED_LM) != 0 || (h->launch_auto && grid < h->num_cus);
+  const bool fused = !use_rows(h) && ((h->launch_flags & clc::FLAG_FUSED_LM) != 0 || (h->launch_auto && grid < h->num_cus));
 
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
@@ -964,13 +1097,13 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
     h->btiles_cap_bytes = bytes;
   }
   if (P > h->problems_cap) {
-    void* olds[] = {h->d_tile_off, h->d_nobs, h->d_states, h->d_results};
+    void* olds[] = {h->d_tile_off, h->d_nobs, h->d_states, h->d_results, h->d_prob_row};
     for (void* p : olds) if (p) CLC_HIP(hipFree(p));
     if (h->h_poses) CLC_HIP(hipHostFree(h->h_poses));
     if (h->h_summaries) CLC_HIP(hipHostFree(h->h_summaries));
     h->h_poses = nullptr; h->h_summaries = nullptr;
     h->d_tile_off = nullptr; h->d_nobs = nullptr; h->d_poses = nullptr; h->d_summaries = nullptr;
-    h->d_states = nullptr; h->d_results = nullptr; h->results_valid = 0;
+    h->d_states = nullptr; h->d_results = nullptr; h->results_valid = 0; h->d_prob_row = nullptr;
     h->problems_cap = 0;
     CLC_HIP(hipMalloc(&h->d_tile_off, sizeof(long long) * (P + 1)));
     CLC_HIP(hipMalloc(&h->d_nobs, sizeof(long long) * P));
@@ -980,6 +1113,7 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
     CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_summaries), h->h_summaries, 0));
     CLC_HIP(hipMalloc(&h->d_states, sizeof(clc::LmState) * P));
     CLC_HIP(hipMalloc(&h->d_results, sizeof(clc_result_record) * P));
+    CLC_HIP(hipMalloc(&h->d_prob_row, sizeof(long long) * (P + 1)));
     h->problems_cap = P;
   }
   if (P == 0) { h->n_problems = 0; return CLC_OK; }
@@ -1005,10 +1139,14 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   int crc = CLC_OK;
   h->bcompact_ok = false;
+  h->brows_ok = false;
   h->results_valid = 0;
-  if (e == hipSuccess && d_aos)
-    crc = compress_records(h, d_aos, n_total, rel, tile_off, &h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups,
-                           &h->bgroups_cap_bytes, &h->bn_groups, &h->bcompact_ok);
+  if (e == hipSuccess && d_aos) {
+    const LayoutTargets T = {&h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups, &h->bgroups_cap_bytes, &h->bn_groups,
+                             &h->bcompact_ok, &h->d_brxy, &h->brxy_cap_bytes, &h->d_brdesc, &h->brdesc_cap_bytes, &h->bn_rows,
+                             &h->brows_ok, &h->d_prob_row};
+    crc = build_layouts(h, d_aos, n_total, rel, tile_off, T);
+  }
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
   if (crc != CLC_OK) return crc;
   h->n_problems = P;
@@ -1414,6 +1552,16 @@ int clc_debug_eval_timeline(clc_handle* h, const double pose[7], double lf, long
 }
 
 // Layout report: compact[0/1] + group counts for the single-problem array and the batch.
+// Row-layout report: rows[0/1] + row counts for the single-problem array and the batch.
+int clc_debug_rows(clc_handle* h, int* rows, long long* n_rows, int* brows, long long* bn_rows) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_rows: NULL handle");
+  if (rows) *rows = h->rows_ok ? 1 : 0;
+  if (n_rows) *n_rows = h->n_rows;
+  if (brows) *brows = h->brows_ok ? 1 : 0;
+  if (bn_rows) *bn_rows = h->bn_rows;
+  return CLC_OK;
+}
+
 int clc_debug_layout(clc_handle* h, int* compact, long long* n_groups, int* bcompact, long long* bn_groups) {
   if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_layout: NULL handle");
   if (compact) *compact = h->compact_ok ? 1 : 0;

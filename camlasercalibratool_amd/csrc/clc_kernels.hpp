@@ -31,6 +31,7 @@
 
 #include "clc_lm.hpp"
 #include "clc_math.hpp"
+#include "clc_rows.hpp"
 
 namespace clc {
 
@@ -320,7 +321,9 @@ constexpr int FLAG_NONTEMPORAL = 4;     // nt loads for the streamed tiles
 constexpr int FLAG_FUSED_LM = 8;        // clc_solve: controller in the tail of the evaluation launch
 constexpr int FLAG_DEEP = 64;            // compact layout: two tiles of points in flight per wave (HBM-resident arrays)
 constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 3:2 old/young wave tile weighting
-constexpr int FLAG_STEP = 128;          // clc_solve: one step_kernel launch per LM iteration (compact layout)
+constexpr int FLAG_STEP = 128;          // clc_solve: one step_kernel launch per LM iteration (compact or row layout)
+constexpr int FLAG_ROWS = 256;          // row layout (clc_rows.hpp): 16 B/observation + 64 B/row, per-scan moments
+constexpr int FLAG_EQUAL_WAVES = 512;   // row layout, 512-thread workgroups: equal shares per wave instead of the 3:2 old/young weighting
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -356,12 +359,12 @@ struct WaveMap {
 
 constexpr int W_OLD = 3, W_YOUNG = 2;
 
-template <int BT>
+template <int BT, bool WEIGHTED = true>
 __device__ __forceinline__ WaveMap make_wave_map(int block, int n_blocks, int wave) {
   WaveMap m;
   m.block = (unsigned int)block;
   m.n_blocks = (unsigned int)n_blocks;
-  if (BT == 512) {
+  if (BT == 512 && WEIGHTED) {
     m.cwt = 4 * W_OLD + 4 * W_YOUNG;
     m.cw0 = wave < 4 ? wave * W_OLD : 4 * W_OLD + (wave - 4) * W_YOUNG;
     m.cw1 = m.cw0 + (wave < 4 ? W_OLD : W_YOUNG);
@@ -701,6 +704,266 @@ __global__ void build_ctiles_kernel(const double* __restrict__ aos, const unsign
     base[2 * TILE + j] = z;
     reinterpret_cast<unsigned int*>(base + 3 * TILE)[j] = g;
   }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Row layout (clc_rows.hpp; SURVEY.md §8f row 3 taken to its end).  At upload the records are grouped into scans
+// (runs of bit-identical (n, d, scale)), every scan is padded to whole ROWS of 64 points, and the device keeps
+//   * xy[row][64] (x, y) interleaved — 1 KiB per row, one coalesced 16-byte load per lane — and
+//   * desc[row] (64 B, wave-uniform: scalar loads): the scan's plane and scale, the valid count of the row, and
+//     whether the row starts a scan,
+// i.e. 17 B of traffic per observation for scans that fill their rows (28 B in the compact layout, 64 B algorithmic).
+// Needs p.z == 0 for every record (always true for the reference's scan points); otherwise the upload keeps the
+// compact / 64-byte layouts only.  A wave owns a contiguous run of rows, keeps DEPTH row loads in flight, accumulates
+// per-scan moments (one point per lane per row, ~26 FP64 instructions) and expands them into the 28 accumulators
+// when the scan changes (rows_flush).  Same lane->row map for every launch: bitwise reproducible.
+// ---------------------------------------------------------------------------------------
+constexpr int ROWS_DEPTH = 8;
+
+template <bool NT>
+__device__ __forceinline__ v2d load_row(const double* __restrict__ xy, long long row, int lane) {
+  const v2d* p = reinterpret_cast<const v2d*>(xy + row * ROW_DOUBLES) + lane;
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+__device__ __forceinline__ long long uniform_ll(long long v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFLL));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+template <bool WITH_LOSS, bool NT, class PoseFn>
+__device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, const RowDesc* __restrict__ desc_all,
+                                            long long r_begin_in, long long r_end_in, const int lane, PoseFn get_pose,
+                                            const double inv_lf2, double (&acc)[NACC]) {
+  // wave-uniform run [r_begin, r_end): scalar descriptor loads, loop control on the scalar unit (32-bit row index
+  // relative to the run's first row — 64-bit compares would go through the vector unit)
+  const long long r_begin = uniform_ll(r_begin_in);
+  const int n = __builtin_amdgcn_readfirstlane((int)(r_end_in - r_begin_in));
+  const double* __restrict__ xy = xy_all + r_begin * ROW_DOUBLES;
+  const RowDesc* __restrict__ desc = desc_all + r_begin;
+  v2d buf[ROWS_DEPTH];
+#pragma unroll
+  for (int u = 0; u < ROWS_DEPTH; ++u)
+    if (u < n) buf[u] = load_row<NT>(xy, u, lane);
+  RowDesc dn;
+  if (n > 0) dn = desc[0];
+  PoseU P;
+  if (!get_pose(P)) return false;  // after the prologue loads are in flight (see stream_tiles)
+  RowPlane q;
+  RowMoments M;
+  for (int base = 0; base < n; base += ROWS_DEPTH) {
+#pragma unroll
+    for (int u = 0; u < ROWS_DEPTH; ++u) {
+      const int r = base + u;
+      if (r >= n) break;
+      const RowDesc dc = dn;
+      if (r + 1 < n) dn = desc[r + 1];  // the next row's descriptor is in flight while this row is consumed
+      if (dc.first != 0 || r == 0) {    // wave-uniform: the scan changes (or the wave's run begins inside one)
+        if (r != 0) rows_flush<WITH_LOSS>(q, M, acc);
+        rows_plane_setup(P.R, P.t, dc.nx, dc.ny, dc.nz, dc.d, dc.s, q);
+        rows_moments_reset<WITH_LOSS>(M);
+      }
+      const v2d v = buf[u];
+      if (r + ROWS_DEPTH < n) buf[u] = load_row<NT>(xy, r + ROWS_DEPTH, lane);
+      if (lane < dc.count) rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M);
+    }
+  }
+  if (n > 0) rows_flush<WITH_LOSS>(q, M, acc);
+  return true;
+}
+
+// ---- upload-time kernels of the row layout (all O(N) work on the device) -------------------------------------
+// Inclusive prefix sum of small unsigned values (flags, rows per scan), three passes: per-block totals, a one-block
+// scan of the totals, per-block scan + offset.  out[i] = sum(in[0..i]) - minus_one.
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;
+
+template <class TIn>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_totals_kernel(const TIn* __restrict__ in, long long n,
+                                                                        unsigned long long* __restrict__ totals) {
+  __shared__ unsigned long long sh[SCAN_THREADS];
+  const long long base = (long long)blockIdx.x * SCAN_CHUNK + (long long)threadIdx.x * SCAN_ITEMS;
+  unsigned long long s = 0;
+  for (int j = 0; j < SCAN_ITEMS; ++j)
+    if (base + j < n) s += (unsigned long long)in[base + j];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = SCAN_THREADS / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = sh[0];
+}
+
+// exclusive scan of the block totals in place, one workgroup; totals[n_blocks] receives the grand total
+__global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(unsigned long long* __restrict__ totals, long long n_blocks) {
+  __shared__ unsigned long long sh[SCAN_THREADS];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (long long base = 0; base < n_blocks; base += SCAN_THREADS) {
+    const long long i = base + threadIdx.x;
+    const unsigned long long v = i < n_blocks ? totals[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+      const unsigned long long a = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < n_blocks) totals[i] = carry + sh[threadIdx.x] - v;  // exclusive
+    __syncthreads();
+    if (threadIdx.x == SCAN_THREADS - 1) carry += sh[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[n_blocks] = carry;
+}
+
+template <class TIn>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const TIn* __restrict__ in, long long n,
+                                                                 const unsigned long long* __restrict__ totals,
+                                                                 unsigned int minus_one, unsigned int* __restrict__ out) {
+  __shared__ unsigned long long sh[SCAN_THREADS];
+  const long long base = (long long)blockIdx.x * SCAN_CHUNK + (long long)threadIdx.x * SCAN_ITEMS;
+  unsigned int v[SCAN_ITEMS];
+  unsigned long long s = 0;
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    v[j] = base + j < n ? (unsigned int)in[base + j] : 0u;
+    s += v[j];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+    const unsigned long long a = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += a;
+    __syncthreads();
+  }
+  unsigned long long run = totals[blockIdx.x] + sh[threadIdx.x] - s;  // exclusive prefix of this thread's first item
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    run += v[j];
+    if (base + j < n) out[base + j] = (unsigned int)(run - minus_one);
+  }
+}
+
+// flag[k] = 1 when record k starts a new scan ((n, d, scale) differ bitwise from record k-1); *any_z is set when some
+// record has p.z != 0 (the row layout then does not apply).
+__global__ void scan_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag,
+                                 unsigned int* __restrict__ any_z) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool z = false;
+  if (k < n) {
+    bool nw = (k == 0);
+    const unsigned long long* a = reinterpret_cast<const unsigned long long*>(aos + 8 * k);
+    if (!nw) {
+      const unsigned long long* b = a - 8;
+      nw = (a[0] != b[0]) | (a[1] != b[1]) | (a[2] != b[2]) | (a[3] != b[3]) | (a[7] != b[7]);
+    }
+    flag[k] = nw ? 1 : 0;
+    z = aos[8 * k + 6] != 0.0;
+  }
+  if (__any(z) && (threadIdx.x & 63) == 0) atomicOr(any_z, 1u);
+}
+
+// a problem never shares a scan with its predecessor
+__global__ void mark_problem_starts_kernel(const long long* __restrict__ rec_off, long long n_problems, long long n,
+                                           unsigned char* __restrict__ flag) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_problems && rec_off[p] < n) flag[rec_off[p]] = 1;
+}
+
+// starts[g] = first record of scan g; starts[G] = n; rows[g] = rows the scan occupies (filled by scan_rows_kernel)
+__global__ void scan_starts_kernel(const unsigned char* __restrict__ flag, const unsigned int* __restrict__ gid, long long n,
+                                   long long n_groups, long long* __restrict__ starts) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n && flag[k]) starts[gid[k]] = k;
+  if (k == 0) starts[n_groups] = n;
+}
+
+__global__ void scan_rows_kernel(const long long* __restrict__ starts, long long n_groups, unsigned int* __restrict__ rows) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_groups) rows[g] = (unsigned int)((starts[g + 1] - starts[g] + ROW - 1) / ROW);
+}
+
+// row_begin[G+1]: exclusive prefix of rows[] (row_begin[0] = 0 written here).  One thread per row SLOT.
+__global__ void build_rows_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
+                                  const unsigned int* __restrict__ row_begin, long long n_groups, long long n_rows,
+                                  double* __restrict__ xy, RowDesc* __restrict__ desc) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long r = t >> 6;
+  const int lane = (int)(t & 63);
+  if (r >= n_rows) return;
+  // scan of row r: the last g with row_begin[g] <= r  (wave-uniform search)
+  long long lo = 0, hi = n_groups;  // invariant: row_begin[lo] <= r < row_begin[hi]
+  while (hi - lo > 1) {
+    const long long mid = (lo + hi) >> 1;
+    if ((long long)row_begin[mid] <= r) lo = mid; else hi = mid;
+  }
+  const long long g = lo;
+  const long long first = starts[g] + (r - (long long)row_begin[g]) * ROW;
+  const long long end = starts[g + 1];
+  const long long k = first + lane;
+  double x = 0.0, y = 0.0;
+  if (k < end) { x = aos[8 * k + 4]; y = aos[8 * k + 5]; }
+  v2d v; v[0] = x; v[1] = y;
+  reinterpret_cast<v2d*>(xy + r * ROW_DOUBLES)[lane] = v;
+  if (lane == 0) {
+    const double* a = aos + 8 * starts[g];
+    RowDesc d;
+    d.nx = a[0]; d.ny = a[1]; d.nz = a[2]; d.d = a[3]; d.s = a[7];
+    d.count = (int32_t)((end - first) < ROW ? (end - first) : ROW);
+    d.first = (r == (long long)row_begin[g]) ? 1 : 0;
+    d.pad_[0] = 0.0; d.pad_[1] = 0.0;
+    desc[r] = d;
+  }
+}
+
+// prob_row[p] = first row of problem p (problems start scans); prob_row[P] = n_rows
+__global__ void problem_rows_kernel(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
+                                    const unsigned int* __restrict__ row_begin, long long n_problems, long long n,
+                                    long long n_rows, long long* __restrict__ prob_row) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_problems) return;
+  prob_row[p] = (p < n_problems && rec_off[p] < n) ? (long long)row_begin[gid[rec_off[p]]] : n_rows;
+}
+
+// groups[g] of the compact layout, from the device-resident starts
+__global__ void build_groups_dev_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
+                                        long long n_groups, double* __restrict__ groups) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const double* r = aos + 8 * starts[g];
+  double* o = groups + g * GROUP_DOUBLES;
+  o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[7]; o[5] = 0.0;
+}
+
+// K1 on the row layout: same contract as eval_kernel (one 28-double partial per workgroup).
+template <bool WITH_LOSS, bool NT, int BT, bool WEIGHTED>
+__global__ __launch_bounds__(BT) void eval_rows_kernel(const double* __restrict__ xy, const RowDesc* __restrict__ desc,
+                                                       const long long n_rows, const double* __restrict__ pose,
+                                                       const int32_t* __restrict__ status, const double lf,
+                                                       const int reduce_mode, double* __restrict__ partials,
+                                                       const Pose7 pose_arg, const int use_pose_arg) {
+  auto get_pose = [&](PoseU& P) -> bool {
+    if (use_pose_arg) {
+      load_pose(pose_arg.v, P);
+      return true;
+    }
+    const int32_t st = status != nullptr ? *status : (int32_t)CLC_RUNNING;
+    load_pose(pose, P);
+    return st == CLC_RUNNING;
+  };
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const WaveMap wm = make_wave_map<BT, WEIGHTED>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
+  if (!stream_rows<WITH_LOSS, NT>(xy, desc, wm.begin(n_rows), wm.end(n_rows), lane, get_pose, inv_lf2, acc)) return;
+  block_reduce_store<BT / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 
 template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT, bool COMPACT, int BT>
@@ -1080,7 +1343,9 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
 // A launch that finds the solve already terminated (queued ahead by the host) copies the state forward, so that
 // the launch queued behind it sees the termination too, and exits without touching the host mailbox.
 // ---------------------------------------------------------------------------------------
-template <bool WITH_LOSS, bool DEEP, int MODE>
+// LAYOUT 0: compact tiles (ctiles + group table, n = observations); 1: row layout (ctiles = xy rows, groups = row
+// descriptors, n = rows; DEEP selects non-temporal loads, WEIGHTED the 3:2 old/young wave shares).
+template <bool WITH_LOSS, bool DEEP, int MODE, int LAYOUT = 0, bool WEIGHTED = true>
 __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ rows_in,
                                                    const LmState* __restrict__ state_in,
                                                    const double* __restrict__ ctiles,
@@ -1129,9 +1394,12 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
-  const WaveMap wm = make_wave_map<512>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
+  const WaveMap wm = make_wave_map<512, WEIGHTED>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
   bool active;
-  if (DEEP) active = stream_ctiles_deep<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
+  if (LAYOUT == 1)
+    active = stream_rows<WITH_LOSS, DEEP>(ctiles, reinterpret_cast<const RowDesc*>(groups), wm.begin(n), wm.end(n), lane,
+                                          get_pose, inv_lf2, acc);
+  else if (DEEP) active = stream_ctiles_deep<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else active = stream_ctiles<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   if (!active) return;  // the controller terminated the solve: nothing to evaluate
   block_reduce_store<8>(acc, 0, rows_out + (size_t)blockIdx.x * NACC);
@@ -1327,6 +1595,30 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
     active = stream_tiles<WITH_LOSS, true, true, NT>(tiles + tile_off[prob] * TILE_DOUBLES, n_obs[prob], wm, lane,
                                                      get_pose, inv_lf2, acc);
   if (!active) return;  // uniform over the problem's workgroups: it has terminated
+  block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
+}
+
+// K4 on the row layout: problem k owns rows [prob_row[k], prob_row[k+1]).
+template <bool WITH_LOSS, bool NT>
+__global__ __launch_bounds__(BLOCK) void batched_rows_eval_kernel(
+    const double* __restrict__ xy, const RowDesc* __restrict__ desc, const long long* __restrict__ prob_row,
+    const LmState* __restrict__ states, const int blocks_per_problem, const double lf, double* __restrict__ partials) {
+  const int prob = blockIdx.x / blocks_per_problem;
+  const int j = blockIdx.x - prob * blocks_per_problem;
+  const LmState* st = states + prob;
+  auto get_pose = [&](PoseU& P) -> bool {
+    const int32_t s = st->status;
+    load_pose(st->x_eval, P);
+    return s == CLC_RUNNING;
+  };
+  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const long long r0 = prob_row[prob], r1 = prob_row[prob + 1];
+  const WaveMap wm = make_wave_map<BLOCK>(j, blocks_per_problem, threadIdx.x >> 6);
+  if (!stream_rows<WITH_LOSS, NT>(xy, desc, r0 + wm.begin(r1 - r0), r0 + wm.end(r1 - r0), lane, get_pose, inv_lf2, acc)) return;
   block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
 }
 

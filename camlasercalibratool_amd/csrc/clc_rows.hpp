@@ -1,0 +1,192 @@
+// clc_rows.hpp — per-scan moment form of the point-to-plane evaluation ("row layout", the default streaming path).
+//
+// Within one scan every residual block carries the same plane (n, d) and the same scale s
+// (src/LaseCamCalCeres.cpp:231,239-240,245: one plane and one 1/sqrt(count) per Oberserve, one PointInPlaneFactor per
+// point), and every scan point lies in the lidar plane z = 0 (src/utilities.cpp:203; main/calibr_simulation.cpp:79-96).
+// With m = R^T n and c0 = n.t + d (constant over the scan) the quantities of PointInPlaneFactor::Evaluate (:43-66) are
+//     r0 = n.(R p + t) + d = mx x + my y + c0                        (residual before the scale, :47-48)
+//     u  = [n, p x m] = [nx, ny, nz, y mz, -x mz, x my - y mx]        (Jacobian row J = s u, :56-57)
+// i.e. u is LINEAR in (1, x, y).  So instead of 28 rank-1 accumulations per point (21 + 6 + 1), a lane accumulates the
+// weighted moments of its points of the scan,
+//     S0 = sum w,  Sx = sum w x,  Sy = sum w y,  Sxx, Sxy, Syy,  T0 = sum w r0,  Tx = sum w r0 x,  Ty = sum w r0 y,
+// with the Cauchy weight w = rho'(r^2) = 1 / (1 + r0^2 / lf^2) (the scale cancels inside the loss argument, see
+// clc_kernels.hpp), and expands them ONCE per scan segment into the 6x6 normal equation:
+//     H += s^2 A M A^T,   g += s^2 A [T0, Tx, Ty]^T,   u = A [1, x, y]^T.
+// The robust cost 1/2 sum rho = lf^2/2 sum s^2 log(1 + r0^2/lf^2) needs no logarithm per point either: the lane keeps
+// the running PRODUCT of (1 + r0^2/lf^2) as (mantissa, exponent) — one multiply and a frexp per point — and takes one
+// logarithm per segment.
+// Per point: ~26 FP64 instructions instead of ~100; per streamed byte: 16 B (x, y) instead of 28 (x, y, z, group id).
+//
+// Written for device code and for the host-side unit shim (tests/shim/rows_shim.cpp, g++): same source, the device-only
+// intrinsics have plain-C fall-backs.
+#pragma once
+#include "clc_math.hpp"
+
+namespace clc {
+
+constexpr int ROW = 64;          // points per row = lanes per wavefront: one point per lane per row
+constexpr int ROW_DOUBLES = 128; // (x, y) interleaved: lane l reads doubles 2l, 2l+1 with one 16-byte load
+constexpr int NACC_ROWS = 28;    // same accumulator layout as the per-point path: H(21) g(6) cost(1)
+
+// One descriptor per row (64 B, read with scalar loads — it is wave-uniform): the plane and scale of the row's scan
+// (:227-231, :239-240), the number of valid points in the row (the last row of a scan is padded) and whether the row
+// starts a new scan.
+struct RowDesc {
+  double nx, ny, nz, d, s;
+  int32_t count;   // 1..64 valid points (lanes 0..count-1)
+  int32_t first;   // 1: first row of its scan (moments restart here)
+  double pad_[2];
+};
+static_assert(sizeof(RowDesc) == 64, "RowDesc is 64 bytes");
+
+// x = m * 2^e with m in [0.5, 1) for finite x > 0.
+CLC_HD double frexp_pos(double x, int& e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  e = __builtin_amdgcn_frexp_exp(x);
+  return __builtin_amdgcn_frexp_mant(x);
+#else
+  return frexp(x, &e);
+#endif
+}
+
+// 1/x to ~1 ulp for finite x >= 1 (device: v_rcp_f64 seed + two Newton steps).
+CLC_HD double rcp_ge1(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
+// log(m * 2^e) for m in [0.5, 1): fdlibm-style, m -> [sqrt(1/2), sqrt(2)), f = m - 1, s = f/(2+f),
+// log(m) = f - s (f - R(s^2)), 7-term minimax R.  < 1 ulp.
+CLC_HD double log_mant_exp(double m, int e) {
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f * rcp_ge1(2.0 + f);  // 2 + f in [1.7, 2.42)
+  const double z = s * s;
+  const double w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
+// What a lane knows about the scan it is in: m = R^T n restricted to what the point loop needs, and the plane itself
+// for the expansion.
+struct RowPlane {
+  double nx, ny, nz, s2;  // plane normal, scale^2
+  double mx, my, mz, c0;  // m = R^T n, c0 = n.t + d
+};
+
+// R row-major, t: the pose (wave-uniform).
+CLC_HD void rows_plane_setup(const double* R, const double* t, double nx, double ny, double nz, double d, double s,
+                             RowPlane& q) {
+  q.nx = nx; q.ny = ny; q.nz = nz;
+  q.s2 = s * s;
+  q.mx = fma(R[6], nz, fma(R[3], ny, R[0] * nx));
+  q.my = fma(R[7], nz, fma(R[4], ny, R[1] * nx));
+  q.mz = fma(R[8], nz, fma(R[5], ny, R[2] * nx));
+  q.c0 = fma(t[2], nz, fma(t[1], ny, fma(t[0], nx, d)));
+}
+
+struct RowMoments {
+  double S0, Sx, Sy, Sxx, Sxy, Syy, T0, Tx, Ty;
+  double prod;  // WITH_LOSS: mantissa of prod (1 + r0^2/lf^2) in [0.5, 1);  without loss: sum r0^2
+  int expo;     // WITH_LOSS: its binary exponent
+};
+
+template <bool WITH_LOSS>
+CLC_HD void rows_moments_reset(RowMoments& M) {
+  M.S0 = M.Sx = M.Sy = M.Sxx = M.Sxy = M.Syy = M.T0 = M.Tx = M.Ty = 0.0;
+  M.prod = WITH_LOSS ? 0.5 : 0.0;  // 0.5 * 2^1 = 1
+  M.expo = WITH_LOSS ? 1 : 0;
+}
+
+// One scan point (x, y, 0).
+template <bool WITH_LOSS>
+CLC_HD void rows_point(const RowPlane& q, const double inv_lf2, const double x, const double y, RowMoments& M) {
+  const double r0 = fma(q.my, y, fma(q.mx, x, q.c0));
+  double w = 1.0;
+  if (WITH_LOSS) {
+    const double sum = fma(r0 * r0, inv_lf2, 1.0);
+    w = fmax(2.2250738585072014e-308, rcp_ge1(sum));
+    int e;
+    M.prod = frexp_pos(M.prod * sum, e);  // mantissa in [0.5,1) times a finite sum >= 1: cannot overflow
+    M.expo += e;
+  } else {
+    M.prod = fma(r0, r0, M.prod);
+  }
+  const double wx = w * x, wy = w * y, wr = w * r0;
+  M.S0 += w;
+  M.Sx += wx;
+  M.Sy += wy;
+  M.Sxx = fma(wx, x, M.Sxx);
+  M.Sxy = fma(wx, y, M.Sxy);
+  M.Syy = fma(wy, y, M.Syy);
+  M.T0 += wr;
+  M.Tx = fma(wr, x, M.Tx);
+  M.Ty = fma(wr, y, M.Ty);
+}
+
+// Expand a lane's moments of one scan segment into its 28 accumulators
+// (acc[0..20] H upper triangle row-major, acc[21..26] g, acc[27] sum s^2 log(sum) or sum s^2 r0^2; finalize_cost()
+// applies lf^2/2 resp. 1/2 afterwards, as for the per-point path).
+template <bool WITH_LOSS>
+CLC_HD void rows_flush(const RowPlane& q, const RowMoments& M, double* acc) {
+  const double s2 = q.s2;
+  const double S0 = s2 * M.S0, Sx = s2 * M.Sx, Sy = s2 * M.Sy;
+  const double Sxx = s2 * M.Sxx, Sxy = s2 * M.Sxy, Syy = s2 * M.Syy;
+  const double T0 = s2 * M.T0, Tx = s2 * M.Tx, Ty = s2 * M.Ty;
+  const double nx = q.nx, ny = q.ny, nz = q.nz, mx = q.mx, my = q.my, mz = q.mz;
+  // translation block: n n^T S0
+  const double ax = nx * S0, ay = ny * S0, az = nz * S0;
+  acc[0] = fma(ax, nx, acc[0]);
+  acc[1] = fma(ax, ny, acc[1]);
+  acc[2] = fma(ax, nz, acc[2]);
+  acc[6] = fma(ay, ny, acc[6]);
+  acc[7] = fma(ay, nz, acc[7]);
+  acc[11] = fma(az, nz, acc[11]);
+  // cross block: n (sum w u_theta)^T,  sum w u_theta = (mz Sy, -mz Sx, my Sx - mx Sy)
+  const double v3 = mz * Sy, v4 = -(mz * Sx), v5 = fma(my, Sx, -(mx * Sy));
+  acc[3] = fma(nx, v3, acc[3]);
+  acc[4] = fma(nx, v4, acc[4]);
+  acc[5] = fma(nx, v5, acc[5]);
+  acc[8] = fma(ny, v3, acc[8]);
+  acc[9] = fma(ny, v4, acc[9]);
+  acc[10] = fma(ny, v5, acc[10]);
+  acc[12] = fma(nz, v3, acc[12]);
+  acc[13] = fma(nz, v4, acc[13]);
+  acc[14] = fma(nz, v5, acc[14]);
+  // rotation block: sum w u_theta u_theta^T
+  const double mz2 = mz * mz;
+  const double A = fma(my, Sxx, -(mx * Sxy));  // sum w x (x my - y mx)
+  const double B = fma(my, Sxy, -(mx * Syy));  // sum w y (x my - y mx)
+  acc[15] = fma(mz2, Syy, acc[15]);
+  acc[16] = fma(-mz2, Sxy, acc[16]);
+  acc[17] = fma(mz, B, acc[17]);
+  acc[18] = fma(mz2, Sxx, acc[18]);
+  acc[19] = fma(-mz, A, acc[19]);
+  acc[20] = fma(my, A, fma(-mx, B, acc[20]));
+  // gradient: sum w r0 u
+  acc[21] = fma(nx, T0, acc[21]);
+  acc[22] = fma(ny, T0, acc[22]);
+  acc[23] = fma(nz, T0, acc[23]);
+  acc[24] = fma(mz, Ty, acc[24]);
+  acc[25] = fma(-mz, Tx, acc[25]);
+  acc[26] = fma(my, Tx, fma(-mx, Ty, acc[26]));
+  // cost
+  if (WITH_LOSS)
+    acc[27] = fma(s2, log_mant_exp(M.prod, M.expo), acc[27]);
+  else
+    acc[27] = fma(s2, M.prod, acc[27]);
+}
+
+}  // namespace clc

@@ -252,6 +252,12 @@ class Solver:
         check(self._L.clc_debug_wave_reduce(self._h, dptr(lanes), dptr(out), C.c_int(reduce_mode)), "clc_debug_wave_reduce")
         return out
 
+    def debug_rows(self):
+        """Row layout report -> (rows_ok, n_rows, batched_rows_ok, batched_n_rows)."""
+        r, n, br, bn = C.c_int(), C.c_longlong(), C.c_int(), C.c_longlong()
+        check(self._L.clc_debug_rows(self._h, C.byref(r), C.byref(n), C.byref(br), C.byref(bn)), "clc_debug_rows")
+        return bool(r.value), n.value, bool(br.value), bn.value
+
     def time_steps(self, pose: np.ndarray, first: int, last: int) -> Tuple[float, int]:
         """Mean period [ms] of the step_kernel launches first..last of one default solve (HIP events on the handle's
         stream right before launch `first` and right after launch `last`) and the solve's number of passes."""

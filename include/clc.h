@@ -137,9 +137,12 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
  * controller in the tail of the evaluation launch (one launch per iteration), 16 = compact 28-byte
  * layout, 32 = 512-thread workgroups with old/young wave tile weighting, 64 = compact layout with
  * two tiles in flight per wave, 128 = clc_solve issues ONE launch per LM iteration (every workgroup
- * runs the controller on the previous launch's partial rows before it streams; needs 16 and 32);
- * -1 = library default (2|16|32|128, and 64 / 4 chosen per launch when the array exceeds the
- * 256 MiB Infinity Cache).  Results change only in summation order. */
+ * runs the controller on the previous launch's partial rows before it streams; needs 32 and 16 or 256),
+ * 256 = row layout (every scan padded to rows of 64 points, 16-byte (x, y) stream + one 64-byte
+ * descriptor per row, per-scan moment accumulation; used when every record has p.z == 0, else the
+ * flags without it apply), 512 = row layout with equal tile shares per wave;
+ * -1 = library default (2|16|32|128|256; non-temporal loads / the deep pipeline chosen per launch when
+ * the array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 
 /* ---- problem assembly (host) --------------------------------------------------------

@@ -103,7 +103,8 @@ def test_eval_reduction_matches_oracle_ragged_sizes(sv, oracle_mod, n, with_loss
     pose = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)) if n % 2 else X0
     pose = oracle_mod.pose_plus(pose, rng.normal(size=6) * 0.05)
     for flags in (0, 1, 2, 4, 6, 7, 16 | 2, 16 | 6, 16 | 7, 32 | 2, 32 | 6, 32 | 16 | 2, 32 | 16 | 7,
-                  64 | 16, 64 | 32 | 16 | 4):  # reduction x prefetch x nt x compact x 512-thread WGs x deep pipeline
+                  64 | 16, 64 | 32 | 16 | 4,  # reduction x prefetch x nt x compact x 512-thread WGs x deep pipeline
+                  256, 256 | 1, 256 | 4, 256 | 32, 256 | 32 | 4, 256 | 32 | 512):  # row layout x nt x workgroup size x wave shares
         sv.set_launch(0, flags)
         c, g, H = sv.eval(pose, with_loss=with_loss)
         c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
@@ -199,6 +200,68 @@ def test_compact_layout_is_lossless_and_optional(sv, oracle_mod):
     c0, g0, H0 = oracle_mod.evaluate_ne(junk, pose)
     c1, g1, H1 = sv.eval(pose)
     assert abs(c1 - c0) <= 1e-11 * abs(c0) and np.abs(H1 - H0).max() <= 1e-11 * np.abs(H0).max()
+
+
+def test_row_layout_matches_oracle_and_the_per_point_paths(sv, oracle_mod):
+    """The row layout (every scan padded to rows of 64 points, per-scan moments expanded once per scan segment) against
+    the oracle and the per-point layouts: ragged C1 scans (0..180 points: partial rows, empty poses), C5 board-edge terms
+    (single-record scans with un-normalised planes), a truncated array, loss on and off.  Records with p.z != 0 do not
+    qualify and silently keep the per-point layouts."""
+    rng = np.random.default_rng(5)
+    gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    cases = []
+    S1 = sd.GenerateSimData(3, n_poses=50, noise_sigma=0.02)
+    cases.append(clc.flatten_observations(S1, False))
+    S5 = sd.sim_board_edges(5, n_poses=300, pts_per_pose=137, noise_sigma=0.002)
+    cases.append(clc.flatten_observations(S5, True, True))
+    cases.append(clc.flatten_observations(sd.sim_fixed_count(8, 120, 500, 0.01), False)[:57311].copy())
+    for rec in cases:
+        sv.upload(rec)
+        ok, n_rows, _, _ = sv.debug_rows()
+        assert ok and n_rows >= (rec.shape[0] + 63) // 64
+        for pose in (X0, oracle_mod.pose_plus(gt, rng.normal(size=6) * 0.03)):
+            for with_loss in (True, False):
+                c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
+                sv.set_launch(0, 2 | 16 | 32)
+                c2, g2, H2 = sv.eval(pose, with_loss=with_loss)
+                for grid, flags in ((0, -1), (0, 256 | 32 | 512), (5, 256 | 32), (0, 256), (3, 256 | 4)):
+                    sv.set_launch(grid, flags)
+                    c, g, H = sv.eval(pose, with_loss=with_loss)
+                    for (a, b) in ((c, c0), (c, c2)):
+                        assert abs(a - b) <= 1e-11 * abs(b)
+                    for (a, b) in ((H, H0), (H, H2), (g, g0), (g, g2)):
+                        assert np.abs(a - b).max() <= 1e-11 * np.abs(H0).max() if a is H else np.abs(a - b).max() <= 1e-10 * np.abs(g0).max() + 1e-16
+                    assert sv.eval(pose, with_loss=with_loss)[0] == c  # fixed lane -> row map: bitwise repeatable
+        sv.set_launch(0, -1)
+    # z != 0: no row layout, same answers through the compact layout
+    rec = cases[0].copy()
+    rec[::7, 6] = 0.01
+    sv.upload(rec)
+    assert not sv.debug_rows()[0] and _layout(sv)[0] == 1
+    c0, g0, H0 = oracle_mod.evaluate_ne(rec, X0)
+    c, g, H = sv.eval(X0)
+    assert abs(c - c0) <= 1e-11 * abs(c0) and np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
+    res = sv.solve(X0)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    assert _dT(res.pose, ref.pose) <= T_TOL and res.summary.num_iterations == ref.summary.num_iterations
+
+
+@pytest.mark.parametrize("grid", [1, 2, 3, 7])
+@pytest.mark.parametrize("n_poses,pts", [(40, 500), (97, 333), (260, 65)])
+def test_row_layout_long_runs_per_wave(sv, oracle_mod, grid, n_poses, pts):
+    """Few workgroups: every wave walks many rows, so the 8-deep rotation of the row buffers wraps several times and ends
+    at every residue of the unroll, with scan changes at every position of it."""
+    S = sd.sim_fixed_count(17, n_poses, pts, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    pose = oracle_mod.pose_plus(X0, np.random.default_rng(grid).normal(size=6) * 0.05)
+    c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose)
+    for flags in (256, 256 | 32, 256 | 32 | 4, 256 | 32 | 512):
+        sv.set_launch(grid, flags)
+        c, g, H = sv.eval(pose)
+        assert abs(c - c0) <= 1e-11 * abs(c0)
+        assert np.abs(g - g0).max() <= 1e-11 * np.abs(g0).max() and np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
+    sv.set_launch(0, -1)
 
 
 def test_eval_empty_and_errors(sv):
@@ -298,20 +361,22 @@ def test_fused_controller_launch_matches_two_kernel_path(sv, oracle_mod, grid):
     assert first.summary.num_iterations == ref.summary.num_iterations
 
 
+@pytest.mark.parametrize("base", [2 | 16 | 32, 2 | 32 | 256], ids=["compact", "rows"])
 @pytest.mark.parametrize("grid", [0, 1, 7, 256, 300, 1000, 2048])
 @pytest.mark.parametrize("n_poses,noise", [(400, 0.01), (3, 0.03)])
-def test_step_kernel_solve_matches_two_kernel_path(sv, oracle_mod, grid, n_poses, noise):
+def test_step_kernel_solve_matches_two_kernel_path(sv, oracle_mod, grid, n_poses, noise, base):
     """flags bit 128 (the default): one step_kernel launch per LM iteration, every workgroup running the controller
     redundantly on the previous launch's rows.  Same grid => bit-identical to the [eval_kernel, lm_kernel] path,
     including the per-iteration trace, for any number of workgroups (fewer/more than CUs, more than one round of
-    256 rows), repeated back to back (state / row double buffers, launches queued ahead of a finished solve)."""
+    256 rows), repeated back to back (state / row double buffers, launches queued ahead of a finished solve); for the
+    compact and for the row layout."""
     S = sd.sim_fixed_count(77, n_poses, 500, noise_sigma=noise)
     rec = clc.flatten_observations(S, False)
     sv.upload(rec)
     ref = oracle_mod.solve(rec, X0, linear_solver="qr")
-    sv.set_launch(grid, 2 | 16 | 32)
+    sv.set_launch(grid, base)
     two = sv.solve(X0)
-    sv.set_launch(grid, 2 | 16 | 32 | 128)
+    sv.set_launch(grid, base | 128)
     for rep in range(25):
         r = sv.solve(X0)
         assert np.array_equal(r.pose, two.pose) and r.summary.final_cost == two.summary.final_cost, rep
@@ -322,13 +387,13 @@ def test_step_kernel_solve_matches_two_kernel_path(sv, oracle_mod, grid, n_poses
     o = clc.default_options()
     o.max_num_iterations = 3  # stopped by the iteration cap: NO_CONVERGENCE through the same path
     a = sv.solve(X0, o)
-    sv.set_launch(grid, 2 | 16 | 32)
+    sv.set_launch(grid, base)
     b = sv.solve(X0, o)
     sv.set_launch(0, -1)
     assert a.summary.termination == b.summary.termination == 5  # NO_CONVERGENCE and np.array_equal(a.pose, b.pose)
     assert a.summary.num_iterations == b.summary.num_iterations == 3
     o.max_num_iterations = 0  # one evaluation, no step
-    sv.set_launch(grid, 2 | 16 | 32 | 128)
+    sv.set_launch(grid, base | 128)
     z = sv.solve(X0, o)
     sv.set_launch(0, -1)
     assert z.summary.termination == 5 and z.summary.num_iterations == 0 and z.summary.num_evaluations == 1
@@ -360,8 +425,11 @@ def test_randomized_problems_step_vs_pair_vs_oracle(sv, oracle_mod):
         a = sv.solve(x0, o)
         sv.set_launch(0, 2 | 16 | 32)
         b = sv.solve(x0, o)
-        sv.set_launch(0, -1)  # library default: may pick another layout / workgroup size when the scans are too short
-        d = sv.solve(x0, o)   # for the compact layout — equal to the others up to summation order only
+        sv.set_launch(0, -1)  # library default: the row layout (per-scan moments) — equal to the others up to rounding only
+        d = sv.solve(x0, o)
+        sv.set_launch(0, 2 | 32 | 256)  # row layout through the [evaluation, controller] launch pair
+        e = sv.solve(x0, o)
+        assert np.array_equal(d.pose, e.pose) and d.summary.final_cost == e.summary.final_cost, case
         ref = oracle_mod.solve(rec, x0, options=oo, linear_solver="qr")
         assert np.array_equal(a.pose, b.pose) and a.summary.final_cost == b.summary.final_cost, case
         assert a.summary.termination == b.summary.termination == d.summary.termination == ref.summary.termination, case

@@ -1,0 +1,98 @@
+"""The per-scan moment form of the evaluation (camlasercalibratool_amd/csrc/clc_rows.hpp — what the row-layout kernels
+run per lane) compiled for the host and checked against the oracle's per-residual evaluation: the expansion
+H += s^2 A M A^T, the gradient, and the product/exponent form of the Cauchy cost."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from camlasercalibratool_amd import simdata as sd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    src = os.path.join(HERE, "shim", "rows_shim.cpp")
+    out = os.path.join(HERE, "shim", "librows_shim.so")
+    deps = [src] + [os.path.join(HERE, "..", "camlasercalibratool_amd", "csrc", f) for f in ("clc_rows.hpp", "clc_math.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", src, "-o", out])
+    L = C.CDLL(out)
+    L.shim_rows_eval.restype = C.c_long
+    L.shim_log_mant_exp.restype = C.c_double
+    L.shim_log_mant_exp.argtypes = [C.c_double, C.c_int]
+    return L
+
+
+def _rows_eval(shim, rec, pose, with_loss=True, lf=0.05, rows_per_wave=0):
+    out = np.empty(28)
+    rec = np.ascontiguousarray(rec)
+    n_rows = shim.shim_rows_eval(rec.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(rec.shape[0]),
+                                 np.ascontiguousarray(pose).ctypes.data_as(C.POINTER(C.c_double)), C.c_int(int(with_loss)),
+                                 C.c_double(lf), C.c_long(rows_per_wave), out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert n_rows >= 0
+    cost = 0.5 * lf * lf * out[27] if with_loss else 0.5 * out[27]
+    return cost, out[21:27].copy(), out[:21].copy(), n_rows
+
+
+def _rand_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    return np.concatenate([rng.normal(size=3), q])
+
+
+def test_log_from_mantissa_and_exponent(shim):
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        m = rng.uniform(0.5, 1.0)
+        e = int(rng.integers(-5, 900))
+        ref = np.log(m) + e * np.log(2.0)
+        assert abs(shim.shim_log_mant_exp(m, e) - ref) <= 4e-16 * max(1.0, abs(ref))
+    assert shim.shim_log_mant_exp(0.5, 1) == 0.0
+
+
+@pytest.mark.parametrize("with_loss", [True, False])
+@pytest.mark.parametrize("rows_per_wave", [0, 1, 3])
+def test_moment_form_matches_per_residual_evaluation(shim, oracle_mod, with_loss, rows_per_wave):
+    """Ragged scans (0..180 points, C1), poses near and far from the solution."""
+    import oracle
+    rng = np.random.default_rng(3)
+    S = sd.GenerateSimData(5, n_poses=40, noise_sigma=0.02)
+    rec = oracle.flatten(S, False, False)
+    gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    for pose in (gt, sd.pose7_from_T(np.eye(4)), _rand_pose(rng), oracle.pose_plus(gt, rng.normal(size=6) * 0.01)):
+        c, g, H, n_rows = _rows_eval(shim, rec, pose, with_loss, rows_per_wave=rows_per_wave)
+        c0, g0, H0 = oracle.evaluate_ne(rec, pose, with_loss=with_loss)
+        assert abs(c - c0) <= 1e-12 * abs(c0)
+        assert np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
+        assert np.abs(g - g0).max() <= 1e-11 * max(np.abs(g0).max(), 1e-3 * np.sqrt(np.abs(H0).max() * abs(c0)))
+
+
+def test_moment_form_c2_sized_scans_and_board_edge_terms(shim, oracle_mod):
+    """500-point scans (C2/C3 shape) + the two single-record board-edge groups per scan (C5, un-normalised planes)."""
+    import oracle
+    S = sd.sim_board_edges(5, 60, 500, noise_sigma=0.002)
+    rec = oracle.flatten(S, True, True)
+    gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    pose = oracle.pose_plus(gt, np.array([0.05, -0.04, 0.03, 0.05, -0.06, 0.04]))
+    c, g, H, n_rows = _rows_eval(shim, rec, pose)
+    assert n_rows == 60 * (8 + 2)  # 8 rows per 500-point scan, one row per edge record
+    c0, g0, H0 = oracle.evaluate_ne(rec, pose)
+    assert abs(c - c0) <= 1e-12 * abs(c0) and np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
+    assert np.abs(g - g0).max() <= 1e-11 * np.abs(g0).max()
+
+
+def test_moment_form_far_outliers_do_not_overflow_the_cost_product(shim, oracle_mod):
+    """Residuals of 1e6 m (sum = 4e14 per point): the product form keeps mantissa and exponent apart."""
+    import oracle
+    S = sd.sim_fixed_count(9, 12, 500, noise_sigma=0.01)
+    rec = oracle.flatten(S, False, False)
+    pose = sd.pose7_from_T(np.eye(4)).copy()
+    pose[:3] = (1e6, -2e6, 5e5)
+    c, g, H, _ = _rows_eval(shim, rec, pose)
+    c0, g0, H0 = oracle.evaluate_ne(rec, pose)
+    assert np.isfinite(c) and abs(c - c0) <= 1e-12 * abs(c0)
+    assert np.abs(H - H0).max() <= 1e-10 * np.abs(H0).max()
