@@ -396,7 +396,7 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
     CLC_HIP(hipMemcpyAsync(&total_rows, brbeg.p + G, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     CLC_HIP(hipStreamSynchronize(h->stream));
     R = (long long)total_rows;
-    rows_ok = R > 0 && (size_t)R * clc::ROW <= 2 * n_total + 64 * P;  // padding at most doubles the array
+    rows_ok = R > 0 && (size_t)R * clc::ROW <= 3 * n_total + 64 * P;  // rows at least a third full on average
   }
   if (rows_ok) {
     rc = ensure_bytes(T.d_rxy, T.rxy_cap, (size_t)R * clc::ROW_DOUBLES * sizeof(double));

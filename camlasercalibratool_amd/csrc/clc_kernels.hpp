@@ -734,22 +734,38 @@ __device__ __forceinline__ long long uniform_ll(long long v) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+// Descriptor of a row as ONE 8-byte vector load per lane (lane l holds double l & 7 of the 64-byte descriptor), so that it
+// rides the same in-order, DEPTH-deep vmcnt pipeline as the points; the wave-uniform fields are then read with
+// v_readlane.  (Scalar loads of the descriptors, one row ahead, left every wave waiting ~1 us of HBM latency per
+// 128-byte line of descriptors: 4-5 TB/s beyond the Infinity Cache instead of what the row stream allows.)
+__device__ __forceinline__ double load_desc_lane(const RowDesc* __restrict__ desc, int row, int lane) {
+  return reinterpret_cast<const double*>(desc + row)[lane & 7];
+}
+
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 template <bool WITH_LOSS, bool NT, class PoseFn>
 __device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, const RowDesc* __restrict__ desc_all,
                                             long long r_begin_in, long long r_end_in, const int lane, PoseFn get_pose,
                                             const double inv_lf2, double (&acc)[NACC]) {
-  // wave-uniform run [r_begin, r_end): scalar descriptor loads, loop control on the scalar unit (32-bit row index
-  // relative to the run's first row — 64-bit compares would go through the vector unit)
+  // wave-uniform run [r_begin, r_end): loop control on the scalar unit (32-bit row index relative to the run's first
+  // row — 64-bit compares would go through the vector unit)
   const long long r_begin = uniform_ll(r_begin_in);
   const int n = __builtin_amdgcn_readfirstlane((int)(r_end_in - r_begin_in));
   const double* __restrict__ xy = xy_all + r_begin * ROW_DOUBLES;
   const RowDesc* __restrict__ desc = desc_all + r_begin;
   v2d buf[ROWS_DEPTH];
+  double dbuf[ROWS_DEPTH];
 #pragma unroll
   for (int u = 0; u < ROWS_DEPTH; ++u)
-    if (u < n) buf[u] = load_row<NT>(xy, u, lane);
-  RowDesc dn;
-  if (n > 0) dn = desc[0];
+    if (u < n) {
+      dbuf[u] = load_desc_lane(desc, u, lane);
+      buf[u] = load_row<NT>(xy, u, lane);
+    }
   PoseU P;
   if (!get_pose(P)) return false;  // after the prologue loads are in flight (see stream_tiles)
   RowPlane q;
@@ -759,16 +775,21 @@ __device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, c
     for (int u = 0; u < ROWS_DEPTH; ++u) {
       const int r = base + u;
       if (r >= n) break;
-      const RowDesc dc = dn;
-      if (r + 1 < n) dn = desc[r + 1];  // the next row's descriptor is in flight while this row is consumed
-      if (dc.first != 0 || r == 0) {    // wave-uniform: the scan changes (or the wave's run begins inside one)
+      const double dv = dbuf[u];
+      const v2d v = buf[u];
+      if (r + ROWS_DEPTH < n) {
+        dbuf[u] = load_desc_lane(desc, r + ROWS_DEPTH, lane);
+        buf[u] = load_row<NT>(xy, r + ROWS_DEPTH, lane);
+      }
+      const int count = __builtin_amdgcn_readlane(__double2loint(dv), 5);  // RowDesc: double 5 = {count, first}
+      const int first = __builtin_amdgcn_readlane(__double2hiint(dv), 5);
+      if (first != 0 || r == 0) {  // wave-uniform: the scan changes (or the wave's run begins inside one)
         if (r != 0) rows_flush<WITH_LOSS>(q, M, acc);
-        rows_plane_setup(P.R, P.t, dc.nx, dc.ny, dc.nz, dc.d, dc.s, q);
+        rows_plane_setup(P.R, P.t, readlane_d(dv, 0), readlane_d(dv, 1), readlane_d(dv, 2), readlane_d(dv, 3),
+                         readlane_d(dv, 4), q);
         rows_moments_reset<WITH_LOSS>(M);
       }
-      const v2d v = buf[u];
-      if (r + ROWS_DEPTH < n) buf[u] = load_row<NT>(xy, r + ROWS_DEPTH, lane);
-      if (lane < dc.count) rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M);
+      if (lane < count) rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M);
     }
   }
   if (n > 0) rows_flush<WITH_LOSS>(q, M, acc);

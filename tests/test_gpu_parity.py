@@ -218,7 +218,7 @@ def test_row_layout_matches_oracle_and_the_per_point_paths(sv, oracle_mod):
     for rec in cases:
         sv.upload(rec)
         ok, n_rows, _, _ = sv.debug_rows()
-        assert ok and n_rows >= (rec.shape[0] + 63) // 64
+        assert ok and n_rows >= (rec.shape[0] + 63) // 64, (rec.shape, n_rows)
         for pose in (X0, oracle_mod.pose_plus(gt, rng.normal(size=6) * 0.03)):
             for with_loss in (True, False):
                 c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
