@@ -96,7 +96,8 @@ struct clc_handle {
   double* d_partials = nullptr;
   int partials_cap_blocks = 0;
   // LM state
-  clc::LmState* d_state = nullptr;
+  clc::SolveBlock* d_block = nullptr;  // {per-solve constants of the step-kernel chain, LM state x 2}: one allocation
+  clc::LmState* d_state = nullptr;     // = &d_block->st[0]
   clc_iteration* d_trace = nullptr;
   int trace_cap = 0;
   // scratch
@@ -539,8 +540,9 @@ int clc_create(clc_handle** out, int device) {
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CLC_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
-  CLC_HIP(hipMalloc(&h->d_state, 2 * sizeof(clc::LmState)));
-  h->d_state_b = h->d_state + 1;
+  CLC_HIP(hipMalloc(&h->d_block, sizeof(clc::SolveBlock)));
+  h->d_state = &h->d_block->st[0];
+  h->d_state_b = &h->d_block->st[1];
   CLC_HIP(hipMalloc(&h->d_small, sizeof(double) * kSmallDoubles));
   CLC_HIP(hipHostMalloc(&h->h_small, sizeof(double) * kSmallDoubles, hipHostMallocDefault));
   CLC_HIP(hipMalloc(&h->d_queue, sizeof(unsigned int)));
@@ -559,7 +561,7 @@ void clc_destroy(clc_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-  void* ptrs[] = {h->d_tiles, h->d_partials, h->d_state, h->d_trace, h->d_small, h->d_btiles,
+  void* ptrs[] = {h->d_tiles, h->d_partials, h->d_block, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
                   h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results,
                   h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->d_prob_row};
@@ -747,14 +749,18 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
   std::atomic_thread_fence(std::memory_order_seq_cst);
   clc::Pose7 p0;
   for (int i = 0; i < 7; ++i) p0.v[i] = pose[i];
-  clc_iteration* d_trace = want_trace ? h->d_trace : nullptr;
-  const int d_trace_cap = want_trace ? h->trace_cap : 0;
+  clc::SolveParams prm;
+  std::memset(&prm, 0, sizeof(prm));
+  prm.opt = opt;
+  prm.pose0 = p0;
+  prm.trace = want_trace ? h->d_trace : nullptr;
+  prm.mailbox = h->d_mailbox;
+  prm.trace_cap = want_trace ? h->trace_cap : 0;
   const bool deep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
                     (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
   const bool rows = use_rows(h);
   const bool rows_nt = rows && rows_nontemporal(h, h->n_rows);
   const bool rows_eq = (h->launch_flags & clc::FLAG_EQUAL_WAVES) != 0;
-  clc::LmState* st[2] = {h->d_state, h->d_state_b};
   double* rows_buf[2] = {h->d_partials, h->d_partials_b};
   int launched = 0, status = CLC_RUNNING, last_done = 0;
   long long spins = 0;
@@ -767,17 +773,14 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
       const int k = launched;
       if (win_ms && k == win_first) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
       // launch k reads state[(k-1)&1] / rows[(k-1)&1] and writes state[k&1] / rows[k&1]
-      const clc::LmState* s_in = st[(k + 1) & 1];
-      clc::LmState* s_out = st[k & 1];
       const double* r_in = rows_buf[(k + 1) & 1];
       double* r_out = rows_buf[k & 1];
 #define CLC_LAUNCH_STEP(LOSS, DEEP, MODE)                                                                     \
-  hipLaunchKernelGGL((clc::step_kernel<LOSS, DEEP, MODE>), dim3(grid), dim3(512), 0, h->stream, r_in, s_in,      \
-                     h->d_ctiles, h->d_groups, (long long)h->n_obs, r_out, s_out, d_trace, h->d_mailbox,         \
-                     d_trace_cap, opt, p0)
+  hipLaunchKernelGGL((clc::step_kernel<LOSS, DEEP, MODE>), dim3(grid), dim3(512), 0, h->stream, r_in,            \
+                     h->d_ctiles, h->d_groups, (int)h->n_obs, grid | ((k & 1) << 30), r_out, h->d_block, prm)
 #define CLC_LAUNCH_STEP_R(LOSS, NT, MODE, WG)                                                                 \
-  hipLaunchKernelGGL((clc::step_kernel<LOSS, NT, MODE, 1, WG>), dim3(grid), dim3(512), 0, h->stream, r_in, s_in, \
-                     h->d_rxy, h->d_rdesc, h->n_rows, r_out, s_out, d_trace, h->d_mailbox, d_trace_cap, opt, p0)
+  hipLaunchKernelGGL((clc::step_kernel<LOSS, NT, MODE, 1, WG>), dim3(grid), dim3(512), 0, h->stream, r_in,       \
+                     h->d_rxy, h->d_rdesc, (int)h->n_rows, grid | ((k & 1) << 30), r_out, h->d_block, prm)
 #define CLC_LAUNCH_STEP_M(LOSS, DEEP)                                                                         \
   do { if (k == 0) CLC_LAUNCH_STEP(LOSS, DEEP, 0); else if (k == 1) CLC_LAUNCH_STEP(LOSS, DEEP, 1);             \
        else CLC_LAUNCH_STEP(LOSS, DEEP, 2); } while (0)
@@ -885,7 +888,8 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
   if ((h->launch_flags & clc::FLAG_STEP) != 0 && (((h->launch_flags & clc::FLAG_COMPACT) != 0 && h->compact_ok) || use_rows(h)) &&
-      (h->launch_flags & clc::FLAG_WG512) != 0 && opt.profile_events != 1)  // 1: HIP events around K1, two-kernel path
+      (h->launch_flags & clc::FLAG_WG512) != 0 && h->n_obs < 0x7FFFFFFFull &&
+      opt.profile_events != 1)  // 1: HIP events around K1, two-kernel path
     return solve_stepped(h, opt, grid, pose, summary, trace, trace_cap, t0);
   const int max_evals = opt.max_num_iterations + 1;
   const bool want_trace = trace != nullptr && trace_cap > 0;

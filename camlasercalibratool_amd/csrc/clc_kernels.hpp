@@ -414,7 +414,7 @@ __device__ __forceinline__ void accumulate_tile(const PoseU& P, double inv_lf2, 
 template <bool WITH_LOSS, bool WITH_JAC, bool PREFETCH, bool NT, class PoseFn>
 __device__ __forceinline__ bool stream_tiles(const double* __restrict__ tiles, const long long n,
                                              const WaveMap wm, const int lane, PoseFn get_pose,
-                                             const double inv_lf2, double (&acc)[NACC]) {
+                                             const double& inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
   const int rem = (int)(n % TILE);
   const long long T = n_full + (rem != 0 ? 1 : 0);
@@ -526,7 +526,7 @@ template <bool WITH_LOSS, bool WITH_JAC, bool NT, class PoseFn>
 __device__ __forceinline__ bool stream_ctiles(const double* __restrict__ ctiles,
                                               const double* __restrict__ groups, const long long n,
                                               const WaveMap wm, const int lane, PoseFn get_pose,
-                                              const double inv_lf2, double (&acc)[NACC]) {
+                                              const double& inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
   const int rem = (int)(n % TILE);
   const long long T = n_full + (rem != 0 ? 1 : 0);
@@ -608,7 +608,7 @@ template <bool WITH_LOSS, bool WITH_JAC, bool NT, class PoseFn>
 __device__ __forceinline__ bool stream_ctiles_deep(const double* __restrict__ ctiles,
                                                    const double* __restrict__ groups, const long long n,
                                                    const WaveMap wm, const int lane, PoseFn get_pose,
-                                                   const double inv_lf2, double (&acc)[NACC]) {
+                                                   const double& inv_lf2, double (&acc)[NACC]) {
   const long long n_full = n / TILE;
   const int rem = (int)(n % TILE);
   const long long T = n_full + (rem != 0 ? 1 : 0);
@@ -751,7 +751,7 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 template <bool WITH_LOSS, bool NT, class PoseFn>
 __device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, const RowDesc* __restrict__ desc_all,
                                             long long r_begin_in, long long r_end_in, const int lane, PoseFn get_pose,
-                                            const double inv_lf2, double (&acc)[NACC]) {
+                                            const double& inv_lf2, double (&acc)[NACC]) {
   // wave-uniform run [r_begin, r_end): loop control on the scalar unit (32-bit row index relative to the run's first
   // row — 64-bit compares would go through the vector unit)
   const long long r_begin = uniform_ll(r_begin_in);
@@ -1364,37 +1364,69 @@ __global__ __launch_bounds__(BT) void eval_lm_kernel(const double* __restrict__ 
 // A launch that finds the solve already terminated (queued ahead by the host) copies the state forward, so that
 // the launch queued behind it sees the termination too, and exits without touching the host mailbox.
 // ---------------------------------------------------------------------------------------
+// Per-solve constants of the step-kernel chain in DEVICE memory.  Kernel arguments beyond the first 16 dwords are fetched
+// from the kernarg segment (host-coherent memory: a ~1 us round trip) before the first instruction that needs one of them
+// can run; the steady-state launches therefore take ONLY preloadable arguments (8 pointers / two ints: the
+// -amdgpu-kernarg-preload-count build preloads them into SGPRs while the wave is dispatched), the grid size comes as an
+// explicit argument rather than from the implicit kernarg block, and everything else — the solver options, the start
+// pose, where the trace and the host mailbox live — is read from this block, which launch 0 of the solve (MODE 0: it has
+// them as ordinary by-value arguments) leaves behind in device memory.
+struct SolveParams {
+  clc_options opt;
+  Pose7 pose0;
+  clc_iteration* trace;
+  HostMailbox* mailbox;
+  int32_t trace_cap;
+  int32_t pad_;
+};
+
+// The per-solve block and the two LM state buffers (double-buffered by launch parity) live in one allocation, so one
+// pointer argument reaches all three: user SGPRs hold 16 dwords, two of them the kernarg segment pointer — 14 dwords of
+// preloaded arguments is all a kernel gets.
+struct SolveBlock {
+  SolveParams prm;
+  LmState st[2];
+};
+
 // LAYOUT 0: compact tiles (ctiles + group table, n = observations); 1: row layout (ctiles = xy rows, groups = row
 // descriptors, n = rows; DEEP selects non-temporal loads, WEIGHTED the 3:2 old/young wave shares).
 template <bool WITH_LOSS, bool DEEP, int MODE, int LAYOUT = 0, bool WEIGHTED = true>
 __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ rows_in,
-                                                   const LmState* __restrict__ state_in,
                                                    const double* __restrict__ ctiles,
-                                                   const double* __restrict__ groups, const long long n,
-                                                   double* __restrict__ rows_out,
-                                                   LmState* __restrict__ state_out,
-                                                   clc_iteration* __restrict__ trace, HostMailbox* mailbox,
-                                                   const int trace_cap, const clc_options opt, const Pose7 pose0) {
-  // Argument order matters: the build preloads the first kernel arguments into SGPRs (-amdgpu-kernarg-preload-count),
-  // so what the first loads need — the row buffer, the state, the tiles — comes first and the wave does not start
-  // with a ~1 us kernel-argument fetch in front of them.
+                                                   const double* __restrict__ groups, const int n, const int grid_parity,
+                                                   double* __restrict__ rows_out, SolveBlock* __restrict__ blk,
+                                                   const SolveParams init) {
+  // Preloaded: rows_in, ctiles, groups, n, grid_parity, rows_out, blk = 12 dwords.  `init` is read by MODE 0 only (the
+  // other instantiations never touch it, so they never wait for the kernarg segment).
+  // grid_parity = number of workgroups | (launch index & 1) << 30: this launch reads LM state st[parity ^ 1], writes st[parity].
   __shared__ double red[LM_GROUPS][32];
   __shared__ double sh_state[LM_STATE_WORDS];
   const long long c0 = clock64();
   const bool leader = blockIdx.x == 0;
+  const int grid = grid_parity & 0x3FFFFFFF;
+  const int parity = (grid_parity >> 30) & 1;
+  const LmState* __restrict__ state_in = &blk->st[parity ^ 1];
+  LmState* __restrict__ state_out = &blk->st[parity];
+  SolveParams* __restrict__ params = &blk->prm;
   // the controller's loads go out first: its chain (rows -> combine -> LM step) is the long pole of the launch, the
   // tile prologue loads issued next only have to be in flight before it ends
   LmLoads L;
   if (MODE != 0) lm_issue_loads<false, MODE == 1, 512>(rows_in, state_in, L);
+  if (MODE == 0 && leader && threadIdx.x == 0) *params = init;  // for launches 1, 2, ... of this solve
+  const SolveParams* __restrict__ prm = params;
+  double inv_lf2 = 0.0;  // set by get_pose: it depends on the options, which must not be waited for before the loads go out
   auto get_pose = [&](PoseU& P) -> bool {
     if (MODE == 0) {
-      load_pose(pose0.v, P);
+      load_pose(init.pose0.v, P);
+      inv_lf2 = make_uniform(1.0 / (init.opt.loss_scale_factor * init.opt.loss_scale_factor));
       return true;
     }
-    const bool consumed = lm_tail<false, MODE == 1, 512, true>(rows_in, (int)gridDim.x, state_in,
-                                                           leader ? state_out : nullptr, opt, leader ? trace : nullptr,
-                                                           leader ? trace_cap : 0, leader ? mailbox : nullptr, red,
-                                                           sh_state, c0, &pose0, L);
+    const clc_options opt = prm->opt;  // wave-uniform, read-only: scalar loads from the device-resident block
+    inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
+    const bool consumed = lm_tail<false, MODE == 1, 512, true>(rows_in, grid, state_in,
+                                                           leader ? state_out : nullptr, opt, leader ? prm->trace : nullptr,
+                                                           leader ? prm->trace_cap : 0, leader ? prm->mailbox : nullptr, red,
+                                                           sh_state, c0, &prm->pose0, L);
     if (!consumed) {
       // the solve had terminated before this launch: hand the state on (the launch queued behind this one reads
       // the other buffer) and leave; the host mailbox is NOT touched — it may already belong to the next solve
@@ -1409,13 +1441,11 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
     load_pose(x, P);
     return running;
   };
-  const double lf = opt.loss_scale_factor;
-  const double inv_lf2 = make_uniform(1.0 / (lf * lf));
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
-  const WaveMap wm = make_wave_map<512, WEIGHTED>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
+  const WaveMap wm = make_wave_map<512, WEIGHTED>(blockIdx.x, grid, threadIdx.x >> 6);
   bool active;
   if (LAYOUT == 1)
     active = stream_rows<WITH_LOSS, DEEP>(ctiles, reinterpret_cast<const RowDesc*>(groups), wm.begin(n), wm.end(n), lane,
