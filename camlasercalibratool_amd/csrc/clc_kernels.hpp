@@ -1146,7 +1146,9 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
   L.passes_before = 0;
   L.my_word = 0.0;
   if (threadIdx.x < HT) {  // wave-uniform
-    if (!FIRST && threadIdx.x == 64) L.passes_before = state->n_evals;
+    // a per-lane (vector) load: read through a uniform address this becomes a scalar load whose s_waitcnt sits in front
+    // of wave 1's row loads — the wave then reaches the row-sum barrier ~1 us after the others
+    if (!FIRST && threadIdx.x == 64) L.passes_before = (&state->n_evals)[threadIdx.x - 64];
     const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
     L.my_word = reinterpret_cast<const double*>(state)[cw];
     const int cc = c < NACC ? c : NACC - 1;
@@ -1165,25 +1167,17 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
 // CHECK_STATUS: the staged state is inspected before anything is consumed or published; if the solve had already
 // terminated the function returns false right after the first barrier (state staged in LDS, nothing else done).
 // `red` is [LM_GROUPS][32] doubles of LDS.
-template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS = false>
-__device__ __forceinline__ bool lm_tail(const double* __restrict__ partials, int n_blocks,
-                                        const LmState* __restrict__ state, LmState* __restrict__ state_out,
-                                        const clc_options& opt,
-                                        clc_iteration* __restrict__ trace, int trace_cap,
-                                        HostMailbox* mailbox, double (*red)[32], double* sh_state,
-                                        const long long c0, const Pose7* init_pose, LmLoads& L) {
+// Phase A of the tail: this thread's share of the row sums -> LDS, its word of the LM state -> LDS.  No barrier: a caller
+// may issue further loads (the step kernel: its first rows of points) between this and lm_tail_finish.
+template <bool COHERENT, int HT>
+__device__ __forceinline__ void lm_tail_sums(const double* __restrict__ partials, int n_blocks, double (*red)[32],
+                                             double* sh_state, const LmLoads& L, long long* stamps /* nullable: [2] */) {
   static_assert(LM_STATE_WORDS <= 256, "one state word per thread");
-  // Called by every thread of the workgroup (it contains barriers); the first HT threads work, any waves beyond
-  // them only take part in the barriers.
   const bool helper = threadIdx.x < HT;
-  // Progress for the host's launch-ahead metering is published EARLY, by the first lane of wave 1
-  // (not the controller's wave): the ~1.5 us a store to pinned host memory needs to be
-  // acknowledged then overlaps the controller instead of delaying the end of the launch.
-  const long long passes_before = L.passes_before;
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   if (helper) {  // wave-uniform
     const int cc = c < NACC ? c : NACC - 1;
-    const long long ca = clock64();
+    if (stamps && threadIdx.x == 0) stamps[0] = clock64();
     if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = L.my_word;
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -1192,7 +1186,7 @@ __device__ __forceinline__ bool lm_tail(const double* __restrict__ partials, int
 #pragma unroll
       for (int j = 0; j < 16; ++j) s1 += (c < NACC && g + 8 + LM_GROUPS * j < n_blocks) ? L.v[16 + j] : 0.0;
     }
-    if (opt.profile_events && threadIdx.x == 0 && mailbox != nullptr) { mailbox->prof[4] = ca; mailbox->prof[5] = clock64(); }
+    if (stamps && threadIdx.x == 0) stamps[1] = clock64();
     for (int b0 = 256; b0 < n_blocks; b0 += 256) {  // grids beyond 256 workgroups: further rounds of 256 rows
       const double* bb = partials + (size_t)(b0 + g) * NACC + cc;
       double v[16];
@@ -1210,6 +1204,20 @@ __device__ __forceinline__ bool lm_tail(const double* __restrict__ partials, int
     red[g][c] = s0;
     if (HT == 256) red[g + 8][c] = s1;
   }
+}
+
+// Phase B: barrier, ordered combination of the 16 row groups, LM controller, publication.
+template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS = false>
+__device__ __forceinline__ bool lm_tail_finish(const LmState* __restrict__ state, LmState* __restrict__ state_out,
+                                               const clc_options& opt,
+                                               clc_iteration* __restrict__ trace, int trace_cap,
+                                               HostMailbox* mailbox, double (*red)[32], double* sh_state,
+                                               const long long c0, const Pose7* init_pose, const LmLoads& L) {
+  // Called by every thread of the workgroup (it contains barriers).
+  // Progress for the host's launch-ahead metering is published EARLY, by the first lane of wave 1
+  // (not the controller's wave): the ~1.5 us a store to pinned host memory needs to be
+  // acknowledged then overlaps the controller instead of delaying the end of the launch.
+  const long long passes_before = L.passes_before;
   __syncthreads();
   if (CHECK_STATUS && !FIRST && reinterpret_cast<const LmState*>(sh_state)->status != CLC_RUNNING) return false;
   // the 16 row groups are combined in order by 28 lanes in parallel (one column each): done by the controller's
@@ -1260,6 +1268,20 @@ __device__ __forceinline__ bool lm_tail(const double* __restrict__ partials, int
   if (state_out != nullptr && threadIdx.x < LM_STATE_WORDS)
     reinterpret_cast<double*>(state_out)[threadIdx.x] = sh_state[threadIdx.x];
   return true;
+}
+
+// Both phases back to back (lm_kernel, eval_lm_kernel).
+template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS = false>
+__device__ __forceinline__ bool lm_tail(const double* __restrict__ partials, int n_blocks,
+                                        const LmState* __restrict__ state, LmState* __restrict__ state_out,
+                                        const clc_options& opt,
+                                        clc_iteration* __restrict__ trace, int trace_cap,
+                                        HostMailbox* mailbox, double (*red)[32], double* sh_state,
+                                        const long long c0, const Pose7* init_pose, LmLoads& L) {
+  lm_tail_sums<COHERENT, HT>(partials, n_blocks, red, sh_state, L,
+                             (opt.profile_events && mailbox != nullptr) ? &mailbox->prof[4] : nullptr);
+  return lm_tail_finish<COHERENT, FIRST, HT, CHECK_STATUS>(state, state_out, opt, trace, trace_cap, mailbox, red, sh_state, c0,
+                                                           init_pose, L);
 }
 
 template <bool FIRST>
@@ -1423,10 +1445,10 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
     }
     const clc_options opt = prm->opt;  // wave-uniform, read-only: scalar loads from the device-resident block
     inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
-    const bool consumed = lm_tail<false, MODE == 1, 512, true>(rows_in, grid, state_in,
-                                                           leader ? state_out : nullptr, opt, leader ? prm->trace : nullptr,
-                                                           leader ? prm->trace_cap : 0, leader ? prm->mailbox : nullptr, red,
-                                                           sh_state, c0, &prm->pose0, L);
+    const bool consumed = lm_tail_finish<false, MODE == 1, 512, true>(state_in, leader ? state_out : nullptr, opt,
+                                                                  leader ? prm->trace : nullptr, leader ? prm->trace_cap : 0,
+                                                                  leader ? prm->mailbox : nullptr, red, sh_state, c0,
+                                                                  &prm->pose0, L);
     if (!consumed) {
       // the solve had terminated before this launch: hand the state on (the launch queued behind this one reads
       // the other buffer) and leave; the host mailbox is NOT touched — it may already belong to the next solve
@@ -1446,6 +1468,12 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const WaveMap wm = make_wave_map<512, WEIGHTED>(blockIdx.x, grid, threadIdx.x >> 6);
+  // Order of the memory traffic of a launch: every wave's share of the previous launch's rows FIRST (57 KB per
+  // workgroup through a 64 B/clk vector cache: the controller waits for the slowest wave's rows), and only when a wave
+  // has summed its rows does it issue its first rows of points — those have the whole controller to arrive.  (Issued
+  // ahead of the row sums, as the tile prologue used to be, the 8 x 9 KB of points of the older waves sat in the queue in
+  // front of the younger waves' rows.)
+  if (MODE != 0) lm_tail_sums<false, 512>(rows_in, grid, red, sh_state, L, nullptr);
   bool active;
   if (LAYOUT == 1)
     active = stream_rows<WITH_LOSS, DEEP>(ctiles, reinterpret_cast<const RowDesc*>(groups), wm.begin(n), wm.end(n), lane,

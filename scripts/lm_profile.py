@@ -11,5 +11,6 @@ for _ in range(5):
     r = sv.solve(x0, o)
     p = (C.c_longlong * 8)()
     _capi.lib().clc_debug_lm_profile(sv._h, p)
-    print("cycles: entry->loads issued %d, ->landed+summed %d, ->combined %d, ->controller start %d | controller %d, mailbox %d (termination %s)"
-          % (p[4]-p[0], p[5]-p[4], p[6]-p[5], p[1]-p[6], p[2]-p[1], p[3]-p[2], r.termination))
+    # step-kernel path: stamps of the leader workgroup, wave 0 (kernel entry, rows combined, controller start / end, mailbox)
+    print("cycles: entry->rows combined %d, ->controller start %d | controller %d, mailbox %d (termination %s)"
+          % (p[6]-p[0], p[1]-p[6], p[2]-p[1], p[3]-p[2], r.termination))
