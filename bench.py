@@ -39,7 +39,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured achievable
 BYTES_PER_EVAL = 64     # one clc_observation record read once per evaluation
-COMPACT_BYTES_PER_EVAL = 28  # what the default (compact) layout actually streams: 24 B point + 4 B group id
+COMPACT_BYTES_PER_EVAL = 28  # the compact layout streams 24 B point + 4 B group id per observation
+ROW_BYTES = 64 * 16 + 64     # the default (row) layout streams 1 KiB of (x, y) + a 64 B descriptor per row of 64 points
 
 
 def parse():
@@ -54,8 +55,9 @@ def parse():
     ap.add_argument("--kernel-events", action="store_true",
                     help="bracket every evaluation-kernel launch with HIP event pairs INSIDE the timed region "
                          "(perturbs the timed solves; default: events are used after the timed region)")
-    ap.add_argument("--large-obs", type=int, default=8_000_000,
-                    help="extra >Infinity-Cache evaluation-kernel measurement (0 disables)")
+    ap.add_argument("--large-obs", type=int, default=32_000_000,
+                    help="extra evaluation-kernel measurement on a working set beyond the Infinity Cache in the layout streamed "
+                         "(3.2e7 obs = 544 MB of rows; 0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-batched", action="store_true", help="skip the extra C3 (1024 problems x 1e4 obs) measurement")
     ap.add_argument("--problems-per-gpu", type=int, default=8192, help="C4 shard: independent problems per GPU (N>1 workload)")
@@ -146,10 +148,16 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         res["max_abs_T_err_vs_ground_truth_sampled"] = err
         # dominant kernel of the step: batched_eval_kernel over the whole shard (all problems active)
         kms = min(ss.solver.time_batched_eval(x0, reps=10) for _ in range(3))
-        res["roofline"] = {"bound": "hbm", "kernel": "clc::batched_eval_kernel (all problems of the shard active)",
-                           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs_local, "avg_kernel_ms": kms,
+        _, _, brows_ok, bn_rows = ss.solver.debug_rows()
+        streamed = bn_rows * ROW_BYTES if brows_ok else COMPACT_BYTES_PER_EVAL * n_obs_local
+        res["roofline"] = {"bound": "hbm", "traffic": None,
+                           "kernel": ("clc::batched_rows_eval_kernel<loss=1,nt=1>" if brows_ok else "clc::batched_eval_kernel<compact,deep>")
+                                     + " (all problems of the shard active)",
+                           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs_local, "streamed_bytes_per_launch": int(streamed),
+                           "avg_kernel_ms": kms,
                            "achieved": BYTES_PER_EVAL * n_obs_local / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": BYTES_PER_EVAL * n_obs_local / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "achieved_streamed": streamed / (kms * 1e-3) / 1e9, "frac_streamed": streamed / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "timing": "hipEvent pair around 10 back-to-back launches on the solver's stream (best of 3)"}
         if not args.no_cpu_baseline:
             import oracle as _o
@@ -285,54 +293,56 @@ def main():
         # The timed region consists of step_kernel launches only: one per evaluation pass (every workgroup first runs
         # the LM controller on the previous launch's partial rows, then streams its share of the observations) plus
         # one final controller-only launch per solve.  Its launch period is measured with HIP events on the solver's
-        # stream (below); the rocprofv3 average of the streaming launches of step_kernel<...,2> in profiles/ is the
+        # stream (below); the rocprofv3 average of the streaming launches of step_kernel<..., 2, ...> in profiles/ is the
         # per-dispatch figure it must agree with.  The wall time of the timed region per pass is reported next to it.
         passes = res.summary.num_evaluations
         wall_ms_per_pass = (1e3 * elapsed_max / args.steps) / passes
         # HIP events on the solver's stream right before launch 2 and right after launch passes-1 of a solve: the
         # steady-state launches, every one of which consumed a pass and streamed the array
         step_ms = min(solver.time_steps(x0, 2, passes - 1)[0] for _ in range(5)) if passes >= 4 else wall_ms_per_pass
-        # the streaming part alone: HIP events on the solver's stream around 200 back-to-back launches of
-        # eval_kernel (same loop, same layout, no controller prologue) on the same resident array and pose
+        # the streaming part alone: HIP events on the solver's stream around 200 back-to-back launches of the
+        # evaluation kernel (same loop, same layout, no controller prologue) on the same resident array and pose
         b2b = min(solver.time_eval(x0, reps=200) for _ in range(3))
+        rows_ok, n_rows, _, _ = solver.debug_rows()
+        # The default layout is a lossless re-encoding of the 64-byte records: per scan one plane, per point (x, y)
+        # [z == 0] in rows of 64 points + a 64-byte descriptor per row.  The bytes actually streamed per launch:
+        streamed = (n_rows * ROW_BYTES) if rows_ok else COMPACT_BYTES_PER_EVAL * n_obs
+        layout = ("rows (16 B point + 64 B descriptor per row of 64 points, per-scan moments)" if rows_ok
+                  else "compact (24 B point + 4 B group id per observation; group table per scan)")
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "kernel": "clc::step_kernel<loss=1,deep=0,mode=2> (controller prologue + compact streaming loop)",
+                "kernel": ("clc::step_kernel<loss=1,nt=0,mode=2,layout=rows,weighted=1>" if rows_ok else "clc::step_kernel<loss=1,deep=0,mode=2,layout=compact>")
+                          + " (controller prologue + streaming loop)",
                 "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs,
                 "achieved": BYTES_PER_EVAL * n_obs / (step_ms * 1e-3) / 1e9, "avg_kernel_ms": step_ms,
                 "timing": f"hipEvent pair on the solver's stream around launches 2..{passes - 1} (steady state, back to back) of one "
                           "clc_solve, / number of launches (best of 5)",
                 "timed_region_wall_ms_per_pass": wall_ms_per_pass,
-                "streaming_alone": {"kernel": "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
+                "layout": layout, "streamed_bytes_per_launch": int(streamed),
+                "streaming_alone": {"kernel": "clc::eval_rows_kernel<loss=1,nt=0,512,weighted=1>" if rows_ok else "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
                                     "avg_kernel_ms": b2b, "achieved": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9,
                                     "frac": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "achieved_streamed": streamed / (b2b * 1e-3) / 1e9,
+                                    "frac_streamed": streamed / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "timing": "hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)"}}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        # The default layout is a lossless re-encoding of the 64-byte records (28 B/obs): the bytes
-        # actually streamed are fewer than the algorithmic bytes the contract prices the kernel at.
-        roof["layout"] = "compact (24 B point + 4 B group id per observation; group table per scan)"
-        roof["streamed_bytes_per_launch"] = COMPACT_BYTES_PER_EVAL * n_obs
-        roof["achieved_streamed"] = COMPACT_BYTES_PER_EVAL * n_obs / (step_ms * 1e-3) / 1e9
+        roof["achieved_streamed"] = streamed / (step_ms * 1e-3) / 1e9
         roof["frac_streamed"] = roof["achieved_streamed"] / HBM_PEAK_GBS
-        roof["streaming_alone"]["achieved_streamed"] = COMPACT_BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9
-        # same kernel on the 64-byte tiles (clc_set_launch flags = prefetch + non-temporal)
+        # the same evaluation on the other layouts (A/B through clc_set_launch): compact 28 B/obs, 64-byte tiles
+        solver.set_launch(0, 2 | 16 | 32)
+        b2bc = min(solver.time_eval(x0, reps=200) for _ in range(3))
         solver.set_launch(0, 6)
         b2b64 = min(solver.time_eval(x0, reps=200) for _ in range(3))
         solver.set_launch(0, -1)
+        roof["compact28"] = {"avg_kernel_ms": b2bc, "achieved": BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9,
+                             "frac": BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "frac_streamed": COMPACT_BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS}
         roof["tiled64"] = {"avg_kernel_ms": b2b64, "achieved": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9,
                            "frac": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "64-byte records streamed as stored: achieved == actual HBM rate"}
-        # in-solve diagnostic: event pairs around every launch of a few extra solves
-        opt_ev = clc.default_options()
-        opt_ev.profile_events = 1
-        ev_ms, ev_n = (k_ms, k_launches)
-        if ev_n == 0:
-            for _ in range(10):
-                r_ev = solver.solve(x0, opt_ev, trace_cap=0)
-                ev_ms += r_ev.summary.eval_kernel_ms
-                ev_n += r_ev.summary.eval_kernel_launches
-        roof["in_solve_event_pair_ms"] = ev_ms / max(ev_n, 1)
-        roof["note"] = (f"{BYTES_PER_EVAL * n_obs / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state "
-                        "passes may be served on-die; see roofline_large for a >L3 working set")
+        roof["note"] = (f"{streamed / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state passes are served on-die, and "
+                        "~8 us of every launch is fixed cost (launch boundary, the previous launch's 57 KB of partial rows, the LM controller); "
+                        "`frac` prices the launch at the contract's 64 algorithmic bytes per evaluation, `frac_streamed` at the bytes the "
+                        "layout moves; see roofline_large for a working set beyond the cache")
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
@@ -343,23 +353,36 @@ def main():
                 pass
         out["roofline"] = roof
 
-    # ---- >L3 working set: evaluation kernel only (rank 0, N=1) ----
+    # ---- working set beyond the 256 MiB Infinity Cache IN THE LAYOUT STREAMED: evaluation kernel only (rank 0, N=1) ----
     if rank == 0 and world == 1 and args.large_obs > 0:
         reps = (args.large_obs + n_obs - 1) // n_obs
         big = np.ascontiguousarray(np.tile(rec, (reps, 1))[: args.large_obs])
+        nb = int(big.shape[0])
         solver.upload(big)
-        ms = min(solver.time_eval(x0, reps=20) for _ in range(3))
-        gbs = BYTES_PER_EVAL * big.shape[0] / (ms * 1e-3) / 1e9
-        solver.set_launch(0, 6)
-        ms64 = min(solver.time_eval(x0, reps=20) for _ in range(3))
-        solver.set_launch(0, -1)
-        out["roofline_large"] = {"observations": int(big.shape[0]), "bytes": int(BYTES_PER_EVAL * big.shape[0]),
-                                 "avg_kernel_ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": gbs / HBM_PEAK_GBS, "evals_per_s": big.shape[0] / (ms * 1e-3),
-                                 "achieved_streamed": COMPACT_BYTES_PER_EVAL * big.shape[0] / (ms * 1e-3) / 1e9,
-                                 "tiled64": {"avg_kernel_ms": ms64, "achieved": BYTES_PER_EVAL * big.shape[0] / (ms64 * 1e-3) / 1e9,
-                                             "frac": BYTES_PER_EVAL * big.shape[0] / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         del big
+        rows_ok_l, n_rows_l, _, _ = solver.debug_rows()
+        streamed_l = (n_rows_l * ROW_BYTES) if rows_ok_l else COMPACT_BYTES_PER_EVAL * nb
+        ms = min(solver.time_eval(x0, reps=20) for _ in range(3))
+        solver.set_launch(0, 2 | 16 | 32)
+        msc = min(solver.time_eval(x0, reps=10) for _ in range(3))
+        solver.set_launch(0, 6)
+        ms64 = min(solver.time_eval(x0, reps=10) for _ in range(3))
+        solver.set_launch(0, -1)
+        gbs = BYTES_PER_EVAL * nb / (ms * 1e-3) / 1e9
+        out["roofline_large"] = {
+            "observations": nb, "algorithmic_bytes": int(BYTES_PER_EVAL * nb), "streamed_bytes": int(streamed_l),
+            "beyond_infinity_cache": bool(streamed_l > 256 * 2**20),
+            "kernel": "clc::eval_rows_kernel<loss=1,nt=1,512,weighted=1>" if rows_ok_l else "clc::eval_kernel (compact, deep)",
+            "avg_kernel_ms": ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved_streamed": streamed_l / (ms * 1e-3) / 1e9, "frac_streamed": streamed_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "evals_per_s": nb / (ms * 1e-3),
+            "note": "frac_streamed = bytes the layout moves / time / 8 TB/s is the HBM fraction; frac prices the same launch at the "
+                    "contract's 64 algorithmic bytes per evaluation and exceeds 1 because the layout is a 3.8x lossless compression",
+            "compact28": {"avg_kernel_ms": msc, "streamed_bytes": COMPACT_BYTES_PER_EVAL * nb,
+                          "frac_streamed": COMPACT_BYTES_PER_EVAL * nb / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "frac": BYTES_PER_EVAL * nb / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "tiled64": {"avg_kernel_ms": ms64, "achieved": BYTES_PER_EVAL * nb / (ms64 * 1e-3) / 1e9,
+                        "frac": BYTES_PER_EVAL * nb / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         solver.upload(rec)
 
     # ---- BASELINE.json configs[2] (C3): 1 024 independent T_cl problems x 10^4 observations ----
@@ -384,6 +407,12 @@ def main():
             "lm_iterations_min_max": [min(s_.num_iterations for s_ in smb), max(s_.num_iterations for s_ in smb)],
             "max_abs_T_err_vs_ground_truth": float(max(np.abs(sd.T_from_pose7(pb[k]) - gts[k]).max() for k in range(Pb))),
         }
+        kb = min(solver.time_batched_eval(xb, reps=20) for _ in range(3))
+        _, _, brows_ok, bn_rows = solver.debug_rows()
+        sb = bn_rows * ROW_BYTES if brows_ok else COMPACT_BYTES_PER_EVAL * int(offb[-1])
+        out["batched_c3"]["eval_kernel"] = {"avg_kernel_ms": kb, "streamed_bytes": int(sb),
+                                            "frac": BYTES_PER_EVAL * int(offb[-1]) / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "frac_streamed": sb / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline:
             import oracle as _o
             w = 0.0

@@ -59,6 +59,15 @@ bool all_finite(const double* p, int n) {
 }
 
 constexpr int kDefaultLookahead = 2;
+// experiments: CLC_LAUNCH_AHEAD overrides the default launch-ahead depth (options with launch_ahead = 0)
+int default_lookahead() {
+  static const int v = [] {
+    const char* e = std::getenv("CLC_LAUNCH_AHEAD");
+    const int n = e ? std::atoi(e) : 0;
+    return n > 0 ? n : kDefaultLookahead;
+  }();
+  return v;
+}
 constexpr size_t kInfinityCacheBytes = 256u << 20;  // MI355X memory-side cache (MI355X_MICROARCH.md)
 constexpr int kDefaultLaunchFlags = 2 | 16 | 32 | 128 | 256;  // prefetch + compact layout + 512-thread weighted workgroups + step kernel (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py, scripts/step_check.py)
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
@@ -741,7 +750,7 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
     const int rc = ensure_trace(h, opt.max_num_iterations + 8);
     if (rc != CLC_OK) return rc;
   }
-  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
+  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : default_lookahead();
   const int max_launches = opt.max_num_iterations + 2;  // (max_iterations + 1) evaluations + the final controller pass
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
@@ -904,7 +913,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // Launch-ahead depth: the host keeps this many LM iterations queued beyond the last one the
   // device has reported done (pinned mailbox), so the stream never drains and the host never
   // blocks; at most `lookahead` already-queued iterations turn into no-ops after termination.
-  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
+  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : default_lookahead();
   // Controller in the tail of the evaluation launch (one launch per LM iteration) vs its own launch: fused saves a
   // launch boundary (~1 us per iteration) when the evaluation is short, and loses a little when many workgroups
   // queue for the ticket (scripts/size_sweep.py: 0.178 vs 0.193 ms at 5 500 obs, 0.222 vs 0.213 at 1e5, equal at 1e6).
@@ -1185,7 +1194,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   hipLaunchKernelGGL(clc::batched_init_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
                      opt, h->d_poses, (int)P);
   CLC_HIP(hipGetLastError());
-  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : kDefaultLookahead;
+  const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : default_lookahead();
   const int max_evals = opt.max_num_iterations + 1;
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
