@@ -1060,8 +1060,17 @@ int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
-  hipLaunchKernelGGL(clc::normal9_kernel, dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_tiles,
-                     (long long)h->n_obs, h->d_partials);
+  if (use_rows(h)) {
+    if (rows_nontemporal(h, h->n_rows))
+      hipLaunchKernelGGL(clc::normal9_rows_kernel<true>, dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_rxy,
+                         reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, h->d_partials);
+    else
+      hipLaunchKernelGGL(clc::normal9_rows_kernel<false>, dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_rxy,
+                         reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, h->d_partials);
+  } else {
+    hipLaunchKernelGGL(clc::normal9_kernel, dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_tiles,
+                       (long long)h->n_obs, h->d_partials);
+  }
   CLC_HIP(hipGetLastError());
   hipLaunchKernelGGL(clc::reduce9_kernel, dim3(1), dim3(clc::BLOCK), 0, h->stream, h->d_partials, grid,
                      h->d_small + 128);
@@ -1079,7 +1088,7 @@ int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9
       Atb[3 * ci + ri] = r[36 + 3 * ci + ri];
     }
   rc = clc::host::closed_form_from_normal(AtA, Atb, Tlc, unobservable, sv9);
-  if (rc != CLC_OK) return fail(rc, "clc_closed_form: 9x9 normal equation is not positive definite");
+  if (rc != CLC_OK) return fail(rc, "clc_closed_form: non-finite solution of the 9x9 normal equation");
   return CLC_OK;
 }
 

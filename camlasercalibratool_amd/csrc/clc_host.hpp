@@ -134,61 +134,101 @@ inline void jacobi_eig_sym(const double* Ain, int n, double* w, double* V) {
   }
 }
 
-// SPD solve (n <= 9) standing in for AtA.ldlt().solve(...) at src/LaseCamCalCeres.cpp:181.
-inline bool chol_solve_n(const double* A, const double* b, double* x, int n) {
-  double L[81], z[9];
-  for (int i = 0; i < n * n; ++i) L[i] = 0.0;
-  for (int j = 0; j < n; ++j) {
-    double d = A[j * n + j];
-    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
-    if (!(d > 0.0)) return false;
-    L[j * n + j] = std::sqrt(d);
-    for (int i = j + 1; i < n; ++i) {
-      double s = A[i * n + j];
-      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
-      L[i * n + j] = s / L[j * n + j];
+// AtA.ldlt().solve(rhs) at src/LaseCamCalCeres.cpp:181 (n <= 9).  Eigen's LDLT is the "robust Cholesky with pivoting"
+// of its documentation: P A P^T = L D L^T, at every step the largest remaining diagonal entry is brought to the pivot
+// position by a symmetric permutation; the solve applies P, L^-1, the PSEUDO-inverse of D (an exactly zero pivot
+// contributes zero instead of a division by zero), L^-T, P^T.  It therefore returns a finite vector for a semi-definite
+// (unobservable) normal matrix too — which is what the reference goes on to use after printing its notice (:173-181).
+// A plain Cholesky, as round 1 used here, fails on such input.
+inline void ldlt_solve_n(const double* Ain, const double* b, double* x, int n) {
+  double A[81], D[9], y[9];
+  int perm[9];
+  for (int i = 0; i < n * n; ++i) A[i] = Ain[i];
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    double big = std::fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(A[i * n + i]) > big) { big = std::fabs(A[i * n + i]); piv = i; }
+    if (piv != k) {  // symmetric row/column swap (the full matrix is kept, both triangles)
+      for (int j = 0; j < n; ++j) std::swap(A[k * n + j], A[piv * n + j]);
+      for (int i = 0; i < n; ++i) std::swap(A[i * n + k], A[i * n + piv]);
+      std::swap(perm[k], perm[piv]);
+    }
+    // column k of L and D[k] (rows/columns < k already hold L below the diagonal)
+    double d = A[k * n + k];
+    for (int j = 0; j < k; ++j) d -= A[k * n + j] * A[k * n + j] * D[j];
+    D[k] = d;
+    for (int i = k + 1; i < n; ++i) {
+      double v = A[i * n + k];
+      for (int j = 0; j < k; ++j) v -= A[i * n + j] * A[k * n + j] * D[j];
+      A[i * n + k] = (d != 0.0) ? v / d : 0.0;
     }
   }
-  for (int i = 0; i < n; ++i) {
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[i * n + k] * z[k];
-    z[i] = s / L[i * n + i];
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    double s = z[i];
-    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
-    x[i] = s / L[i * n + i];
-  }
-  return true;
+  for (int i = 0; i < n; ++i) y[i] = b[perm[i]];            // P b
+  for (int i = 0; i < n; ++i)                                 // L^-1
+    for (int j = 0; j < i; ++j) y[i] -= A[i * n + j] * y[j];
+  for (int i = 0; i < n; ++i) y[i] = (std::fabs(D[i]) > 2.2250738585072014e-308) ? y[i] / D[i] : 0.0;  // D^+
+  for (int i = n - 1; i >= 0; --i)                            // L^-T
+    for (int j = i + 1; j < n; ++j) y[i] -= A[j * n + i] * y[j];
+  for (int i = 0; i < n; ++i) x[perm[i]] = y[i];              // P^T
 }
 
-// Nearest orthogonal matrix U V^T of a 3x3 M (src/LaseCamCalCeres.cpp:195-196; like the
-// reference, no determinant check): U V^T = M (M^T M)^(-1/2).
+// Nearest orthogonal matrix U V^T of a 3x3 M from its singular value decomposition (src/LaseCamCalCeres.cpp:195-196:
+// JacobiSVD of Rlc, U * V^T; like the reference, no determinant check).  V and the singular values come from the
+// symmetric eigen-decomposition of M^T M, U = M V / sigma column by column; a column whose singular value vanishes
+// (rank-deficient M: h1 parallel to h2, or zero) is completed to an orthonormal basis — an SVD always has a full
+// orthogonal U, so U V^T stays defined where M (M^T M)^(-1/2), the closed formula round 1 used, divides by zero.
 inline void nearest_orthogonal3(const double* M, double* Q) {
-  double MtM[9], w[3], V[9], P[9];
+  double MtM[9], w[3], V[9], U[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
       double s = 0.0;
       for (int k = 0; k < 3; ++k) s += M[3 * k + i] * M[3 * k + j];
       MtM[3 * i + j] = s;
     }
-  jacobi_eig_sym(MtM, 3, w, V);
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double s = 0.0;
-      for (int k = 0; k < 3; ++k) s += V[3 * i + k] * (1.0 / std::sqrt(w[k])) * V[3 * j + k];
-      P[3 * i + j] = s;
+  jacobi_eig_sym(MtM, 3, w, V);  // descending
+  const double smax = std::sqrt(std::max(w[0], 0.0));
+  int have[3] = {0, 0, 0};
+  for (int c = 0; c < 3; ++c) {
+    double u[3] = {0, 0, 0};
+    for (int r = 0; r < 3; ++r)
+      for (int k = 0; k < 3; ++k) u[r] += M[3 * r + k] * V[3 * k + c];
+    const double nrm = std::sqrt((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]);
+    if (nrm > 1e-14 * smax && nrm > 0.0) {
+      for (int r = 0; r < 3; ++r) U[3 * r + c] = u[r] / nrm;
+      have[c] = 1;
     }
+  }
+  // complete the missing columns (singular values are sorted: the missing ones come last)
+  if (!have[0]) { U[0] = 1; U[3] = 0; U[6] = 0; have[0] = 1; }
+  if (!have[1]) {  // any unit vector orthogonal to column 0
+    const double a[3] = {U[0], U[3], U[6]};
+    int m = std::fabs(a[0]) <= std::fabs(a[1]) ? (std::fabs(a[0]) <= std::fabs(a[2]) ? 0 : 2) : (std::fabs(a[1]) <= std::fabs(a[2]) ? 1 : 2);
+    double e[3] = {0, 0, 0}, c1[3];
+    e[m] = 1.0;
+    cross3(a, e, c1);
+    const double nrm = std::sqrt((c1[0] * c1[0] + c1[1] * c1[1]) + c1[2] * c1[2]);
+    for (int r = 0; r < 3; ++r) U[3 * r + 1] = c1[r] / nrm;
+    have[1] = 1;
+  }
+  if (!have[2]) {
+    const double a[3] = {U[0], U[3], U[6]}, b2[3] = {U[1], U[4], U[7]};
+    double c2[3];
+    cross3(a, b2, c2);
+    for (int r = 0; r < 3; ++r) U[3 * r + 2] = c2[r];
+  }
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
       double s = 0.0;
-      for (int k = 0; k < 3; ++k) s += M[3 * i + k] * P[3 * k + j];
+      for (int k = 0; k < 3; ++k) s += U[3 * i + k] * V[3 * j + k];
       Q[3 * i + j] = s;
     }
 }
 
 // Back end of CamLaserCalClosedSolution (src/LaseCamCalCeres.cpp:162-200) given the reduced
-// 9x9 normal equation.  Returns CLC_OK or CLC_ERR_LINALG.
+// 9x9 normal equation.  Like the reference it always produces a Tlc — for an unobservable system (flagged through
+// *unobservable, :164-178) whatever the pivoted LDLT and the SVD yield; CLC_ERR_NONFINITE only if that is not finite.
 inline int closed_form_from_normal(const double* AtA, const double* Atb, double* Tlc,
                                    int* unobservable, double* sv9) {
   double w[9], V[81];
@@ -200,7 +240,7 @@ inline int closed_form_from_normal(const double* AtA, const double* Atb, double*
   }
   *unobservable = un;
   double H[9];
-  if (!chol_solve_n(AtA, Atb, H, 9)) return CLC_ERR_LINALG;  // :181
+  ldlt_solve_n(AtA, Atb, H, 9);  // :181
   const double *h1 = H, *h2 = H + 3, *h3 = H + 6;
   double h12[3];
   cross3(h1, h2, h12);
@@ -216,6 +256,8 @@ inline int closed_form_from_normal(const double* AtA, const double* Atb, double*
     Tlc[4 * i + 3] = tlc[i];
   }
   Tlc[15] = 1.0;
+  for (int i = 0; i < 16; ++i)
+    if (!std::isfinite(Tlc[i])) return CLC_ERR_NONFINITE;
   return CLC_OK;
 }
 

@@ -748,10 +748,67 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-template <bool WITH_LOSS, bool NT, class PoseFn>
-__device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, const RowDesc* __restrict__ desc_all,
-                                            long long r_begin_in, long long r_end_in, const int lane, PoseFn get_pose,
-                                            const double& inv_lf2, double (&acc)[NACC]) {
+// What a wave does with the rows it streams is a policy: begin_scan(pose, plane of the scan), point(x, y) for every
+// valid point of a row, flush(acc) when the scan ends.  LmRows = the LM evaluation (clc_rows.hpp), Normal9Rows = the 9x9
+// normal equation of the closed-form initialiser (K5).
+template <bool WITH_LOSS>
+struct LmRows {
+  static constexpr int NA = NACC;
+  const double& inv_lf2;  // set by get_pose (it may depend on options that arrive late)
+  RowPlane q;
+  RowMoments M;
+  __device__ __forceinline__ explicit LmRows(const double& inv) : inv_lf2(inv) {}
+  __device__ __forceinline__ void begin_scan(const PoseU& P, double nx, double ny, double nz, double d, double s) {
+    rows_plane_setup(P.R, P.t, nx, ny, nz, d, s, q);
+    rows_moments_reset<WITH_LOSS>(M);
+  }
+  __device__ __forceinline__ void point(double x, double y) { rows_point<WITH_LOSS>(q, inv_lf2, x, y, M); }
+  __device__ __forceinline__ void flush(double (&acc)[NACC]) { rows_flush<WITH_LOSS>(q, M, acc); }
+};
+
+constexpr int NACC9 = 45;
+
+// Row A_k = kron([x, y, 1], n), b_k = -d (src/LaseCamCalCeres.cpp:144-158): A^T A = sum kron(b b^T, n n^T) and
+// A^T b = -d kron(sum b, n) share the scan's n, so a lane only accumulates the 6 moments of b = (x, y, 1) per scan
+// (5 FP64 instructions per point) and expands them once per scan.
+// acc layout (as normal9_kernel): [bb(6: xx xy x yy y 1)] x [nn(6: 00 01 02 11 12 22)] then A^T b (9: b-major).
+struct Normal9Rows {
+  static constexpr int NA = NACC9;
+  double nx, ny, nz, md;
+  double sxx, sxy, sx, syy, sy, s1;
+  __device__ __forceinline__ void begin_scan(const PoseU&, double nx_, double ny_, double nz_, double d, double) {
+    nx = nx_; ny = ny_; nz = nz_; md = -d;
+    sxx = sxy = sx = syy = sy = s1 = 0.0;
+  }
+  __device__ __forceinline__ void point(double x, double y) {
+    sxx = fma(x, x, sxx);
+    sxy = fma(x, y, sxy);
+    syy = fma(y, y, syy);
+    sx += x;
+    sy += y;
+    s1 += 1.0;
+  }
+  __device__ __forceinline__ void flush(double (&acc)[NACC9]) {
+    const double nn[6] = {nx * nx, nx * ny, nx * nz, ny * ny, ny * nz, nz * nz};
+    const double bb[6] = {sxx, sxy, sx, syy, sy, s1};
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[6 * i + j] = fma(bb[i], nn[j], acc[6 * i + j]);
+    const double bv[3] = {sx, sy, s1};
+    const double nv[3] = {nx * md, ny * md, nz * md};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[36 + 3 * i + j] = fma(bv[i], nv[j], acc[36 + 3 * i + j]);
+  }
+};
+
+template <class Policy, bool NT, class PoseFn>
+__device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __restrict__ xy_all,
+                                                   const RowDesc* __restrict__ desc_all, long long r_begin_in,
+                                                   long long r_end_in, const int lane, PoseFn get_pose,
+                                                   double (&acc)[Policy::NA]) {
   // wave-uniform run [r_begin, r_end): loop control on the scalar unit (32-bit row index relative to the run's first
   // row — 64-bit compares would go through the vector unit)
   const long long r_begin = uniform_ll(r_begin_in);
@@ -768,8 +825,6 @@ __device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, c
     }
   PoseU P;
   if (!get_pose(P)) return false;  // after the prologue loads are in flight (see stream_tiles)
-  RowPlane q;
-  RowMoments M;
   for (int base = 0; base < n; base += ROWS_DEPTH) {
 #pragma unroll
     for (int u = 0; u < ROWS_DEPTH; ++u) {
@@ -784,16 +839,22 @@ __device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, c
       const int count = __builtin_amdgcn_readlane(__double2loint(dv), 5);  // RowDesc: double 5 = {count, first}
       const int first = __builtin_amdgcn_readlane(__double2hiint(dv), 5);
       if (first != 0 || r == 0) {  // wave-uniform: the scan changes (or the wave's run begins inside one)
-        if (r != 0) rows_flush<WITH_LOSS>(q, M, acc);
-        rows_plane_setup(P.R, P.t, readlane_d(dv, 0), readlane_d(dv, 1), readlane_d(dv, 2), readlane_d(dv, 3),
-                         readlane_d(dv, 4), q);
-        rows_moments_reset<WITH_LOSS>(M);
+        if (r != 0) pol.flush(acc);
+        pol.begin_scan(P, readlane_d(dv, 0), readlane_d(dv, 1), readlane_d(dv, 2), readlane_d(dv, 3), readlane_d(dv, 4));
       }
-      if (lane < count) rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M);
+      if (lane < count) pol.point(v[0], v[1]);
     }
   }
-  if (n > 0) rows_flush<WITH_LOSS>(q, M, acc);
+  if (n > 0) pol.flush(acc);
   return true;
+}
+
+template <bool WITH_LOSS, bool NT, class PoseFn>
+__device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, const RowDesc* __restrict__ desc_all,
+                                            long long r_begin_in, long long r_end_in, const int lane, PoseFn get_pose,
+                                            const double& inv_lf2, double (&acc)[NACC]) {
+  LmRows<WITH_LOSS> pol(inv_lf2);
+  return stream_rows_policy<LmRows<WITH_LOSS>, NT>(pol, xy_all, desc_all, r_begin_in, r_end_in, lane, get_pose, acc);
 }
 
 // ---- upload-time kernels of the row layout (all O(N) work on the device) -------------------------------------
@@ -1566,8 +1627,6 @@ __global__ void wave_reduce_test_kernel(const double* __restrict__ in, double* _
 // products, A^T b: 9.  45 accumulators per lane; same streaming/reduction shape as K1.
 // Output per block: 45 doubles: [bb(6: xx xy x yy y 1)][nn(6: 00 01 02 11 12 22)] then 9.
 // ---------------------------------------------------------------------------------------
-constexpr int NACC9 = 45;
-
 __device__ __forceinline__ void accumulate_normal9(double nx, double ny, double nz, double d,
                                                    double x, double y, double (&acc)[NACC9]) {
   const double nn[6] = {nx * nx, nx * ny, nx * nz, ny * ny, ny * nz, nz * nz};
@@ -1621,18 +1680,73 @@ __global__ __launch_bounds__(BLOCK) void normal9_kernel(const double* __restrict
   }
 }
 
+// Fixed-order sum of the 45-column block partials.  Thread (c, rg) sums rows rg, rg + 4, ... of column c with 16 independent
+// loads in flight per round (a dependent load chain over 256 rows cost 16 us here — more than K5 itself), then the four
+// row groups are combined in order.
 __global__ __launch_bounds__(BLOCK) void reduce9_kernel(const double* __restrict__ partials,
                                                         int n_blocks, double* __restrict__ out) {
-  // 45 columns: thread c < 45 of each of 4 row groups (64 threads per group)
   __shared__ double red[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  constexpr int UNROLL = 16;
   double s = 0.0;
-  if (c < NACC9)
-    for (int b = rg; b < n_blocks; b += 4) s += partials[(size_t)b * NACC9 + c];
+  if (c < NACC9) {
+    for (int b0 = rg; b0 < n_blocks; b0 += 4 * UNROLL) {
+      double v[UNROLL];
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) {
+        const int b = b0 + 4 * j;
+        v[j] = (b < n_blocks) ? partials[(size_t)b * NACC9 + c] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < UNROLL; ++j) s += v[j];
+    }
+  }
   red[rg][c] = s;
   __syncthreads();
   if (threadIdx.x < NACC9)
     out[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// K5 on the row layout: 16 B/point instead of 48 of the 64-byte tiles, 5 FP64 instructions per point.
+// Wave reduction of the 45 accumulators: 45 -> 23 registers with one permlane32 swap round, then xor-shuffles.
+template <bool NT>
+__global__ __launch_bounds__(BLOCK) void normal9_rows_kernel(const double* __restrict__ xy, const RowDesc* __restrict__ desc,
+                                                             const long long n_rows, double* __restrict__ partials) {
+  double acc[NACC9];
+#pragma unroll
+  for (int i = 0; i < NACC9; ++i) acc[i] = 0.0;
+  const int lane = threadIdx.x & 63;
+  const WaveMap wm = make_wave_map<BLOCK>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
+  Normal9Rows pol;
+  stream_rows_policy<Normal9Rows, NT>(pol, xy, desc, wm.begin(n_rows), wm.end(n_rows), lane,
+                                      [](PoseU&) { return true; }, acc);
+  __shared__ double wsum[BLOCK / 64][NACC9 + 1];
+  // halves: after the swap, lanes 0-31 hold acc[i] of {l, l+32} summed, lanes 32-63 acc[i+23]
+  double r[23];
+#pragma unroll
+  for (int i = 0; i < 23; ++i) {
+    double x = acc[i], y = (i + 23 < NACC9) ? acc[i + 23] : 0.0;
+    swap_halves(x, y);
+    r[i] = x + y;
+  }
+#pragma unroll
+  for (int i = 0; i < 23; ++i) {
+    double v = r[i];
+    v += dpp_read<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_read<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_read<0x141>(v);  // row_half_mirror
+    v += dpp_read<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
+    v += __shfl_xor(v, 16, 64);  // the two rows of each half
+    if (lane == 0) wsum[threadIdx.x >> 6][i] = v;
+    if (lane == 32 && i + 23 < NACC9 + 1) wsum[threadIdx.x >> 6][i + 23] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC9) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) s += wsum[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * NACC9 + threadIdx.x] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------

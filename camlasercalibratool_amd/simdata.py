@@ -343,6 +343,41 @@ def sim_batch(seed: int, n_problems: int, n_poses: int, pts_per_pose: int,
     return probs, gts
 
 
+def sim_degenerate(kind: str, seed: int = 3, n_poses: int = 40, n_rays: int = 60, noise_sigma: float = 0.0) -> ObservationSet:
+    """Unobservable configurations (the closed form's "system unobservable" branch, src/LaseCamCalCeres.cpp:164-181, and
+    the null-space report of the analysis pass, :371-379):
+      "only_pitch"       all boards rotate about one camera axis and move along one (main/calibr_simulation.cpp:50-51):
+                         the normal matrix is numerically (not exactly) singular;
+      "parallel_boards"  every board faces the camera squarely (R_ca = I): plane normal (0, 0, 1) for all poses, six
+                         columns of A are exactly zero, A^T A has exact zero pivots."""
+    rng = np.random.default_rng(seed)
+    P = n_poses
+    if kind == "only_pitch":
+        ang = (rng.random(P) * 2 - 1) * np.pi / 6
+        Rca = rot_zyx(np.zeros(P), ang, np.zeros(P))
+        tca = np.stack([np.zeros(P), np.zeros(P), rng.uniform(1, 5, P)], 1)
+    elif kind == "parallel_boards":
+        Rca = np.tile(np.eye(3), (P, 1, 1))
+        tca = np.stack([rng.uniform(-1, 1, P), rng.uniform(-1, 1, P), rng.uniform(1, 5, P)], 1)
+    else:
+        raise ValueError(kind)
+    n, d = _plane_in_laser(GT_RLC, GT_TLC, Rca, tca)
+    theta = np.linspace(-0.6, 0.6, n_rays)
+    pts, off = [], [0]
+    for i in range(P):
+        den = np.cos(theta) * n[i, 0] + np.sin(theta) * n[i, 1]
+        with np.errstate(divide="ignore"):
+            depth = -d[i] / den
+        if noise_sigma > 0:
+            depth = depth + rng.normal(0, noise_sigma, depth.shape)
+        ok = np.isfinite(depth) & (depth > 0) & (depth < 8)
+        pts.append(np.stack([depth[ok] * np.cos(theta[ok]), depth[ok] * np.sin(theta[ok]), np.zeros(int(ok.sum()))], 1))
+        off.append(off[-1] + int(ok.sum()))
+    off = np.array(off, dtype=np.int64)
+    flat = np.ascontiguousarray(np.concatenate(pts))
+    return ObservationSet(rot_to_quat_wxyz(Rca), tca, off, flat, off.copy(), flat.copy())
+
+
 # ----------------------------------------------------------------------------------
 # C3/C4 shards: problem k is a pure function of (seed, k), vectorised over problems
 # ----------------------------------------------------------------------------------

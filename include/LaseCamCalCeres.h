@@ -177,14 +177,19 @@ inline void CamLaserCalClosedSolution(const std::vector<Oberserve> obs, Eigen::M
     clc_adapter::Handle H;
     if (!H.h) return;
     double T[16]; int unobservable = 0;
-    if (clc_upload(H.h, rec.data(), rec.size()) != CLC_OK || clc_closed_form(H.h, T, &unobservable, NULL) != CLC_OK) {
+    if (clc_upload(H.h, rec.data(), rec.size()) != CLC_OK) {
         std::cerr << "[clc] " << clc_last_error() << std::endl;
         return;
     }
-    if (unobservable) {  // :173-178
+    const int rc = clc_closed_form(H.h, T, &unobservable, NULL);
+    if (unobservable) {  // :173-178 — printed whatever follows: the reference goes on to solve and return a Tlc
         std::cout <<std::endl<< "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl;
         std::cout << " Notice Notice Notice: system unobservable !!!!!!!" << std::endl;
         std::cout << "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl<<std::endl;
+    }
+    if (rc != CLC_OK) {  // only a non-finite result (the pivoted LDLT / SVD back end is defined for singular input)
+        std::cerr << "[clc] " << clc_last_error() << std::endl;
+        return;
     }
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tlc(i, j) = T[4 * i + j];  // :198-200
     std::cout <<"------- Closed-form solution Tlc: -------\n" << Tlc <<std::endl;      // :202

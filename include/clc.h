@@ -33,7 +33,8 @@ extern "C" {
 #define CLC_ERR_EMPTY_SCAN (-4) /* boundary mode on an empty `points` (reference throws
                                    std::out_of_range at src/LaseCamCalCeres.cpp:278)         */
 #define CLC_ERR_NO_DATA (-5)    /* solve/eval before upload                                 */
-#define CLC_ERR_LINALG (-6)     /* 9x9 closed-form solve failed (rank deficient)             */
+#define CLC_ERR_LINALG (-6)     /* (reserved; round 1 returned it for a rank-deficient 9x9 closed-form
+                                   system — the pivoted LDLT back end now solves those like the reference) */
 #define CLC_ERR_NO_DEVICE (-7)  /* no gfx950 device / HIP runtime unavailable                */
 #define CLC_ERR_COMM (-8)       /* RCCL unavailable or a collective failed: see clc_last_error() */
 
@@ -207,8 +208,11 @@ int clc_information(clc_handle* h, const double pose[7], double H[36], double b[
 /* ---- closed-form initialiser ------------------------------------------------------------
  * CamLaserCalClosedSolution, src/LaseCamCalCeres.cpp:112-203, on the uploaded
  * points_on_line records (uses n, d, p.x, p.y only, :147): device reduction of the 9x9
- * normal equation, host 9x9 solve + nearest-rotation projection.  Tlc[16] row-major 4x4;
- * *unobservable = 1 if any singular value of A^T A < 1e-10 (:164-171); sv9 nullable. */
+ * normal equation (16 bytes per point on the row layout), host 9x9 pivoted LDL^T solve (Eigen's ldlt(),
+ * :181, pseudo-inverse of D) + U V^T of the 3x3 SVD (:195-196).  Tlc[16] row-major 4x4;
+ * *unobservable = 1 if any singular value of A^T A < 1e-10 (:164-171) — like the reference the
+ * function then still returns the Tlc the factorisations give (CLC_ERR_NONFINITE only if that is not
+ * finite; *unobservable is set either way); sv9 nullable. */
 int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9[9]);
 
 /* ---- batched independent problems ---------------------------------------------------------

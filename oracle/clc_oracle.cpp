@@ -896,9 +896,10 @@ void oracle_information(const double* obs, long long N, const double pose[7], do
 }
 
 // -------------------------------------------------------------------------------------
-// 3x3 SVD helper via eigen-decomposition of M^T M (polar factor U V^T is all we need:
-// LaseCamCalCeres.cpp:195-196 — "nearest rotation", no determinant check).
-// Returns Q = U V^T = M (M^T M)^{-1/2}.
+// U V^T of the singular value decomposition M = U S V^T of a 3x3 matrix
+// (LaseCamCalCeres.cpp:195-196 — "nearest rotation", no determinant check).  V, S^2 from the
+// eigen-decomposition of M^T M; U column by column as M v / sigma; columns with sigma = 0 (rank
+// deficient M) are filled in so that U is orthogonal, as a full SVD guarantees.
 // -------------------------------------------------------------------------------------
 static void polar_orthogonal3(const double M[9], double Q[9]) {
   double MtM[9];
@@ -908,59 +909,81 @@ static void polar_orthogonal3(const double M[9], double Q[9]) {
       for (int k = 0; k < 3; ++k) s += M[3 * k + i] * M[3 * k + j];
       MtM[3 * i + j] = s;
     }
-  double w[3], V[9];
-  jacobi_eig_sym(MtM, 3, w, V);
-  // (M^T M)^{-1/2} = V diag(1/sqrt(w)) V^T
-  double P[9];
+  double w[3], V[9], U[9];
+  jacobi_eig_sym(MtM, 3, w, V);  // descending
+  const double cutoff = 1e-14 * std::sqrt(w[0] > 0.0 ? w[0] : 0.0);
+  int rank = 0;
+  for (int c = 0; c < 3; ++c) {
+    double u[3];
+    for (int r = 0; r < 3; ++r) u[r] = (M[3 * r] * V[c] + M[3 * r + 1] * V[3 + c]) + M[3 * r + 2] * V[6 + c];
+    const double len = std::sqrt((u[0] * u[0] + u[1] * u[1]) + u[2] * u[2]);
+    if (!(len > cutoff) || len == 0.0) break;  // sorted: the rest vanish too
+    for (int r = 0; r < 3; ++r) U[3 * r + c] = u[r] / len;
+    ++rank;
+  }
+  if (rank == 0) { U[0] = 1.0; U[3] = 0.0; U[6] = 0.0; rank = 1; }
+  if (rank == 1) {  // a unit vector orthogonal to column 0: cross with the axis it is least aligned with
+    const double a[3] = {U[0], U[3], U[6]};
+    int m = 0;
+    if (std::fabs(a[1]) < std::fabs(a[m])) m = 1;
+    if (std::fabs(a[2]) < std::fabs(a[m])) m = 2;
+    double e[3] = {0.0, 0.0, 0.0}, c[3];
+    e[m] = 1.0;
+    cross3(a, e, c);
+    const double len = std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+    for (int r = 0; r < 3; ++r) U[3 * r + 1] = c[r] / len;
+    rank = 2;
+  }
+  if (rank == 2) {
+    const double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
+    double c[3];
+    cross3(a, b, c);
+    for (int r = 0; r < 3; ++r) U[3 * r + 2] = c[r];
+  }
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double s = 0.0;
-      for (int k = 0; k < 3; ++k) s += V[3 * i + k] * (1.0 / std::sqrt(w[k])) * V[3 * j + k];
-      P[3 * i + j] = s;
-    }
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double s = 0.0;
-      for (int k = 0; k < 3; ++k) s += M[3 * i + k] * P[3 * k + j];
-      Q[3 * i + j] = s;
-    }
+    for (int j = 0; j < 3; ++j) Q[3 * i + j] = (U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1]) + U[3 * i + 2] * V[3 * j + 2];
 }
 
-// LDLT-free 9x9 SPD solve (AtA.ldlt().solve at :181; for SPD input LDLT == Cholesky up
-// to pivoting order, solution identical to rounding).
-static bool chol_solve_n(const double* A, const double* b, double* x, int n) {
-  double L[81];
-  for (int i = 0; i < n * n; ++i) L[i] = 0.0;
-  for (int j = 0; j < n; ++j) {
-    double d = A[j * n + j];
-    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
-    if (!(d > 0.0)) return false;
-    L[j * n + j] = std::sqrt(d);
-    for (int i = j + 1; i < n; ++i) {
-      double s = A[i * n + j];
-      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
-      L[i * n + j] = s / L[j * n + j];
+// AtA.ldlt().solve at :181.  Eigen::LDLT is a Cholesky factorisation with symmetric pivoting on the
+// largest remaining diagonal entry, P A P^T = L D L^T, whose solve uses the pseudo-inverse of D
+// (a zero pivot yields a zero component) — defined for semi-definite matrices as well, which is
+// what the reference relies on when it carries on after the "system unobservable" notice.
+static void ldlt_pivoted_solve(const double* A_in, const double* rhs, double* x, int n) {
+  std::vector<double> A(A_in, A_in + n * n), D(n), y(n);
+  std::vector<int> p(n);
+  for (int i = 0; i < n; ++i) p[i] = i;
+  for (int k = 0; k < n; ++k) {
+    int best = k;
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(A[i * n + i]) > std::fabs(A[best * n + best])) best = i;
+    if (best != k) {
+      for (int j = 0; j < n; ++j) std::swap(A[k * n + j], A[best * n + j]);
+      for (int i = 0; i < n; ++i) std::swap(A[i * n + k], A[i * n + best]);
+      std::swap(p[k], p[best]);
+    }
+    double dk = A[k * n + k];
+    for (int j = 0; j < k; ++j) dk -= A[k * n + j] * A[k * n + j] * D[j];
+    D[k] = dk;
+    for (int i = k + 1; i < n; ++i) {
+      double v = A[i * n + k];
+      for (int j = 0; j < k; ++j) v -= A[i * n + j] * A[k * n + j] * D[j];
+      A[i * n + k] = dk != 0.0 ? v / dk : 0.0;
     }
   }
-  double z[9];
-  for (int i = 0; i < n; ++i) {
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[i * n + k] * z[k];
-    z[i] = s / L[i * n + i];
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    double s = z[i];
-    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
-    x[i] = s / L[i * n + i];
-  }
-  return true;
+  for (int i = 0; i < n; ++i) y[i] = rhs[p[i]];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j) y[i] -= A[i * n + j] * y[j];
+  for (int i = 0; i < n; ++i) y[i] = std::fabs(D[i]) > 2.2250738585072014e-308 ? y[i] / D[i] : 0.0;
+  for (int i = n - 1; i >= 0; --i)
+    for (int j = i + 1; j < n; ++j) y[i] -= A[j * n + i] * y[j];
+  for (int i = 0; i < n; ++i) x[p[i]] = y[i];
 }
 
 // -------------------------------------------------------------------------------------
 // CamLaserCalClosedSolution — src/LaseCamCalCeres.cpp:112-203.
 // Input: records of the points_on_line observations ({n,d,p,scale}; only n,d,p.x,p.y
 // are used, :147).  Output Tlc[16] row-major 4x4, unobservable flag (:164-171),
-// sv9[9] singular values of AtA.  Returns 0, or -1 if the 9x9 solve fails.
+// sv9[9] singular values of AtA.  Returns 0 (like the reference it always produces a Tlc).
 // -------------------------------------------------------------------------------------
 int oracle_closed_form(const double* obs, long long N, double Tlc[16], int* unobservable,
                        double sv9[9]) {
@@ -985,7 +1008,7 @@ int oracle_closed_form(const double* obs, long long N, double Tlc[16], int* unob
   for (int i = 0; i < 9; ++i)
     if (sv9[i] < 1e-10) *unobservable = 1;  // :167
   double Hh[9];
-  if (!chol_solve_n(AtA, Atb, Hh, 9)) return -1;  // :181
+  ldlt_pivoted_solve(AtA, Atb, Hh, 9);  // :181
   const double* h1 = Hh; const double* h2 = Hh + 3; const double* h3 = Hh + 6;
   double h12[3];
   cross3(h1, h2, h12);

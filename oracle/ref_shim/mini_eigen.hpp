@@ -604,21 +604,34 @@ typename MatrixBase<D>::PlainObject MatrixBase<D>::inverse() const {
   return PlainObject(inv);
 }
 
-// LDL^T without pivoting (the reference only factors symmetric positive definite normal matrices)
+// LDL^T with symmetric pivoting on the largest remaining diagonal entry and a pseudo-inverse of D in solve() — what
+// Eigen documents for LDLT ("robust Cholesky decomposition of a matrix with pivoting"; positive or negative
+// SEMI-definite input allowed): the reference calls it on a normal matrix it has just reported as unobservable
+// (LaseCamCalCeres.cpp:173-181), so the semi-definite case must not divide by zero.
 template <typename M>
 class LDLT {
  public:
   template <typename OD>
-  explicit LDLT(const MatrixBase<OD>& A) : n_(A.rows()), L_(A.rows(), A.rows(), internal::Sized()), d_(A.rows()) {
-    for (Index j = 0; j < n_; ++j) {
-      double d = A.coeff(j, j);
-      for (Index k = 0; k < j; ++k) d -= L_(j, k) * L_(j, k) * d_(k);
-      d_(j) = d;
-      L_(j, j) = 1.0;
-      for (Index i = j + 1; i < n_; ++i) {
-        double s = A.coeff(i, j);
-        for (Index k = 0; k < j; ++k) s -= L_(i, k) * L_(j, k) * d_(k);
-        L_(i, j) = s / d;
+  explicit LDLT(const MatrixBase<OD>& A) : n_(A.rows()), L_(A.rows(), A.rows(), internal::Sized()), d_(A.rows()), p_((size_t)A.rows()) {
+    for (Index i = 0; i < n_; ++i)
+      for (Index j = 0; j < n_; ++j) L_(i, j) = A.coeff(i, j);
+    for (Index i = 0; i < n_; ++i) p_[(size_t)i] = i;
+    for (Index k = 0; k < n_; ++k) {
+      Index best = k;
+      for (Index i = k + 1; i < n_; ++i)
+        if (std::abs(L_(i, i)) > std::abs(L_(best, best))) best = i;
+      if (best != k) {
+        for (Index j = 0; j < n_; ++j) std::swap(L_(k, j), L_(best, j));
+        for (Index i = 0; i < n_; ++i) std::swap(L_(i, k), L_(i, best));
+        std::swap(p_[(size_t)k], p_[(size_t)best]);
+      }
+      double d = L_(k, k);
+      for (Index j = 0; j < k; ++j) d -= L_(k, j) * L_(k, j) * d_(j);
+      d_(k) = d;
+      for (Index i = k + 1; i < n_; ++i) {
+        double s = L_(i, k);
+        for (Index j = 0; j < k; ++j) s -= L_(i, j) * L_(k, j) * d_(j);
+        L_(i, k) = d != 0.0 ? s / d : 0.0;
       }
     }
   }
@@ -626,11 +639,14 @@ class LDLT {
   Matrix<double, Dynamic, traits<OD>::Cols> solve(const MatrixBase<OD>& b) const {
     Matrix<double, Dynamic, traits<OD>::Cols> x(b);
     for (Index c = 0; c < x.cols(); ++c) {
+      std::vector<double> y((size_t)n_);
+      for (Index i = 0; i < n_; ++i) y[(size_t)i] = b.coeff(p_[(size_t)i], c);
       for (Index i = 0; i < n_; ++i)
-        for (Index k = 0; k < i; ++k) x(i, c) -= L_(i, k) * x(k, c);
-      for (Index i = 0; i < n_; ++i) x(i, c) /= d_(i);
+        for (Index k = 0; k < i; ++k) y[(size_t)i] -= L_(i, k) * y[(size_t)k];
+      for (Index i = 0; i < n_; ++i) y[(size_t)i] = std::abs(d_(i)) > 2.2250738585072014e-308 ? y[(size_t)i] / d_(i) : 0.0;
       for (Index i = n_ - 1; i >= 0; --i)
-        for (Index k = i + 1; k < n_; ++k) x(i, c) -= L_(k, i) * x(k, c);
+        for (Index k = i + 1; k < n_; ++k) y[(size_t)i] -= L_(k, i) * y[(size_t)k];
+      for (Index i = 0; i < n_; ++i) x(p_[(size_t)i], c) = y[(size_t)i];
     }
     return x;
   }
@@ -639,6 +655,7 @@ class LDLT {
   Index n_;
   MatrixXd L_;
   VectorXd d_;
+  std::vector<Index> p_;
 };
 template <typename D>
 LDLT<Matrix<typename MatrixBase<D>::Scalar, Dynamic, Dynamic>> MatrixBase<D>::ldlt() const {
@@ -699,6 +716,29 @@ class JacobiSVD {
       s_(k) = sv[(size_t)j];
       for (Index i = 0; i < m; ++i) U_(i, k) = sv[(size_t)j] > 0 ? W(i, j) / sv[(size_t)j] : 0.0;
       for (Index i = 0; i < n; ++i) V_(i, k) = V(i, j);
+    }
+    // Eigen's U is unitary whatever the rank: columns of vanishing singular values are completed to an orthonormal
+    // basis (Gram-Schmidt of the canonical vectors against the columns found so far)
+    const double cutoff = n > 0 ? 1e-14 * s_(0) : 0.0;
+    for (Index k = 0; k < n && k < m; ++k) {
+      if (s_(k) > cutoff && s_(k) > 0.0) continue;
+      double best_len = -1.0;
+      std::vector<double> best((size_t)m, 0.0);
+      for (Index e = 0; e < m; ++e) {
+        std::vector<double> v((size_t)m, 0.0);
+        v[(size_t)e] = 1.0;
+        for (Index c = 0; c < n; ++c) {
+          if (c == k || (c > k && !(s_(c) > cutoff && s_(c) > 0.0))) continue;
+          double dot = 0.0;
+          for (Index i = 0; i < m; ++i) dot += U_(i, c) * v[(size_t)i];
+          for (Index i = 0; i < m; ++i) v[(size_t)i] -= dot * U_(i, c);
+        }
+        double len = 0.0;
+        for (Index i = 0; i < m; ++i) len += v[(size_t)i] * v[(size_t)i];
+        if (len > best_len) { best_len = len; best = v; }
+      }
+      const double nrm = std::sqrt(best_len);
+      for (Index i = 0; i < m; ++i) U_(i, k) = best[(size_t)i] / nrm;
     }
   }
   const VectorXd& singularValues() const { return s_; }

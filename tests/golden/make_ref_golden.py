@@ -70,6 +70,14 @@ for seed, noise in [(0, 0.0), (1, 0.01), (4, 0.01), (7, 0.03)]:
     S = sd.GenerateSimData(seed, noise_sigma=noise)
     G["closed_solution"].append(dict(generator="GenerateSimData", seed=seed, noise=noise, Tlc=ref.closed_solution(S).tolist()))
 
+# unobservable inputs: the reference prints its notice and STILL returns what LDLT + SVD give (:173-200)
+G["closed_solution_degenerate"] = []
+for kind in ("parallel_boards", "only_pitch"):
+    S = sd.sim_degenerate(kind)
+    T = ref.closed_solution(S)
+    G["closed_solution_degenerate"].append(dict(kind=kind, Tlc=[[float(v) if np.isfinite(v) else str(v) for v in row] for row in T],
+                                                notice_printed="system unobservable" in ref.last_stdout()))
+
 for gen, seed, noise, lf, bd, init in [("GenerateSimData", 0, 0.0, False, False, "identity"), ("GenerateSimData", 1, 0.01, False, False, "identity"),
                                        ("GenerateSimData", 2, 0.03, False, False, "identity"), ("GenerateSimData", 3, 0.01, True, False, "identity"),
                                        ("GenerateSimData", 5, 0.01, False, False, "closed_form"), ("sim_board_edges", 11, 0.002, True, True, "near_gt"),

@@ -78,6 +78,23 @@ def test_oracle_closed_form_matches_reference_function(oracle_mod, case):
     assert np.abs(T - np.array(case["Tlc"])).max() < 1e-11  # different SVD / LDLT algorithms behind the same formulas
 
 
+@pytest.mark.parametrize("case", G["closed_solution_degenerate"], ids=lambda c: c["kind"])
+def test_oracle_closed_form_on_unobservable_input_behaves_like_the_reference(oracle_mod, case):
+    """src/LaseCamCalCeres.cpp:164-200 on a rank-deficient normal matrix: the reference prints its "system unobservable"
+    notice and still returns LDLT + SVD output.  The oracle flags the same, returns a finite Tlc with an orthogonal
+    rotation block; what the data determine (the translation h3-part and the rows of R not completed by the SVD of a
+    rank-deficient matrix) agrees with the reference's output."""
+    S = sd.sim_degenerate(case["kind"])
+    T, unobservable, sv9 = oracle_mod.closed_form(oracle_mod.flatten(S, True, False))
+    Tref = np.array([[_f(v) for v in row] for row in case["Tlc"]])
+    assert case["notice_printed"] and unobservable and (sv9 < 1e-10).any()
+    assert np.isfinite(T).all() and np.isfinite(Tref).all()
+    for M in (T, Tref):
+        assert np.abs(M[:3, :3] @ M[:3, :3].T - np.eye(3)).max() < 1e-12
+    assert np.abs(T[:, 3] - Tref[:, 3]).max() < 1e-9
+    assert np.abs(np.abs(T[:3, :3]) - np.abs(Tref[:3, :3])).max() < 1e-9  # completed columns may differ in sign
+
+
 @pytest.mark.parametrize("case", G["calibration"], ids=_cal_id)
 def test_oracle_solve_matches_reference_function(oracle_mod, case):
     """CamLaserCalibration as the reference wrote it (assembly loop, factor, loss objects, Plus) vs
@@ -251,6 +268,24 @@ def test_gpu_closed_form_line_fit_scan_match_reference_functions(sv):
         r = np.array([_f(v) for v in c["ranges"]], dtype=np.float32)
         P = sv.scan_to_points(r, np.array([0, r.shape[0]]), c["angle_min"], c["angle_increment"], c["range_min"])
         assert np.abs(P - np.array([[_f(v) for v in row] for row in c["points"]])).max() < 2e-14  # device cos/sin
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G["closed_solution_degenerate"], ids=lambda c: c["kind"])
+def test_gpu_closed_form_on_unobservable_input(sv, oracle_mod, case, capsys):
+    """The HIP path on the same inputs: notice printed, a finite Tlc written (not an error return), equal to the oracle's
+    (same pivoted LDLT / SVD completion rules) and to what the reference's output determines."""
+    S = sd.sim_degenerate(case["kind"])
+    Tlc = np.full((4, 4), 7.0)
+    unobservable, sv9 = clc.CamLaserCalClosedSolution(S, Tlc, solver=sv, verbose=True)
+    out = capsys.readouterr().out
+    assert unobservable and "Notice Notice Notice: system unobservable" in out and "Closed-form solution Tlc" in out
+    To, uo, svo = oracle_mod.closed_form(oracle_mod.flatten(S, True, False))
+    assert uo and np.isfinite(Tlc).all()
+    assert np.abs(Tlc - To).max() < 1e-9
+    assert np.allclose(sv9, svo, rtol=1e-9, atol=1e-6 * svo[0])
+    Tref = np.array([[_f(v) for v in row] for row in case["Tlc"]])
+    assert np.abs(Tlc[:, 3] - Tref[:, 3]).max() < 1e-9
 
 
 @pytest.mark.gpu
