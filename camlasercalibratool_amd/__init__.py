@@ -8,9 +8,9 @@ from .simdata import GenerateSimData, Oberserve, ObservationSet  # noqa: F401
 from ._capi import ClcError, Options, Summary, Iteration, TERMINATION, default_line_options, default_options  # noqa: F401
 from .solver import Solver, SolveResult, flatten_observations  # noqa: F401
 from .calib import (CamLaserCalibration, CamLaserCalClosedSolution, CalibrationReport, LineFittingCeres,  # noqa: F401
-                    points_on_fitted_lines)
+                    Session, points_on_fitted_lines)
 
 __all__ = [
     "CamLaserCalibration", "CamLaserCalClosedSolution", "LineFittingCeres", "Oberserve", "ObservationSet", "GenerateSimData",
-    "Solver", "SolveResult", "Options", "default_options", "flatten_observations", "ClcError",
+    "Session", "Solver", "SolveResult", "Options", "default_options", "flatten_observations", "ClcError",
 ]

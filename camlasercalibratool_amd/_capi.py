@@ -30,6 +30,8 @@ EXPORTED = [
     "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",
     "clc_comm_unique_id", "clc_comm_create", "clc_comm_destroy", "clc_comm_rank", "clc_comm_world",
     "clc_gather_results", "clc_comm_records",
+    "clc_store_observations", "clc_select_observations", "clc_upload_batched_device", "clc_line_fit_batched_device",
+    "clc_scan_to_points_device",
 ]
 
 

@@ -49,57 +49,71 @@ class CalibrationReport:
     null_space: np.ndarray  # [6, n_null]
 
 
+class Session:
+    """The observations of one calibration run resident on the GPU: the pose-major data of std::vector<Oberserve> (tag
+    poses + scan points) is uploaded ONCE; closed form, refinement and the analysis pass — the sequence of
+    main/calibr_offline.cpp:166-170 — then select their residual blocks on the device (clc_select_observations) instead
+    of re-flattening and re-uploading 64-byte records per call.  The module-level functions below are one-call sessions."""
+
+    def __init__(self, obs: ObsLike, solver: Optional[Solver] = None):
+        self.S = _as_set(obs)
+        self.sv = solver or _shared_solver()
+        self.sv.store_observations(self.S)
+
+    def CamLaserCalClosedSolution(self, Tlc: np.ndarray, verbose: bool = True):
+        """Closed-form initialiser; overwrites Tlc (camera->laser) like LaseCamCalCeres.cpp:198-200."""
+        sv = self.sv
+        sv.select_observations(True, False)  # points_on_line only, :143
+        T, unobservable, sv9 = sv.closed_form()
+        if unobservable and verbose:  # :173-178
+            print("\n~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~")
+            print(" Notice Notice Notice: system unobservable !!!!!!!")
+            print("~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~\n")
+        Tlc[...] = T
+        if verbose:
+            print("------- Closed-form solution Tlc: -------\n", Tlc)  # :202
+        return unobservable, sv9
+
+    def CamLaserCalibration(self, Tcl: np.ndarray, use_linefitting_data: bool = True, use_boundary_constraint: bool = False,
+                            options: Optional[Options] = None, verbose: bool = True) -> CalibrationReport:
+        """Nonlinear refinement; Tcl (laser->camera) is in/out like LaseCamCalCeres.cpp:215,:311-314."""
+        sv = self.sv
+        n_rec = sv.select_observations(use_linefitting_data, use_boundary_constraint)
+        pose0 = simdata.pose7_from_T(np.asarray(Tcl, dtype=np.float64))  # :215-219
+        res = sv.solve(pose0, options)
+        if verbose:  # stands in for summary.FullReport(), :309
+            s = res.summary
+            print(f"Solver Summary: iterations {s.num_iterations} (successful {s.num_successful_steps - 1}, "
+                  f"unsuccessful {s.num_unsuccessful_steps}), initial cost {s.initial_cost:.6e}, "
+                  f"final cost {s.final_cost:.6e}, termination {TERMINATION.get(s.termination)}, "
+                  f"residuals {n_rec}, passes {s.num_evaluations}, time {s.solve_ms:.3f} ms")
+        Tcl[...] = simdata.T_from_pose7(res.pose)  # :311-314
+        # analysis pass: no loss, no boundary terms (:316-362) — re-selected on the device, nothing crosses PCIe
+        if use_boundary_constraint and use_linefitting_data:
+            sv.select_observations(use_linefitting_data, False)
+        H, b, chi2, svals, V, n_null = sv.information(res.pose)
+        null = V[:, 6 - n_null:] if n_null > 0 else np.zeros((6, 0))
+        if verbose:  # :365-381
+            print("----- H singular values--------:")
+            print(svals)
+            if n_null > 0:
+                print("====== null space basis, it's means the unobservable direction for Tcl ======")
+                print("       please note the unobservable direction is for Tcl, not for Tlc        ")
+                print(null)
+            print("\nrecover chi2: ", chi2 / 2.0)
+        return CalibrationReport(res, H, b, chi2, svals, null)
+
+
 def CamLaserCalClosedSolution(obs: ObsLike, Tlc: np.ndarray, solver: Optional[Solver] = None, verbose: bool = True):
     """Closed-form initialiser; overwrites Tlc (camera->laser) like LaseCamCalCeres.cpp:198-200."""
-    S = _as_set(obs)
-    rec = flatten_observations(S, use_linefitting_data=True, use_boundary_constraint=False)  # points_on_line only, :143
-    sv = solver or _shared_solver()
-    sv.upload(rec)
-    T, unobservable, sv9 = sv.closed_form()
-    if unobservable and verbose:  # :173-178
-        print("\n~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~")
-        print(" Notice Notice Notice: system unobservable !!!!!!!")
-        print("~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~\n")
-    Tlc[...] = T
-    if verbose:
-        print("------- Closed-form solution Tlc: -------\n", Tlc)  # :202
-    return unobservable, sv9
+    return Session(obs, solver).CamLaserCalClosedSolution(Tlc, verbose)
 
 
 def CamLaserCalibration(obs: ObsLike, Tcl: np.ndarray, use_linefitting_data: bool = True,
                         use_boundary_constraint: bool = False, options: Optional[Options] = None,
                         solver: Optional[Solver] = None, verbose: bool = True) -> CalibrationReport:
     """Nonlinear refinement; Tcl (laser->camera) is in/out like LaseCamCalCeres.cpp:215,:311-314."""
-    S = _as_set(obs)
-    rec = flatten_observations(S, use_linefitting_data, use_boundary_constraint)
-    pose0 = simdata.pose7_from_T(np.asarray(Tcl, dtype=np.float64))  # :215-219
-    sv = solver or _shared_solver()
-    sv.upload(rec)
-    res = sv.solve(pose0, options)
-    if verbose:  # stands in for summary.FullReport(), :309
-        s = res.summary
-        print(f"Solver Summary: iterations {s.num_iterations} (successful {s.num_successful_steps - 1}, "
-              f"unsuccessful {s.num_unsuccessful_steps}), initial cost {s.initial_cost:.6e}, "
-              f"final cost {s.final_cost:.6e}, termination {TERMINATION.get(s.termination)}, "
-              f"residuals {rec.shape[0]}, passes {s.num_evaluations}, time {s.solve_ms:.3f} ms")
-    Tcl[...] = simdata.T_from_pose7(res.pose)  # :311-314
-    # analysis pass: no loss, no boundary terms (:316-362)
-    rec_pts = rec if not (use_boundary_constraint and use_linefitting_data) else flatten_observations(
-        S, use_linefitting_data, False)
-    if rec_pts is not rec:
-        sv.upload(rec_pts)
-    H, b, chi2, svals, V, n_null = sv.information(res.pose)
-
-    null = V[:, 6 - n_null:] if n_null > 0 else np.zeros((6, 0))
-    if verbose:  # :365-381
-        print("----- H singular values--------:")
-        print(svals)
-        if n_null > 0:
-            print("====== null space basis, it's means the unobservable direction for Tcl ======")
-            print("       please note the unobservable direction is for Tcl, not for Tlc        ")
-            print(null)
-        print("\nrecover chi2: ", chi2 / 2.0)
-    return CalibrationReport(res, H, b, chi2, svals, null)
+    return Session(obs, solver).CamLaserCalibration(Tcl, use_linefitting_data, use_boundary_constraint, options, verbose)
 
 
 def LineFittingCeres(Points: np.ndarray, Line: np.ndarray, solver: Optional[Solver] = None,

@@ -98,6 +98,14 @@ struct clc_handle {
   size_t rdesc_cap_bytes = 0;
   long long n_rows = 0;
   bool rows_ok = false;
+  // resident pose-major scans (clc_store_observations): device copies + the host-side CSR offsets
+  double* d_sq = nullptr; size_t sq_cap = 0;     // tag_q (w,x,y,z) [P*4]
+  double* d_st = nullptr; size_t st_cap = 0;     // tag_t [P*3]
+  double* d_spts = nullptr; size_t spts_cap = 0; // points [M*3]
+  double* d_sptl = nullptr; size_t sptl_cap = 0; // points_on_line [ML*3]
+  double* d_soff = nullptr; size_t soff_cap = 0; // pts_off [P+1], ptl_off [P+1], rec_off [P+1] as long long
+  std::vector<long long> s_pts_off, s_ptl_off;
+  int store_poses = -1;                          // -1: nothing stored
   // launch geometry
   int grid_override = 0;
   int launch_flags = kDefaultLaunchFlags;
@@ -573,7 +581,7 @@ void clc_destroy(clc_handle* h) {
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_block, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
                   h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results,
-                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->d_prob_row};
+                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -653,6 +661,117 @@ int clc_upload(clc_handle* h, const clc_observation* records, size_t n) {
     CLC_HIP(hipMemcpy(aos.p, records, n * sizeof(clc_observation), hipMemcpyHostToDevice));
   }
   return clc_upload_device(h, reinterpret_cast<const clc_observation*>(aos.p), n);
+}
+
+// ---- resident scans + device-side problem assembly ---------------------------------------------------------------
+namespace {
+
+int grow(double** p, size_t* cap, size_t bytes) { return ensure_bytes(p, cap, std::max<size_t>(bytes, 8)); }
+
+// per-pose record offsets of a selection (host, O(poses)); CLC_ERR_EMPTY_SCAN mirrors the reference's .at(0) throw
+int selection_offsets(const clc_handle* h, bool linefit, bool boundary, std::vector<long long>* rec_off) {
+  const int P = h->store_poses;
+  rec_off->assign((size_t)P + 1, 0);
+  const std::vector<long long>& off = linefit ? h->s_ptl_off : h->s_pts_off;
+  for (int i = 0; i < P; ++i) {
+    long long c = off[(size_t)i + 1] - off[(size_t)i];
+    if (boundary && linefit) {
+      if (h->s_pts_off[(size_t)i + 1] - h->s_pts_off[(size_t)i] <= 0) return CLC_ERR_EMPTY_SCAN;
+      c += 2;
+    }
+    (*rec_off)[(size_t)i + 1] = (*rec_off)[(size_t)i] + c;
+  }
+  return CLC_OK;
+}
+
+// builds the records of the selection on the device into *aos (allocated here)
+int flatten_on_device(clc_handle* h, bool linefit, bool boundary, DevBuf<double>* aos, long long* n_out) {
+  if (h->store_poses < 0) return fail(CLC_ERR_NO_DATA, "clc_select_observations: no scans stored (clc_store_observations)");
+  std::vector<long long> rec_off;
+  const int rc = selection_offsets(h, linefit, boundary, &rec_off);
+  if (rc == CLC_ERR_EMPTY_SCAN)
+    return fail(rc, "clc_select_observations: boundary constraint on an empty scan (reference: std::out_of_range at LaseCamCalCeres.cpp:278)");
+  const int P = h->store_poses;
+  const long long N = rec_off[(size_t)P];
+  *n_out = N;
+  CLC_HIP(aos->alloc((size_t)std::max<long long>(N, 1) * 8));
+  if (N == 0 || P == 0) return CLC_OK;
+  long long* d_off = reinterpret_cast<long long*>(h->d_soff);
+  CLC_HIP(hipMemcpyAsync(d_off + 2 * ((size_t)P + 1), rec_off.data(), sizeof(long long) * ((size_t)P + 1), hipMemcpyHostToDevice,
+                         h->stream));
+  hipLaunchKernelGGL(clc::flatten_kernel, dim3((unsigned)P), dim3(clc::BLOCK), 0, h->stream, P, h->d_sq, h->d_st, d_off,
+                     h->d_spts, d_off + ((size_t)P + 1), h->d_sptl, linefit ? 1 : 0, boundary ? 1 : 0,
+                     d_off + 2 * ((size_t)P + 1), aos->p);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));  // rec_off (host vector) must outlive the copy
+  return CLC_OK;
+}
+
+}  // namespace
+
+int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz, const double* tag_t,
+                           const int64_t* pts_off, const double* pts, const int64_t* ptl_off, const double* ptl) {
+  if (!h || n_poses < 0 || (n_poses > 0 && (!tag_q_wxyz || !tag_t || !pts_off || !ptl_off)))
+    return fail(CLC_ERR_INVALID_ARG, "clc_store_observations: bad argument");
+  const size_t P = (size_t)n_poses;
+  h->store_poses = -1;
+  h->s_pts_off.assign(P + 1, 0);
+  h->s_ptl_off.assign(P + 1, 0);
+  for (size_t i = 0; i <= P && P > 0; ++i) {
+    h->s_pts_off[i] = pts_off[i] - pts_off[0];
+    h->s_ptl_off[i] = ptl_off[i] - ptl_off[0];
+    if (i > 0 && (h->s_pts_off[i] < h->s_pts_off[i - 1] || h->s_ptl_off[i] < h->s_ptl_off[i - 1]))
+      return fail(CLC_ERR_INVALID_ARG, "clc_store_observations: offsets not monotone");
+  }
+  const size_t M = (size_t)h->s_pts_off[P], ML = (size_t)h->s_ptl_off[P];
+  if ((M > 0 && !pts) || (ML > 0 && !ptl)) return fail(CLC_ERR_INVALID_ARG, "clc_store_observations: NULL points");
+  CLC_HIP(hipSetDevice(h->device));
+  int rc = grow(&h->d_sq, &h->sq_cap, P * 4 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_st, &h->st_cap, P * 3 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_spts, &h->spts_cap, M * 3 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_sptl, &h->sptl_cap, ML * 3 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_soff, &h->soff_cap, 3 * (P + 1) * sizeof(long long));
+  if (rc != CLC_OK) return rc;
+  if (P > 0) {
+    CLC_HIP(hipMemcpyAsync(h->d_sq, tag_q_wxyz, P * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CLC_HIP(hipMemcpyAsync(h->d_st, tag_t, P * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    long long* d_off = reinterpret_cast<long long*>(h->d_soff);
+    CLC_HIP(hipMemcpyAsync(d_off, h->s_pts_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    CLC_HIP(hipMemcpyAsync(d_off + (P + 1), h->s_ptl_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  }
+  if (M > 0) CLC_HIP(hipMemcpyAsync(h->d_spts, pts + 3 * pts_off[0], M * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (ML > 0) CLC_HIP(hipMemcpyAsync(h->d_sptl, ptl + 3 * ptl_off[0], ML * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));  // the caller's arrays may go away
+  h->store_poses = n_poses;
+  return CLC_OK;
+}
+
+int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_boundary_constraint, int64_t* n_records) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_select_observations: NULL handle");
+  CLC_HIP(hipSetDevice(h->device));
+  DevBuf<double> aos;
+  long long N = 0;
+  int rc = flatten_on_device(h, use_linefitting_data != 0, use_boundary_constraint != 0, &aos, &N);
+  if (rc != CLC_OK) return rc;
+  if (n_records) *n_records = (int64_t)N;
+  return clc_upload_device(h, reinterpret_cast<const clc_observation*>(aos.p), (size_t)N);
+}
+
+// test hook: the device-built records of a selection, copied back (records_out[N*8], N from clc_select_observations)
+int clc_debug_flatten_device(clc_handle* h, int use_linefitting_data, int use_boundary_constraint, double* records_out,
+                             int64_t cap_records, int64_t* n_records) {
+  if (!h || !n_records) return fail(CLC_ERR_INVALID_ARG, "clc_debug_flatten_device: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  DevBuf<double> aos;
+  long long N = 0;
+  int rc = flatten_on_device(h, use_linefitting_data != 0, use_boundary_constraint != 0, &aos, &N);
+  if (rc != CLC_OK) return rc;
+  *n_records = N;
+  if (records_out && N > 0) {
+    if (cap_records < N) return fail(CLC_ERR_INVALID_ARG, "clc_debug_flatten_device: buffer too small");
+    CLC_HIP(hipMemcpy(records_out, aos.p, (size_t)N * 8 * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return CLC_OK;
 }
 
 size_t clc_num_observations(const clc_handle* h) { return h ? h->n_obs : 0; }
@@ -1093,8 +1212,10 @@ int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9
 }
 
 // ---- batched ---------------------------------------------------------------------------
-int clc_upload_batched(clc_handle* h, const clc_observation* records, const int64_t* offsets,
-                       size_t n_problems) {
+namespace {
+// records: host pointer (on_device = false: staged through a temporary device buffer) or device pointer
+int upload_batched_impl(clc_handle* h, const clc_observation* records, bool on_device, const int64_t* offsets,
+                        size_t n_problems) {
   if (!h || !offsets || (n_problems > 0 && !records))
     return fail(CLC_ERR_INVALID_ARG, "clc_upload_batched: bad argument");
   CLC_HIP(hipSetDevice(h->device));
@@ -1145,11 +1266,14 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
   const size_t n_total = (size_t)(offsets[P] - offsets[0]);
   DevBuf<double> baos;
   DevBuf<long long> boff;
-  if (n_total > 0) {
+  double* d_aos = nullptr;
+  if (n_total > 0 && on_device) {
+    d_aos = const_cast<double*>(reinterpret_cast<const double*>(records + offsets[0]));
+  } else if (n_total > 0) {
     CLC_HIP(baos.alloc(n_total * 8));
     CLC_HIP(hipMemcpy(baos.p, records + offsets[0], n_total * sizeof(clc_observation), hipMemcpyHostToDevice));
+    d_aos = baos.p;
   }
-  double* d_aos = n_total > 0 ? baos.p : nullptr;
   std::vector<long long> rel(P + 1);
   for (size_t k = 0; k <= P; ++k) rel[k] = offsets[k] - offsets[0];
   CLC_HIP(boff.alloc(P + 1));
@@ -1173,6 +1297,15 @@ int clc_upload_batched(clc_handle* h, const clc_observation* records, const int6
   if (crc != CLC_OK) return crc;
   h->n_problems = P;
   return CLC_OK;
+}
+}  // namespace
+
+int clc_upload_batched(clc_handle* h, const clc_observation* records, const int64_t* offsets, size_t n_problems) {
+  return upload_batched_impl(h, records, false, offsets, n_problems);
+}
+
+int clc_upload_batched_device(clc_handle* h, const clc_observation* records_dev, const int64_t* offsets, size_t n_problems) {
+  return upload_batched_impl(h, records_dev, true, offsets, n_problems);
 }
 
 size_t clc_num_problems(const clc_handle* h) { return h ? h->n_problems : 0; }
@@ -1348,6 +1481,49 @@ int clc_scan_to_points(clc_handle* h, const float* ranges, const int64_t* offset
                      (int)n_scans, bam.p, bai.p, brm.p, bp.p);
   CLC_HIP(hipGetLastError());
   CLC_HIP(hipMemcpyAsync(points + 3 * offsets[0], bp.p, 3 * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  return CLC_OK;
+}
+
+int clc_line_fit_batched_device(clc_handle* h, const clc_options* opt_in, const double* xy_dev, const int64_t* offsets_dev,
+                                size_t n_scans, double* lines_dev, clc_summary* summaries_dev) {
+  if (!h || (n_scans > 0 && (!offsets_dev || !lines_dev || !xy_dev)))
+    return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched_device: bad argument");
+  clc_options opt;
+  if (opt_in) opt = *opt_in; else clc_line_options_default(&opt);
+  if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched_device: max_num_iterations < 0");
+  if (opt.use_loss && !(opt.loss_scale_factor > 0.0))
+    return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched_device: loss_scale_factor must be > 0");
+  if (n_scans == 0) return CLC_OK;
+  if (n_scans > 0x7FFFFFF0ull) return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched_device: too many scans");
+  CLC_HIP(hipSetDevice(h->device));
+  static_assert(sizeof(long long) == sizeof(int64_t), "offset type");
+  const unsigned blocks = (unsigned)((n_scans + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64));
+  const long long* d_off = reinterpret_cast<const long long*>(offsets_dev);
+  if (opt.use_loss)
+    hipLaunchKernelGGL((clc::line_fit_kernel<true>), dim3(blocks), dim3(clc::BLOCK), 0, h->stream, xy_dev, d_off,
+                       (int)n_scans, opt, lines_dev, summaries_dev);
+  else
+    hipLaunchKernelGGL((clc::line_fit_kernel<false>), dim3(blocks), dim3(clc::BLOCK), 0, h->stream, xy_dev, d_off,
+                       (int)n_scans, opt, lines_dev, summaries_dev);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  return CLC_OK;
+}
+
+int clc_scan_to_points_device(clc_handle* h, const float* ranges_dev, const int64_t* offsets_dev, size_t n_scans,
+                              size_t n_rays, const float* angle_min_dev, const float* angle_increment_dev,
+                              const float* range_min_dev, double* points_dev) {
+  if (!h || (n_scans > 0 && (!offsets_dev || !angle_min_dev || !angle_increment_dev || !range_min_dev)) ||
+      (n_rays > 0 && (!ranges_dev || !points_dev || n_scans == 0)))
+    return fail(CLC_ERR_INVALID_ARG, "clc_scan_to_points_device: bad argument");
+  if (n_rays == 0) return CLC_OK;
+  CLC_HIP(hipSetDevice(h->device));
+  const int threads = 256;
+  hipLaunchKernelGGL(clc::scan_to_points_flat_kernel, dim3((unsigned)((n_rays + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, ranges_dev, reinterpret_cast<const long long*>(offsets_dev), (long long)n_scans,
+                     (long long)n_rays, angle_min_dev, angle_increment_dev, range_min_dev, points_dev);
+  CLC_HIP(hipGetLastError());
   CLC_HIP(hipStreamSynchronize(h->stream));
   return CLC_OK;
 }

@@ -1022,6 +1022,82 @@ __global__ void build_groups_dev_kernel(const double* __restrict__ aos, const lo
   o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[7]; o[5] = 0.0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Residual-block construction on the device (src/LaseCamCalCeres.cpp:222-295) from the pose-major form of
+// std::vector<Oberserve>: tag poses + CSR scan points stay resident (24 B per point crossed PCIe instead of the 64-byte
+// records), and the records of any (use_linefitting_data, use_boundary_constraint) selection are produced here.
+// Every operation is an individually rounded IEEE operation (__dmul_rn / __dadd_rn / __dsub_rn: no FMA contraction), in
+// the order of clc::host::flatten, so the records are bitwise those of the host path (clc_flatten_observations).
+// One workgroup per pose; rec_off[i] = first record of pose i (exclusive prefix of per-pose record counts, host-built:
+// O(poses)).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3_rn(const double* a, const double* b, double* c) {
+  c[0] = __dsub_rn(__dmul_rn(a[1], b[2]), __dmul_rn(a[2], b[1]));
+  c[1] = __dsub_rn(__dmul_rn(a[2], b[0]), __dmul_rn(a[0], b[2]));
+  c[2] = __dsub_rn(__dmul_rn(a[0], b[1]), __dmul_rn(a[1], b[0]));
+}
+
+__device__ __forceinline__ void pi_from_ppp_rn(const double* x1, const double* x2, const double* x3, double* pi) {
+  const double a[3] = {__dsub_rn(x1[0], x3[0]), __dsub_rn(x1[1], x3[1]), __dsub_rn(x1[2], x3[2])};
+  const double b[3] = {__dsub_rn(x2[0], x3[0]), __dsub_rn(x2[1], x3[1]), __dsub_rn(x2[2], x3[2])};
+  double c12[3];
+  cross3_rn(a, b, pi);
+  cross3_rn(x1, x2, c12);
+  pi[3] = -__dadd_rn(__dadd_rn(__dmul_rn(x3[0], c12[0]), __dmul_rn(x3[1], c12[1])), __dmul_rn(x3[2], c12[2]));
+}
+
+__global__ __launch_bounds__(BLOCK) void flatten_kernel(const int n_poses, const double* __restrict__ tag_q_wxyz,
+                                                        const double* __restrict__ tag_t, const long long* __restrict__ pts_off,
+                                                        const double* __restrict__ pts, const long long* __restrict__ ptl_off,
+                                                        const double* __restrict__ ptl, const int linefit, const int boundary,
+                                                        const long long* __restrict__ rec_off, double* __restrict__ rec) {
+  const int i = blockIdx.x;
+  if (i >= n_poses) return;
+  // plane of the tag (z_tag = 0) in the camera frame: [R_ca e3 ; -(R_ca e3).t_ca]   (:227-231)
+  const double x = tag_q_wxyz[4 * i + 1], y = tag_q_wxyz[4 * i + 2], z = tag_q_wxyz[4 * i + 3], w = tag_q_wxyz[4 * i];
+  const double tx = __dmul_rn(2.0, x), ty = __dmul_rn(2.0, y), tz = __dmul_rn(2.0, z);
+  const double twx = __dmul_rn(tx, w), twy = __dmul_rn(ty, w), twz = __dmul_rn(tz, w);
+  const double txx = __dmul_rn(tx, x), txy = __dmul_rn(ty, x), txz = __dmul_rn(tz, x);
+  const double tyy = __dmul_rn(ty, y), tyz = __dmul_rn(tz, y), tzz = __dmul_rn(tz, z);
+  double R[9];
+  R[0] = __dsub_rn(1.0, __dadd_rn(tyy, tzz)); R[1] = __dsub_rn(txy, twz);                R[2] = __dadd_rn(txz, twy);
+  R[3] = __dadd_rn(txy, twz);                R[4] = __dsub_rn(1.0, __dadd_rn(txx, tzz)); R[5] = __dsub_rn(tyz, twx);
+  R[6] = __dsub_rn(txz, twy);                R[7] = __dadd_rn(tyz, twx);                R[8] = __dsub_rn(1.0, __dadd_rn(txx, tyy));
+  const double t[3] = {tag_t[3 * i], tag_t[3 * i + 1], tag_t[3 * i + 2]};
+  const double n[3] = {R[2], R[5], R[8]};
+  const double d = -__dadd_rn(__dadd_rn(__dmul_rn(n[0], t[0]), __dmul_rn(n[1], t[1])), __dmul_rn(n[2], t[2]));
+  const long long* off = linefit ? ptl_off : pts_off;  // :233-237
+  const double* P = linefit ? ptl : pts;
+  const long long lo = off[i], cnt = off[i + 1] - lo;
+  const double scale = __ddiv_rn(1.0, __dsqrt_rn((double)cnt));  // :239-240
+  double* out = rec + 8 * rec_off[i];
+  for (long long j = threadIdx.x; j < cnt; j += blockDim.x) {
+    double* o = out + 8 * j;
+    const double* p = P + 3 * (lo + j);
+    o[0] = n[0]; o[1] = n[1]; o[2] = n[2]; o[3] = d;
+    o[4] = p[0]; o[5] = p[1]; o[6] = p[2]; o[7] = scale;
+  }
+  if (boundary && linefit && threadIdx.x == 0) {  // :258-294 (the host checked that the scan is not empty, :278)
+    const double orig = 0.0265 + 0.0165;  // :262
+    const double pm[3][3] = {{0.0 - orig, 0.0 - orig, 0.0}, {0.5 - orig, 0.0 - orig, 0.0}, {0.0 - orig, 0.5 - orig, 0.0}};
+    double pc[3][3];
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 3; ++a)  // :270-272
+        pc[k][a] = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(R[3 * a], pm[k][0]), __dmul_rn(R[3 * a + 1], pm[k][1])),
+                                       __dmul_rn(R[3 * a + 2], pm[k][2])), t[a]);
+    const double zero[3] = {0.0, 0.0, 0.0};
+    double pi1[4], pi2[4];
+    pi_from_ppp_rn(pc[0], pc[1], zero, pi1);  // :275
+    pi_from_ppp_rn(pc[0], pc[2], zero, pi2);  // :276
+    const double* front = pts + 3 * pts_off[i];           // obi.points.at(0), :278
+    const double* back = pts + 3 * (pts_off[i + 1] - 1);  // obi.points.at(size-1), :279
+    double* a = out + 8 * cnt;
+    a[0] = pi1[0]; a[1] = pi1[1]; a[2] = pi1[2]; a[3] = pi1[3]; a[4] = front[0]; a[5] = front[1]; a[6] = front[2]; a[7] = scale;
+    double* b = a + 8;
+    b[0] = pi2[0]; b[1] = pi2[1]; b[2] = pi2[2]; b[3] = pi2[3]; b[4] = back[0]; b[5] = back[1]; b[6] = back[2]; b[7] = scale;
+  }
+}
+
 // K1 on the row layout: same contract as eval_kernel (one 28-double partial per workgroup).
 template <bool WITH_LOSS, bool NT, int BT, bool WEIGHTED>
 __global__ __launch_bounds__(BT) void eval_rows_kernel(const double* __restrict__ xy, const RowDesc* __restrict__ desc,
@@ -2001,6 +2077,27 @@ __global__ void scan_to_points_kernel(const float* __restrict__ ranges, const lo
     double* p = points + 3 * (lo + i);
     p[0] = x; p[1] = y; p[2] = 0.0;
   }
+}
+
+// The same for device-resident scans of any count: one thread per ray, its scan found by binary search in the offsets.
+__global__ void scan_to_points_flat_kernel(const float* __restrict__ ranges, const long long* __restrict__ off,
+                                           const long long n_scans, const long long n_rays,
+                                           const float* __restrict__ angle_min, const float* __restrict__ angle_inc,
+                                           const float* __restrict__ range_min, double* __restrict__ points) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_rays) return;
+  long long lo = 0, hi = n_scans;  // off[lo] <= k < off[hi]
+  while (hi - lo > 1) {
+    const long long mid = (lo + hi) >> 1;
+    if (off[mid] <= k) lo = mid; else hi = mid;
+  }
+  const long long s = lo, i = k - off[s];
+  const float r = ranges[k];
+  const double th = angle_min[s] + (double)i * angle_inc[s];
+  double x = (double)r * cos(th), y = (double)r * sin(th);
+  if (!(r < 30.0 && r >= range_min[s])) { x = 1000.0; y = 1000.0; }
+  double* p = points + 3 * k;
+  p[0] = x; p[1] = y; p[2] = 0.0;
 }
 
 }  // namespace clc

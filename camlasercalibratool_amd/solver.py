@@ -149,6 +149,34 @@ class Solver:
     def num_observations(self) -> int:
         return int(self._L.clc_num_observations(self._h))
 
+    # ---- resident scans: problem assembly on the device ----
+    def store_observations(self, obs_set):
+        """Upload the pose-major form of std::vector<Oberserve> (tag poses + scan points, 24 B per point) once; it stays
+        resident for any number of select_observations calls."""
+        S = obs_set
+        check(self._L.clc_store_observations(self._h, C.c_int(S.n_poses), dptr(np.ascontiguousarray(S.tag_q, dtype=np.float64)),
+                                             dptr(np.ascontiguousarray(S.tag_t, dtype=np.float64)), iptr(S.pts_off), dptr(S.pts),
+                                             iptr(S.ptl_off), dptr(S.ptl)), "clc_store_observations")
+
+    def select_observations(self, use_linefitting_data: bool = True, use_boundary_constraint: bool = False) -> int:
+        """Build the residual blocks of the selection on the device (src/LaseCamCalCeres.cpp:222-295) and make them the
+        handle's observation array (as upload() would) -> number of records."""
+        n = C.c_int64()
+        check(self._L.clc_select_observations(self._h, C.c_int(int(use_linefitting_data)), C.c_int(int(use_boundary_constraint)),
+                                              C.byref(n)), "clc_select_observations")
+        return n.value
+
+    def debug_flatten_device(self, use_linefitting_data: bool = True, use_boundary_constraint: bool = False) -> np.ndarray:
+        """The device-built records of a selection, copied back (test hook)."""
+        n = C.c_int64()
+        check(self._L.clc_debug_flatten_device(self._h, C.c_int(int(use_linefitting_data)), C.c_int(int(use_boundary_constraint)),
+                                               None, C.c_int64(0), C.byref(n)), "clc_debug_flatten_device")
+        rec = np.empty((n.value, 8))
+        if n.value:
+            check(self._L.clc_debug_flatten_device(self._h, C.c_int(int(use_linefitting_data)), C.c_int(int(use_boundary_constraint)),
+                                                   dptr(rec), C.c_int64(n.value), C.byref(n)), "clc_debug_flatten_device")
+        return rec
+
     # ---- plug-in level ----
     def factor_evaluate(self, pose: np.ndarray, want_jacobian: bool = True):
         n = self.num_observations
@@ -204,6 +232,12 @@ class Solver:
         check(self._L.clc_upload_batched(self._h, dptr(records), iptr(offsets), C.c_size_t(len(offsets) - 1)),
               "clc_upload_batched")
 
+    def upload_batched_device(self, device_ptr: int, offsets: np.ndarray):
+        """records already in HBM as an [N,8] float64 AoS array (ready on the solver's stream); offsets on the host."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        check(self._L.clc_upload_batched_device(self._h, C.c_void_p(device_ptr), iptr(offsets), C.c_size_t(len(offsets) - 1)),
+              "clc_upload_batched_device")
+
     @property
     def num_problems(self) -> int:
         return int(self._L.clc_num_problems(self._h))
@@ -230,6 +264,20 @@ class Solver:
         check(self._L.clc_line_fit_batched(self._h, C.byref(o), dptr(xy), iptr(offsets), C.c_size_t(S), dptr(lines), sm),
               "clc_line_fit_batched")
         return lines, sm
+
+    def line_fit_batched_device(self, xy_ptr: int, offsets_ptr: int, n_scans: int, lines_ptr: int, summaries_ptr: int = 0,
+                                options: Optional[Options] = None):
+        """LineFittingCeres on device-resident arrays (data_ptr()s; ready on the solver's stream)."""
+        o = options or default_line_options()
+        check(self._L.clc_line_fit_batched_device(self._h, C.byref(o), C.c_void_p(xy_ptr), C.c_void_p(offsets_ptr), C.c_size_t(n_scans),
+                                                  C.c_void_p(lines_ptr), C.c_void_p(summaries_ptr or 0)), "clc_line_fit_batched_device")
+
+    def scan_to_points_device(self, ranges_ptr: int, offsets_ptr: int, n_scans: int, n_rays: int, angle_min_ptr: int,
+                              angle_increment_ptr: int, range_min_ptr: int, points_ptr: int):
+        """TranScanToPoints on device-resident arrays (data_ptr()s; ready on the solver's stream)."""
+        check(self._L.clc_scan_to_points_device(self._h, C.c_void_p(ranges_ptr), C.c_void_p(offsets_ptr), C.c_size_t(n_scans),
+                                                C.c_size_t(n_rays), C.c_void_p(angle_min_ptr), C.c_void_p(angle_increment_ptr),
+                                                C.c_void_p(range_min_ptr), C.c_void_p(points_ptr)), "clc_scan_to_points_device")
 
     def scan_to_points(self, ranges: np.ndarray, offsets: np.ndarray, angle_min, angle_increment, range_min) -> np.ndarray:
         """TranScanToPoints (src/utilities.cpp:181-215) for many scans: ranges float32 [M], CSR offsets [S+1],

@@ -169,84 +169,127 @@ inline void LineFittingCeres(const std::vector<Eigen::Vector3d> Points, Eigen::V
     Line(1) = line[1];
 }
 
+namespace clc_adapter {
+
+// The observations of one calibration run resident on the GPU.  The pose-major data of std::vector<Oberserve> (tag
+// poses + scan points, 24 bytes per point) crosses PCIe ONCE (clc_store_observations); the residual blocks of closed
+// form, refinement and analysis pass — the sequence of main/calibr_offline.cpp:166-170 — are then selected on the device
+// (clc_select_observations) instead of being re-flattened into 64-byte records and re-uploaded per call.  The two free
+// functions below, which keep the reference's signatures, are one-call sessions; a caller that owns its main() can hold
+// a Session across the calls:
+//     clc_adapter::Session run(obs);
+//     run.ClosedSolution(Tlc_initial);  Eigen::Matrix4d Tcl = Tlc_initial.inverse();  run.Calibration(Tcl, false);
+class Session {
+ public:
+    explicit Session(const std::vector<Oberserve>& obs) : ok_(false)
+    {
+        const Flat f = flatten(obs);
+        Handle H;
+        if (!H.h) return;
+        const int P = (int)(f.pts_off.size() - 1);
+        if (clc_store_observations(H.h, P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts.data(),
+                                   f.ptl_off.data(), f.ptl.data()) != CLC_OK) {
+            std::cerr << "[clc] " << clc_last_error() << std::endl;
+            return;
+        }
+        ok_ = true;
+    }
+
+    // Closed-form initial guess of Tlc (camera -> laser).  Reference: src/LaseCamCalCeres.cpp:112-203.
+    void ClosedSolution(Eigen::Matrix4d &Tlc)
+    {
+        Handle H;
+        if (!ok_ || !H.h) return;
+        if (clc_select_observations(H.h, /*linefit=*/1, /*boundary=*/0, NULL) != CLC_OK) {  // points_on_line only, :143
+            std::cerr << "[clc] " << clc_last_error() << std::endl;
+            return;
+        }
+        double T[16]; int unobservable = 0;
+        const int rc = clc_closed_form(H.h, T, &unobservable, NULL);
+        if (unobservable) {  // :173-178 — printed whatever follows: the reference goes on to solve and return a Tlc
+            std::cout <<std::endl<< "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl;
+            std::cout << " Notice Notice Notice: system unobservable !!!!!!!" << std::endl;
+            std::cout << "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl<<std::endl;
+        }
+        if (rc != CLC_OK) {  // only a non-finite result (the pivoted LDLT / SVD back end is defined for singular input)
+            std::cerr << "[clc] " << clc_last_error() << std::endl;
+            return;
+        }
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tlc(i, j) = T[4 * i + j];  // :198-200
+        std::cout <<"------- Closed-form solution Tlc: -------\n" << Tlc <<std::endl;      // :202
+    }
+
+    // Nonlinear refinement of Tcl (laser -> camera).  Reference: src/LaseCamCalCeres.cpp:213-383.
+    void Calibration(Eigen::Matrix4d &Tcl, bool use_linefitting_data = true, bool use_boundary_constraint = false)
+    {
+        Handle H;
+        if (!ok_ || !H.h) return;
+        int64_t n_rec = 0;
+        if (clc_select_observations(H.h, use_linefitting_data, use_boundary_constraint, &n_rec) != CLC_OK) {
+            std::cerr << "[clc] " << clc_last_error() << std::endl;  // incl. the reference's std::out_of_range case, :278
+            return;
+        }
+        double R[9], pose[7];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = Tcl(i, j);
+        rot_to_quat_xyzw(R, pose + 3);                                    // :215
+        pose[0] = Tcl(0, 3); pose[1] = Tcl(1, 3); pose[2] = Tcl(2, 3);    // :219
+        clc_options opt; clc_options_default(&opt);                       // DENSE_QR-equivalent, 100 iterations, :302-304
+        clc_summary sum;
+        if (clc_solve(H.h, &opt, pose, &sum, NULL, 0) != CLC_OK) {
+            std::cerr << "[clc] " << clc_last_error() << std::endl;
+            return;
+        }
+        static const char* term[] = {"RUNNING", "CONVERGENCE (gradient)", "CONVERGENCE (parameter)", "CONVERGENCE (function)",
+                                     "CONVERGENCE (radius)", "NO_CONVERGENCE", "FAILURE"};
+        std::cout << "Solver Summary (MI355X HIP backend)\n  Residuals            " << n_rec
+                  << "\n  Initial cost         " << sum.initial_cost << "\n  Final cost           " << sum.final_cost
+                  << "\n  Iterations           " << sum.num_iterations << " (successful " << sum.num_successful_steps - 1
+                  << ", unsuccessful " << sum.num_unsuccessful_steps << ")\n  Evaluation passes    " << sum.num_evaluations
+                  << "\n  Time (ms)            " << sum.solve_ms << "\n  Termination          " << term[sum.termination] << std::endl;  // :309
+
+        // write-back, :311-314 (Quaterniond::toRotationMatrix on the unit quaternion)
+        {
+            const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];
+            const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+            const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+            Tcl(0, 0) = 1 - (tyy + tzz); Tcl(0, 1) = txy - twz;       Tcl(0, 2) = txz + twy;
+            Tcl(1, 0) = txy + twz;       Tcl(1, 1) = 1 - (txx + tzz); Tcl(1, 2) = tyz - twx;
+            Tcl(2, 0) = txz - twy;       Tcl(2, 1) = tyz + twx;       Tcl(2, 2) = 1 - (txx + tyy);
+            Tcl(0, 3) = pose[0]; Tcl(1, 3) = pose[1]; Tcl(2, 3) = pose[2];
+        }
+
+        /// =============================  analysis code (:316-381) ==============================
+        // second pass without loss and without the board-edge terms: re-selected on the device, nothing crosses PCIe
+        if (use_boundary_constraint && use_linefitting_data) {
+            if (clc_select_observations(H.h, use_linefitting_data, 0, NULL) != CLC_OK) return;
+        }
+        double Hm[36], b[6], chi, sv[6], V[36]; int n = 0;
+        if (clc_information(H.h, pose, Hm, b, &chi, sv, V, &n) != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; return; }
+        std::cout << "----- H singular values--------:\n";
+        for (int i = 0; i < 6; ++i) std::cout << sv[i] << "\n";
+        if (n > 0) {
+            std::cout << "====== null space basis, it's means the unobservable direction for Tcl ======" <<std::endl;
+            std::cout << "       please note the unobservable direction is for Tcl, not for Tlc        " <<std::endl;
+            for (int r = 0; r < 6; ++r) { for (int c = 6 - n; c < 6; ++c) std::cout << V[6 * r + c] << " "; std::cout << "\n"; }
+        }
+        std::cout <<"\nrecover chi2: " <<chi / 2. << std::endl;
+    }
+
+ private:
+    bool ok_;
+};
+
+}  // namespace clc_adapter
+
 // Closed-form initial guess of Tlc (camera -> laser).  Reference: src/LaseCamCalCeres.cpp:112-203.
 inline void CamLaserCalClosedSolution(const std::vector<Oberserve> obs, Eigen::Matrix4d &Tlc)
 {
-    std::vector<clc_observation> rec;
-    if (!clc_adapter::records(clc_adapter::flatten(obs), /*linefit=*/true, /*boundary=*/false, rec)) return;  // :143
-    clc_adapter::Handle H;
-    if (!H.h) return;
-    double T[16]; int unobservable = 0;
-    if (clc_upload(H.h, rec.data(), rec.size()) != CLC_OK) {
-        std::cerr << "[clc] " << clc_last_error() << std::endl;
-        return;
-    }
-    const int rc = clc_closed_form(H.h, T, &unobservable, NULL);
-    if (unobservable) {  // :173-178 — printed whatever follows: the reference goes on to solve and return a Tlc
-        std::cout <<std::endl<< "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl;
-        std::cout << " Notice Notice Notice: system unobservable !!!!!!!" << std::endl;
-        std::cout << "~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~~" << std::endl<<std::endl;
-    }
-    if (rc != CLC_OK) {  // only a non-finite result (the pivoted LDLT / SVD back end is defined for singular input)
-        std::cerr << "[clc] " << clc_last_error() << std::endl;
-        return;
-    }
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tlc(i, j) = T[4 * i + j];  // :198-200
-    std::cout <<"------- Closed-form solution Tlc: -------\n" << Tlc <<std::endl;      // :202
+    clc_adapter::Session(obs).ClosedSolution(Tlc);
 }
 
 // Nonlinear refinement of Tcl (laser -> camera).  Reference: src/LaseCamCalCeres.cpp:213-383.
 inline void CamLaserCalibration(const std::vector<Oberserve> obs, Eigen::Matrix4d &Tcl, bool use_linefitting_data = true, bool use_boundary_constraint = false)
 {
-    const clc_adapter::Flat flat = clc_adapter::flatten(obs);
-    std::vector<clc_observation> rec;
-    if (!clc_adapter::records(flat, use_linefitting_data, use_boundary_constraint, rec)) return;
-    double R[9], pose[7];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = Tcl(i, j);
-    clc_adapter::rot_to_quat_xyzw(R, pose + 3);                       // :215
-    pose[0] = Tcl(0, 3); pose[1] = Tcl(1, 3); pose[2] = Tcl(2, 3);    // :219
-
-    clc_adapter::Handle H;
-    if (!H.h) return;
-    clc_options opt; clc_options_default(&opt);                       // DENSE_QR-equivalent, 100 iterations, :302-304
-    clc_summary sum;
-    if (clc_upload(H.h, rec.data(), rec.size()) != CLC_OK || clc_solve(H.h, &opt, pose, &sum, NULL, 0) != CLC_OK) {
-        std::cerr << "[clc] " << clc_last_error() << std::endl;
-        return;
-    }
-    static const char* term[] = {"RUNNING", "CONVERGENCE (gradient)", "CONVERGENCE (parameter)", "CONVERGENCE (function)",
-                                 "CONVERGENCE (radius)", "NO_CONVERGENCE", "FAILURE"};
-    std::cout << "Solver Summary (MI355X HIP backend)\n  Residuals            " << rec.size()
-              << "\n  Initial cost         " << sum.initial_cost << "\n  Final cost           " << sum.final_cost
-              << "\n  Iterations           " << sum.num_iterations << " (successful " << sum.num_successful_steps - 1
-              << ", unsuccessful " << sum.num_unsuccessful_steps << ")\n  Evaluation passes    " << sum.num_evaluations
-              << "\n  Time (ms)            " << sum.solve_ms << "\n  Termination          " << term[sum.termination] << std::endl;  // :309
-
-    // write-back, :311-314 (Quaterniond::toRotationMatrix on the unit quaternion)
-    {
-        const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];
-        const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
-        const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-        Tcl(0, 0) = 1 - (tyy + tzz); Tcl(0, 1) = txy - twz;       Tcl(0, 2) = txz + twy;
-        Tcl(1, 0) = txy + twz;       Tcl(1, 1) = 1 - (txx + tzz); Tcl(1, 2) = tyz - twx;
-        Tcl(2, 0) = txz - twy;       Tcl(2, 1) = tyz + twx;       Tcl(2, 2) = 1 - (txx + tyy);
-        Tcl(0, 3) = pose[0]; Tcl(1, 3) = pose[1]; Tcl(2, 3) = pose[2];
-    }
-
-    /// =============================  analysis code (:316-381) ==============================
-    // second pass without loss and without the board-edge terms
-    if (use_boundary_constraint && use_linefitting_data) {
-        if (!clc_adapter::records(flat, use_linefitting_data, false, rec) || clc_upload(H.h, rec.data(), rec.size()) != CLC_OK) return;
-    }
-    double Hm[36], b[6], chi, sv[6], V[36]; int n = 0;
-    if (clc_information(H.h, pose, Hm, b, &chi, sv, V, &n) != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; return; }
-    std::cout << "----- H singular values--------:\n";
-    for (int i = 0; i < 6; ++i) std::cout << sv[i] << "\n";
-    if (n > 0) {
-        std::cout << "====== null space basis, it's means the unobservable direction for Tcl ======" <<std::endl;
-        std::cout << "       please note the unobservable direction is for Tcl, not for Tlc        " <<std::endl;
-        for (int r = 0; r < 6; ++r) { for (int c = 6 - n; c < 6; ++c) std::cout << V[6 * r + c] << " "; std::cout << "\n"; }
-    }
-    std::cout <<"\nrecover chi2: " <<chi / 2. << std::endl;
+    clc_adapter::Session(obs).Calibration(Tcl, use_linefitting_data, use_boundary_constraint);
 }
 #endif //PROJECT_LASECAMCALCERES_H

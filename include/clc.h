@@ -159,6 +159,20 @@ int clc_flatten_observations(int n_poses, const double* tag_q_wxyz, const double
                              int use_linefitting_data, int use_boundary_constraint,
                              clc_observation* records, int64_t* n_records);
 
+/* ---- resident scans + problem assembly on the device ------------------------------------
+ * The same residual-block construction (src/LaseCamCalCeres.cpp:222-295), but the pose-major data of
+ * std::vector<Oberserve> — tag poses and the scan points, 24 bytes per point — is what crosses PCIe, once, and
+ * stays resident; the 64-byte records of any (use_linefitting_data, use_boundary_constraint) selection are then
+ * built on the device, bitwise equal to clc_flatten_observations' (every operation individually rounded, same
+ * order), and handed to the upload pipeline without touching the host.  This is how the drop-in header runs
+ * closed form -> calibration -> analysis pass of main/calibr_offline.cpp:166-170 on ONE upload
+ * (clc_adapter::Session).  Arguments as clc_flatten_observations.  clc_select_observations replaces the
+ * observation array of the handle (as clc_upload would); CLC_ERR_EMPTY_SCAN as for the host path. */
+int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz, const double* tag_t,
+                           const int64_t* pts_off, const double* pts, const int64_t* ptl_off, const double* ptl);
+int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_boundary_constraint,
+                            int64_t* n_records);
+
 /* ---- observation array --------------------------------------------------------------
  * Copies N records to the device and re-tiles them for coalesced 16-byte loads.  Stays
  * resident until the next upload/destroy.  `clc_upload_device` takes a DEVICE pointer to
@@ -221,6 +235,9 @@ int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9
  * the device.  poses[P*7] in/out, summaries[P]. */
 int clc_upload_batched(clc_handle* h, const clc_observation* records, const int64_t* offsets,
                        size_t n_problems);
+/* records_dev: DEVICE pointer to the same AoS records (ready on the handle's stream); offsets stay a host array. */
+int clc_upload_batched_device(clc_handle* h, const clc_observation* records_dev, const int64_t* offsets,
+                              size_t n_problems);
 int clc_solve_batched(clc_handle* h, const clc_options* opt, double* poses,
                       clc_summary* summaries);
 size_t clc_num_problems(const clc_handle* h);
@@ -235,6 +252,11 @@ size_t clc_num_problems(const clc_handle* h);
 void clc_line_options_default(clc_options* opt);
 int clc_line_fit_batched(clc_handle* h, const clc_options* opt, const double* xy, const int64_t* offsets,
                          size_t n_scans, double* lines, clc_summary* summaries);
+/* The same with every array in DEVICE memory (ready on the handle's stream; results are complete on that stream when
+ * the call returns — it synchronises): xy_dev[2*M], offsets_dev[n_scans+1] (absolute, offsets_dev[0] may be > 0),
+ * lines_dev[2*n_scans] in/out, summaries_dev nullable.  Offsets and start lines are not validated. */
+int clc_line_fit_batched_device(clc_handle* h, const clc_options* opt, const double* xy_dev, const int64_t* offsets_dev,
+                                size_t n_scans, double* lines_dev, clc_summary* summaries_dev);
 
 /* TranScanToPoints, src/utilities.cpp:181-215, for n_scans (<= 65535) scans at once: scan k owns rays
  * [offsets[k], offsets[k+1]) of ranges[] (float32 as in sensor_msgs/LaserScan); ray i of scan k
@@ -243,6 +265,11 @@ int clc_line_fit_batched(clc_handle* h, const clc_options* opt, const double* xy
 int clc_scan_to_points(clc_handle* h, const float* ranges, const int64_t* offsets, size_t n_scans,
                        const float* angle_min, const float* angle_increment, const float* range_min,
                        double* points);
+/* The same with every array in DEVICE memory (any number of scans; n_rays = offsets[n_scans] - offsets[0], which
+ * the caller knows; offsets_dev[0] must be 0). */
+int clc_scan_to_points_device(clc_handle* h, const float* ranges_dev, const int64_t* offsets_dev, size_t n_scans,
+                              size_t n_rays, const float* angle_min_dev, const float* angle_increment_dev,
+                              const float* range_min_dev, double* points_dev);
 
 /* ---- multi-GPU: sharded batches + RCCL gather ------------------------------------------------
  * BASELINE.json configs[3]: independent T_cl problems shard across the GPUs of a node, one process

@@ -24,14 +24,14 @@ static Eigen::Matrix4d invert(const Eigen::Matrix4d& T) {
     return I;
 }
 
-static void GenerateSimData(std::vector<Oberserve>& obs, unsigned seed, double sigma) {
+static void GenerateSimData(std::vector<Oberserve>& obs, unsigned seed, double sigma, size_t n_poses = 50, size_t n_rays = 180) {
     Eigen::Matrix3d Rlc;  // calibr_simulation.cpp:15-20
     Rlc(0, 2) = 1; Rlc(1, 0) = -1; Rlc(2, 1) = -1;
     Eigen::Vector3d tlc(0.1, 0.2, 0.3);
     std::mt19937 generator(seed);
     std::uniform_real_distribution<double> rpy_rand(-M_PI / 6., M_PI / 6.), xy_rand(-3, 3.0), z_rand(1., 5.);
     std::normal_distribution<double> noise(0.0, 1.0);
-    for (size_t i = 0; i < 50; i++) {
+    for (size_t i = 0; i < n_poses; i++) {
         Eigen::Matrix3d Rca = rot(rpy_rand(generator), 2) * rot(rpy_rand(generator), 1) * rot(rpy_rand(generator), 0);
         Eigen::Vector3d tca(xy_rand(generator), xy_rand(generator), z_rand(generator));
         Eigen::Matrix3d Rla = Rlc * Rca;
@@ -39,8 +39,8 @@ static void GenerateSimData(std::vector<Oberserve>& obs, unsigned seed, double s
         Eigen::Vector3d n(Rla(0, 2), Rla(1, 2), Rla(2, 2));
         const double d = -n.dot(tla);
         std::vector<Eigen::Vector3d> points;
-        for (size_t j = 0; j < 180; j++) {
-            const double theta = -M_PI_2 + j * M_PI / 180;
+        for (size_t j = 0; j < n_rays; j++) {
+            const double theta = -M_PI_2 + j * M_PI / n_rays;
             Eigen::Vector3d ray(cos(theta), sin(theta), 0);
             double depth = -d / (ray.dot(n));
             if (std::isnan(depth) || depth < 0) continue;
@@ -61,7 +61,51 @@ static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// main/calibr_offline.cpp:166-170 at C2 size (2 000 poses x ~550 points) through clc_adapter::Session (one upload of the
+// pose-major data, residual blocks selected on the device) and, for comparison, through the two free functions with the
+// reference's signatures (one upload per call).
+static int session_flow(size_t n_poses, size_t n_rays) {
+    std::vector<Oberserve> obs;
+    GenerateSimData(obs, 7u, 0.01, n_poses, n_rays);
+    size_t n_pts = 0;
+    for (size_t i = 0; i < obs.size(); ++i) n_pts += obs[i].points.size();
+    std::cout << "obs size: " << obs.size() << ", points: " << n_pts << std::endl;
+    { Eigen::Vector2d l; l(0) = 0; l(1) = 0; LineFittingCeres(obs[0].points, l); }  // HIP start-up + context, not timed
+    Eigen::Matrix4d Tlc_initial = Eigen::Matrix4d::Identity(), Tcl;
+    double best_session = 1e30, best_free = 1e30, t_store = 0, t_closed = 0, t_cal = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+        const double t0 = now_ms();
+        clc_adapter::Session run(obs);
+        const double t1 = now_ms();
+        Tlc_initial = Eigen::Matrix4d::Identity();
+        run.ClosedSolution(Tlc_initial);
+        const double t2 = now_ms();
+        Tcl = invert(Tlc_initial);
+        run.Calibration(Tcl, false);
+        const double t3 = now_ms();
+        if (t3 - t0 < best_session) { best_session = t3 - t0; t_store = t1 - t0; t_closed = t2 - t1; t_cal = t3 - t2; }
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        const double t0 = now_ms();
+        Eigen::Matrix4d Ti = Eigen::Matrix4d::Identity();
+        CamLaserCalClosedSolution(obs, Ti);
+        Eigen::Matrix4d Tf = invert(Ti);
+        CamLaserCalibration(obs, Tf, false);
+        best_free = std::fmin(best_free, now_ms() - t0);
+    }
+    std::printf("TIMING session flow: total %.3f ms (store %.3f, closed form %.3f, calibration + analysis %.3f); free functions (by-value obs, one upload per call): %.3f ms; points %zu\n",
+                best_session, t_store, t_closed, t_cal, best_free, n_pts);
+    Eigen::Matrix4d Tlc = invert(Tcl);
+    const double Rgt[3][3] = {{0, 0, 1}, {-1, 0, 0}, {0, -1, 0}}, tgt[3] = {0.1, 0.2, 0.3};
+    double eR = 0, et = 0;
+    for (int i = 0; i < 3; ++i) { et = std::fmax(et, std::fabs(Tlc(i, 3) - tgt[i])); for (int j = 0; j < 3; ++j) eR = std::fmax(eR, std::fabs(Tlc(i, j) - Rgt[i][j])); }
+    std::printf("RESULT %.3e %.3e\n", et, eR);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "session")
+        return session_flow(argc > 2 ? (size_t)std::atol(argv[2]) : 2000, argc > 3 ? (size_t)std::atol(argv[3]) : 900);
     const bool offline_flow = argc > 1 && std::string(argv[1]) == "offline";
     double t_fit = 0.0, t_closed = 0.0;
     int n_fit = 0;

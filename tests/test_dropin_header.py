@@ -55,3 +55,17 @@ def test_dropin_simulation_node_flow(flow):
     et, eR = float(m.group(1)), float(m.group(2))
     tol = 1e-7 if flow == "simulation" else 2e-2   # noise-free: exact ground truth (calibr_simulation.cpp:15-20)
     assert et < tol and eR < tol, p.stdout[-600:]
+
+
+@pytest.mark.gpu
+def test_dropin_session_flow_at_c2_size():
+    """clc_adapter::Session: closed form -> refinement -> analysis pass of main/calibr_offline.cpp:166-170 on ONE upload of the
+    pose-major data (2 000 poses x ~550 points), residual blocks assembled on the device; prints the end-to-end time."""
+    p = subprocess.run([_build_exe(), "session", "2000", "900"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.count("Closed-form solution Tlc") == 7 and p.stdout.count("recover chi2") == 7
+    m = re.search(r"RESULT (\S+) (\S+)", p.stdout)
+    assert float(m.group(1)) < 5e-3 and float(m.group(2)) < 5e-3, p.stdout[-600:]
+    t = re.search(r"TIMING session flow: total (\S+) ms", p.stdout)
+    assert t and float(t.group(1)) < 50.0
+    print(re.search(r"TIMING.*", p.stdout).group(0))

@@ -137,6 +137,96 @@ def test_device_resident_input_on_a_torch_stream(sv, oracle_mod):
     assert _dT(res.pose, ref.pose) <= 1e-6 and abs(res.summary.final_cost - ref.summary.final_cost) <= 1e-8
 
 
+def test_device_side_problem_assembly_is_bitwise_the_host_flatten(sv, oracle_mod):
+    """clc_store_observations + clc_select_observations: the residual blocks of every (linefit, boundary) selection built
+    on the device from the resident pose-major scans are bitwise the records clc_flatten_observations / the oracle build
+    on the host (plane :227-231, scale :239-240, board-edge planes :258-288), ragged scans and empty poses included; and
+    the whole Session flow equals the upload-per-call flow."""
+    S = sd.sim_board_edges(5, 60, 137, noise_sigma=0.002)
+    S.ptl = S.ptl[::-1].copy()  # points_on_line differ from points
+    cases = [(S, [(False, False), (True, False), (True, True), (False, True)])]
+    S1 = sd.GenerateSimData(0, n_poses=50, noise_sigma=0.01)  # ragged, possibly empty scans
+    cases.append((S1, [(False, False), (True, False)]))
+    for obs, sels in cases:
+        sv.store_observations(obs)
+        for lf, bd in sels:
+            host = clc.flatten_observations(obs, lf, bd)
+            dev = sv.debug_flatten_device(lf, bd)
+            assert dev.shape == host.shape and np.array_equal(dev, host), (lf, bd)
+            assert sv.select_observations(lf, bd) == host.shape[0] == sv.num_observations
+            c, g, H = sv.eval(X0)
+            sv.upload(host)
+            c2, g2, H2 = sv.eval(X0)
+            assert c == c2 and np.array_equal(H, H2) and np.array_equal(g, g2)
+    # boundary terms on an empty scan: same error as the host path (the reference throws at :278)
+    S2 = sd.sim_board_edges(3, 5, 12)
+    S2.pts_off[:] = 0
+    sv.store_observations(S2)
+    with pytest.raises(clc.ClcError) as e:
+        sv.select_observations(True, True)
+    assert e.value.code == -4
+    # Session == per-call flow (closed form -> refinement with boundary terms -> analysis pass)
+    S3 = sd.sim_board_edges(11, 40, 30, noise_sigma=0.002)
+    ses = clc.Session(S3, solver=sv)
+    Tlc = np.eye(4)
+    ses.CamLaserCalClosedSolution(Tlc, verbose=False)
+    Tcl = np.linalg.inv(Tlc)
+    rep = ses.CamLaserCalibration(Tcl, True, True, verbose=False)
+    rec_cf = clc.flatten_observations(S3, True, False)
+    sv.upload(rec_cf)
+    T2, _, _ = sv.closed_form()
+    assert np.array_equal(T2, Tlc)
+    sv.upload(clc.flatten_observations(S3, True, True))
+    r2 = sv.solve(sd.pose7_from_T(np.linalg.inv(T2)))
+    assert np.array_equal(r2.pose, rep.result.pose) and r2.summary.final_cost == rep.result.summary.final_cost
+    sv.upload(rec_cf)
+    H2 = sv.information(r2.pose)[0]
+    assert np.array_equal(H2, rep.H)
+
+
+def test_device_pointer_front_end_and_batched_upload(sv, oracle_mod):
+    """clc_scan_to_points_device -> clc_line_fit_batched_device on torch tensors (nothing crosses PCIe between the steps),
+    against the host-pointer entry points; clc_upload_batched_device against clc_upload_batched."""
+    import torch
+    rng = np.random.default_rng(4)
+    n_sc, rays = 300, 360
+    ranges = rng.uniform(0.3, 12.0, n_sc * rays).astype(np.float32)
+    ranges[::17] = np.inf
+    off = np.arange(n_sc + 1, dtype=np.int64) * rays
+    am = rng.uniform(-2.4, -2.2, n_sc).astype(np.float32); ai = np.full(n_sc, 0.0131, np.float32); rm = np.full(n_sc, 0.1, np.float32)
+    ref_pts = sv.scan_to_points(ranges, off, am, ai, rm)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_r, d_off, d_am, d_ai, d_rm = t(ranges), t(off), t(am), t(ai), t(rm)
+    d_pts = torch.empty((n_sc * rays, 3), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    sv.scan_to_points_device(d_r.data_ptr(), d_off.data_ptr(), n_sc, n_sc * rays, d_am.data_ptr(), d_ai.data_ptr(), d_rm.data_ptr(),
+                             d_pts.data_ptr())
+    assert np.array_equal(d_pts.cpu().numpy(), ref_pts)
+    # line fit on device-resident (x, y): the first 120 rays of every scan, sentinels replaced
+    xy = ref_pts.reshape(n_sc, rays, 3)[:, :120, :2].copy()
+    th = rng.uniform(-1.2, 1.2, n_sc); c = rng.uniform(0.8, 5.0, n_sc); tt = np.sort(rng.uniform(-0.5, 0.5, (n_sc, 120)), axis=1)
+    xy[:, :, 0] = c[:, None] * np.cos(th)[:, None] - tt * np.sin(th)[:, None] + rng.normal(size=(n_sc, 120)) * 0.004
+    xy[:, :, 1] = c[:, None] * np.sin(th)[:, None] + tt * np.cos(th)[:, None] + rng.normal(size=(n_sc, 120)) * 0.004
+    xy = np.ascontiguousarray(xy.reshape(-1, 2))
+    loff = np.arange(n_sc + 1, dtype=np.int64) * 120
+    lines_ref, sms = sv.line_fit_batched(xy, loff, np.zeros((n_sc, 2)))
+    d_xy, d_loff = t(xy), t(loff)
+    d_lines = torch.zeros((n_sc, 2), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    sv.line_fit_batched_device(d_xy.data_ptr(), d_loff.data_ptr(), n_sc, d_lines.data_ptr())
+    assert np.array_equal(d_lines.cpu().numpy(), lines_ref)
+    # batched upload from device memory
+    rec, boff, xb, gt = sd.sim_shard_records(21, 0, 12, 6, 64, 0.01)
+    sv.upload_batched(rec, boff)
+    p1, s1 = sv.solve_batched(xb)
+    d_rec = t(rec)
+    torch.cuda.synchronize()
+    sv.upload_batched_device(d_rec.data_ptr(), boff)
+    p2, s2 = sv.solve_batched(xb)
+    assert np.array_equal(p1, p2) and [s.final_cost for s in s1] == [s.final_cost for s in s2]
+
+
 def test_two_handles_on_two_threads(oracle_mod):
     """Handles are independent (own stream, own LM state): concurrent solves on two host threads
     give exactly the sequential results."""
