@@ -749,6 +749,19 @@ int flatten_on_device(clc_handle* h, bool linefit, bool boundary, DevBuf<double>
 
 }  // namespace
 
+void* clc_pinned_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, std::max<size_t>(bytes, 8), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void clc_pinned_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz, const double* tag_t,
                            const int64_t* pts_off, const double* pts, const int64_t* ptl_off, const double* ptl) {
   if (!h || n_poses < 0 || (n_poses > 0 && (!tag_q_wxyz || !tag_t || !pts_off || !ptl_off)))

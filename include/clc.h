@@ -168,6 +168,11 @@ int clc_flatten_observations(int n_poses, const double* tag_q_wxyz, const double
  * closed form -> calibration -> analysis pass of main/calibr_offline.cpp:166-170 on ONE upload
  * (clc_adapter::Session).  Arguments as clc_flatten_observations.  clc_select_observations replaces the
  * observation array of the handle (as clc_upload would); CLC_ERR_EMPTY_SCAN as for the host path. */
+/* Page-locked host memory for arrays handed to clc_store_observations / clc_upload*: from pageable memory the runtime
+ * pins and unpins the caller's pages around every copy (tens of milliseconds for 50 MB when the buffer is a fresh
+ * allocation each call); from these buffers the copy is a plain DMA.  NULL on failure. */
+void* clc_pinned_alloc(size_t bytes);
+void clc_pinned_free(void* p);
 int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz, const double* tag_t,
                            const int64_t* pts_off, const double* pts, const int64_t* ptl_off, const double* ptl);
 int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_boundary_constraint,

@@ -93,6 +93,22 @@ static int session_flow(size_t n_poses, size_t n_rays) {
         CamLaserCalibration(obs, Tf, false);
         best_free = std::fmin(best_free, now_ms() - t0);
     }
+    {   // the same steps through the C-ABI, timed one by one (the Session of the last repetition left the scans resident)
+        clc_adapter::Handle H;
+        for (int rep = 0; rep < 3; ++rep) {
+            double T[16], pose[7] = {0, 0, 0, 0, 0, 0, 1}; int un = 0; clc_summary sm; clc_options opt; clc_options_default(&opt);
+            const double a0 = now_ms();
+            clc_select_observations(H.h, 1, 0, NULL);
+            const double a1 = now_ms();
+            clc_closed_form(H.h, T, &un, NULL);
+            const double a2 = now_ms();
+            clc_select_observations(H.h, 0, 0, NULL);
+            const double a3 = now_ms();
+            clc_solve(H.h, &opt, pose, &sm, NULL, 0);
+            const double a4 = now_ms();
+            std::printf("TIMING C-ABI steps: select(linefit) %.3f ms, closed_form %.3f, select(points) %.3f, solve %.3f\n", a1 - a0, a2 - a1, a3 - a2, a4 - a3);
+        }
+    }
     std::printf("TIMING session flow: total %.3f ms (store %.3f, closed form %.3f, calibration + analysis %.3f); free functions (by-value obs, one upload per call): %.3f ms; points %zu\n",
                 best_session, t_store, t_closed, t_cal, best_free, n_pts);
     Eigen::Matrix4d Tlc = invert(Tcl);

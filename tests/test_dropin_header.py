@@ -20,7 +20,7 @@ def _build_exe():
     deps = [src, os.path.join(ROOT, "include", "LaseCamCalCeres.h"), os.path.join(ROOT, "include", "clc.h"), _build.LIB_PATH]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         lib_dir = os.path.dirname(_build.LIB_PATH)
-        subprocess.check_call(["g++", "-O2", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call(["g++", "-O2", "-std=c++11", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"),
                                "-I", os.path.join(HERE, "dropin", "eigen_stub"), src, "-o", EXE,
                                "-L", lib_dir, "-lclc_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
     return EXE
