@@ -486,7 +486,18 @@ def main():
         except Exception as e:  # the library is test infrastructure and may be absent
             out["cpu_baseline"]["variants"]["reference_sources_note"] = f"oracle/_ref not available: {e}"
         dT = float(np.abs(sd.T_from_pose7(res.pose) - sd.T_from_pose7(ref.pose)).max())
+        # what the unpinned part of the oracle (Ceres' minimiser, absent here) can cost: how far the result moves if the
+        # solve ran on to the minimum instead of stopping at function_tolerance — the size of a +-1-iteration
+        # disagreement with a real Ceres (tests/test_ceres_handoff.py, tests/golden/dump_ceres_trace.cpp)
+        tight = clc.default_options()
+        tight.function_tolerance = 1e-12
+        rt = solver.solve(x0, tight, trace_cap=0)
+        sens = {"final_cost_minus_converged_minimum": res.summary.final_cost - rt.summary.final_cost,
+                "bound_function_tolerance_x_cost": 1e-6 * res.summary.final_cost,
+                "T_cl_max_abs_shift_to_converged_minimum": float(np.abs(sd.T_from_pose7(res.pose) - sd.T_from_pose7(rt.pose)).max()),
+                "iterations_default_vs_converged": [res.summary.num_iterations, rt.summary.num_iterations]}
         out["parity"] = {
+            "stopping_rule_sensitivity": sens,
             "T_cl_max_abs_err_vs_oracle": dT,
             "final_cost_abs_err_vs_oracle": abs(res.summary.final_cost - ref.summary.final_cost),
             "iterations_gpu": res.summary.num_iterations, "iterations_oracle": ref.summary.num_iterations,

@@ -170,6 +170,14 @@ inline SolveRecord& last_solve_record() {
   return r;
 }
 
+#define CERES_VERSION_STRING "stand-in (oracle/ref_shim/mini_ceres.hpp -> the oracle's LM restatement)"
+struct IterationSummary {  // ceres::IterationSummary subset
+  int iteration = 0;
+  bool step_is_valid = false, step_is_successful = false;
+  double cost = 0.0, cost_change = 0.0, gradient_max_norm = 0.0, step_norm = 0.0, relative_decrease = 0.0,
+         trust_region_radius = 0.0;
+};
+
 class Solver {
  public:
   struct Options {
@@ -180,6 +188,10 @@ class Solver {
   };
   struct Summary {
     SolveRecord rec;
+    // the part of ceres::Solver::Summary tests/golden/dump_ceres_trace.cpp reads
+    std::vector<IterationSummary> iterations;
+    int termination_type = 0;
+    double initial_cost = 0.0, final_cost = 0.0;
     std::string BriefReport() const {
       std::ostringstream os;
       os << "stand-in Ceres (oracle LM): iterations " << rec.num_iterations << ", initial cost " << rec.initial_cost
@@ -263,8 +275,9 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   oracle_summary s = {};
   const int na = problem->size_;
   const int np = problem->param_ ? problem->param_->LocalSize() : na;
+  std::vector<oracle_iteration> trace((size_t)options.max_num_iterations + 8);
   oracle_minimize_cb(np, na, (long long)problem->blocks_.size(), shim::evaluate, shim::plus, problem,
-                     &o, problem->x_, &s, nullptr, 0);
+                     &o, problem->x_, &s, trace.data(), (int)trace.size());
   SolveRecord rec;
   rec.termination = s.termination;
   rec.num_iterations = s.num_iterations;
@@ -274,7 +287,26 @@ inline void Solve(const Solver::Options& options, Problem* problem, Solver::Summ
   rec.final_cost = s.final_cost;
   rec.num_residual_blocks = (long long)problem->blocks_.size();
   last_solve_record() = rec;
-  if (summary) summary->rec = rec;
+  if (summary) {
+    summary->rec = rec;
+    summary->termination_type = s.termination;
+    summary->initial_cost = s.initial_cost;
+    summary->final_cost = s.final_cost;
+    summary->iterations.clear();
+    for (int i = 0; i <= s.num_iterations && i < (int)trace.size(); ++i) {
+      IterationSummary it;
+      it.iteration = trace[(size_t)i].iteration;
+      it.step_is_valid = trace[(size_t)i].step_is_valid != 0;
+      it.step_is_successful = trace[(size_t)i].step_is_successful != 0;
+      it.cost = trace[(size_t)i].cost;
+      it.cost_change = trace[(size_t)i].cost_change;
+      it.gradient_max_norm = trace[(size_t)i].gradient_max_norm;
+      it.step_norm = trace[(size_t)i].step_norm;
+      it.relative_decrease = trace[(size_t)i].relative_decrease;
+      it.trust_region_radius = trace[(size_t)i].trust_region_radius;
+      summary->iterations.push_back(it);
+    }
+  }
 }
 
 }  // namespace ceres
