@@ -483,17 +483,20 @@ struct BatchedLaunch {
   int lm_threads = 64;
   unsigned lm_blocks = 0;
   bool compact = false, deep = false, nt = false;
-  bool rows = false, rows_nt = false;
+  bool rows = false, rows_nt = false, rows_wave = false;
 };
 
 int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunch* bl) {
   const size_t P = h->n_problems;
+  bl->rows = use_brows(h);
+  bl->rows_wave = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_WG256) == 0;
   // enough workgroups to fill the chip: >= 2 per CU in total, never more than one per 4 tiles
   const size_t target_blocks = h->grid_override > 0 ? (size_t)h->grid_override : 4 * (size_t)h->num_cus;
   int bpp = (int)((target_blocks + P - 1) / P);
   const long long max_tiles = h->batch_max_tiles;
   const int bpp_cap = (int)std::max<long long>(1, max_tiles / 4);
   bpp = std::max(1, std::min(bpp, bpp_cap));
+  if (bl->rows_wave) bpp *= clc::BLOCK / 64;  // the same number of waves, each its own workgroup
   const size_t n_blocks = P * (size_t)bpp;
   if (n_blocks > h->bpartials_cap_blocks) {
     if (h->d_bpartials) CLC_HIP(hipFree(h->d_bpartials));
@@ -511,7 +514,6 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
            (bl->compact && h->launch_auto &&
             h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes + kInfinityCacheBytes / 2);
   bl->deep = (h->launch_flags & clc::FLAG_DEEP) != 0 || bbeyond;
-  bl->rows = use_brows(h);
   bl->rows_nt = bl->rows && rows_nontemporal(h, h->bn_rows);
   return CLC_OK;
 }
@@ -520,12 +522,17 @@ void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLau
   const size_t n_blocks = bl.n_blocks;
   const int bpp = bl.bpp;
   if (bl.rows) {
-#define CLC_LAUNCH_BR(LOSS, NT)                                                                                \
-  hipLaunchKernelGGL((clc::batched_rows_eval_kernel<LOSS, NT>), dim3((unsigned)n_blocks), dim3(clc::BLOCK), 0, h->stream, \
+#define CLC_LAUNCH_BR(LOSS, NT, BT)                                                                            \
+  hipLaunchKernelGGL((clc::batched_rows_eval_kernel<LOSS, NT, BT>), dim3((unsigned)n_blocks), dim3(BT), 0, h->stream,   \
                      h->d_brxy, reinterpret_cast<const clc::RowDesc*>(h->d_brdesc), h->d_prob_row, h->d_states, bpp,     \
                      opt.loss_scale_factor, h->d_bpartials)
-    if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_BR(true, true); else CLC_LAUNCH_BR(true, false); }
-    else { if (bl.rows_nt) CLC_LAUNCH_BR(false, true); else CLC_LAUNCH_BR(false, false); }
+    if (bl.rows_wave) {
+      if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_BR(true, true, 64); else CLC_LAUNCH_BR(true, false, 64); }
+      else { if (bl.rows_nt) CLC_LAUNCH_BR(false, true, 64); else CLC_LAUNCH_BR(false, false, 64); }
+    } else {
+      if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_BR(true, true, 256); else CLC_LAUNCH_BR(true, false, 256); }
+      else { if (bl.rows_nt) CLC_LAUNCH_BR(false, true, 256); else CLC_LAUNCH_BR(false, false, 256); }
+    }
 #undef CLC_LAUNCH_BR
     return;
   }
@@ -645,7 +652,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 1023)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 2047)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;

@@ -323,7 +323,8 @@ constexpr int FLAG_DEEP = 64;            // compact layout: two tiles of points 
 constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 3:2 old/young wave tile weighting
 constexpr int FLAG_STEP = 128;          // clc_solve: one step_kernel launch per LM iteration (compact or row layout)
 constexpr int FLAG_ROWS = 256;          // row layout (clc_rows.hpp): 16 B/observation + 64 B/row, per-scan moments
-constexpr int FLAG_EQUAL_WAVES = 512;   // row layout, 512-thread workgroups: equal shares per wave instead of the 3:2 old/young weighting
+constexpr int FLAG_EQUAL_WAVES = 512;
+constexpr int FLAG_BATCHED_WG256 = 1024;  // batched row kernel: 256-thread workgroups + block reduction instead of one wave per workgroup   // row layout, 512-thread workgroups: equal shares per wave instead of the 3:2 old/young weighting
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -719,7 +720,10 @@ __global__ void build_ctiles_kernel(const double* __restrict__ aos, const unsign
 // per-scan moments (one point per lane per row, ~26 FP64 instructions) and expands them into the 28 accumulators
 // when the scan changes (rows_flush).  Same lane->row map for every launch: bitwise reproducible.
 // ---------------------------------------------------------------------------------------
-constexpr int ROWS_DEPTH = 8;
+#ifndef CLC_ROWS_DEPTH
+#define CLC_ROWS_DEPTH 8
+#endif
+constexpr int ROWS_DEPTH = CLC_ROWS_DEPTH;
 
 template <bool NT>
 __device__ __forceinline__ v2d load_row(const double* __restrict__ xy, long long row, int lane) {
@@ -804,7 +808,7 @@ struct Normal9Rows {
   }
 };
 
-template <class Policy, bool NT, class PoseFn>
+template <class Policy, bool NT, int DEPTH = ROWS_DEPTH, class PoseFn>
 __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __restrict__ xy_all,
                                                    const RowDesc* __restrict__ desc_all, long long r_begin_in,
                                                    long long r_end_in, const int lane, PoseFn get_pose,
@@ -815,26 +819,26 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
   const int n = __builtin_amdgcn_readfirstlane((int)(r_end_in - r_begin_in));
   const double* __restrict__ xy = xy_all + r_begin * ROW_DOUBLES;
   const RowDesc* __restrict__ desc = desc_all + r_begin;
-  v2d buf[ROWS_DEPTH];
-  double dbuf[ROWS_DEPTH];
+  v2d buf[DEPTH];
+  double dbuf[DEPTH];
 #pragma unroll
-  for (int u = 0; u < ROWS_DEPTH; ++u)
+  for (int u = 0; u < DEPTH; ++u)
     if (u < n) {
       dbuf[u] = load_desc_lane(desc, u, lane);
       buf[u] = load_row<NT>(xy, u, lane);
     }
   PoseU P;
   if (!get_pose(P)) return false;  // after the prologue loads are in flight (see stream_tiles)
-  for (int base = 0; base < n; base += ROWS_DEPTH) {
+  for (int base = 0; base < n; base += DEPTH) {
 #pragma unroll
-    for (int u = 0; u < ROWS_DEPTH; ++u) {
+    for (int u = 0; u < DEPTH; ++u) {
       const int r = base + u;
       if (r >= n) break;
       const double dv = dbuf[u];
       const v2d v = buf[u];
-      if (r + ROWS_DEPTH < n) {
-        dbuf[u] = load_desc_lane(desc, r + ROWS_DEPTH, lane);
-        buf[u] = load_row<NT>(xy, r + ROWS_DEPTH, lane);
+      if (r + DEPTH < n) {
+        dbuf[u] = load_desc_lane(desc, r + DEPTH, lane);
+        buf[u] = load_row<NT>(xy, r + DEPTH, lane);
       }
       const int count = __builtin_amdgcn_readlane(__double2loint(dv), 5);  // RowDesc: double 5 = {count, first}
       const int first = __builtin_amdgcn_readlane(__double2hiint(dv), 5);
@@ -849,12 +853,12 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
   return true;
 }
 
-template <bool WITH_LOSS, bool NT, class PoseFn>
+template <bool WITH_LOSS, bool NT, int DEPTH = ROWS_DEPTH, class PoseFn>
 __device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, const RowDesc* __restrict__ desc_all,
                                             long long r_begin_in, long long r_end_in, const int lane, PoseFn get_pose,
                                             const double& inv_lf2, double (&acc)[NACC]) {
   LmRows<WITH_LOSS> pol(inv_lf2);
-  return stream_rows_policy<LmRows<WITH_LOSS>, NT>(pol, xy_all, desc_all, r_begin_in, r_end_in, lane, get_pose, acc);
+  return stream_rows_policy<LmRows<WITH_LOSS>, NT, DEPTH>(pol, xy_all, desc_all, r_begin_in, r_end_in, lane, get_pose, acc);
 }
 
 // ---- upload-time kernels of the row layout (all O(N) work on the device) -------------------------------------
@@ -1794,7 +1798,7 @@ __global__ __launch_bounds__(BLOCK) void normal9_rows_kernel(const double* __res
   const int lane = threadIdx.x & 63;
   const WaveMap wm = make_wave_map<BLOCK>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
   Normal9Rows pol;
-  stream_rows_policy<Normal9Rows, NT>(pol, xy, desc, wm.begin(n_rows), wm.end(n_rows), lane,
+  stream_rows_policy<Normal9Rows, NT, ROWS_DEPTH>(pol, xy, desc, wm.begin(n_rows), wm.end(n_rows), lane,
                                       [](PoseU&) { return true; }, acc);
   __shared__ double wsum[BLOCK / 64][NACC9 + 1];
   // halves: after the swap, lanes 0-31 hold acc[i] of {l, l+32} summed, lanes 32-63 acc[i+23]
@@ -1868,8 +1872,13 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
 }
 
 // K4 on the row layout: problem k owns rows [prob_row[k], prob_row[k+1]).
-template <bool WITH_LOSS, bool NT>
-__global__ __launch_bounds__(BLOCK) void batched_rows_eval_kernel(
+// K4 on the row layout: problem k owns rows [prob_row[k], prob_row[k+1]).
+// BT = 64 (default): ONE WAVE per workgroup — no LDS, no barrier, the wave's 28 totals go straight to its own partial row
+// (blocks_per_problem counts waves).  A problem of 10^4 observations is 160 rows: with 256-thread workgroups the dispatcher
+// refills a CU only when the slowest of four waves has finished and every workgroup pays a barrier + LDS pass; with
+// single-wave workgroups every wave slot is refilled the moment it frees (measured on one C4 shard: see DESIGN.md K4).
+template <bool WITH_LOSS, bool NT, int BT>
+__global__ __launch_bounds__(BT) void batched_rows_eval_kernel(
     const double* __restrict__ xy, const RowDesc* __restrict__ desc, const long long* __restrict__ prob_row,
     const LmState* __restrict__ states, const int blocks_per_problem, const double lf, double* __restrict__ partials) {
   const int prob = blockIdx.x / blocks_per_problem;
@@ -1886,9 +1895,12 @@ __global__ __launch_bounds__(BLOCK) void batched_rows_eval_kernel(
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
   const long long r0 = prob_row[prob], r1 = prob_row[prob + 1];
-  const WaveMap wm = make_wave_map<BLOCK>(j, blocks_per_problem, threadIdx.x >> 6);
+  const WaveMap wm = make_wave_map<BT>(j, blocks_per_problem, threadIdx.x >> 6);
   if (!stream_rows<WITH_LOSS, NT>(xy, desc, r0 + wm.begin(r1 - r0), r0 + wm.end(r1 - r0), lane, get_pose, inv_lf2, acc)) return;
-  block_reduce_store<BLOCK / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
+  if (BT == 64)
+    wave_reduce_butterfly(acc, partials + (size_t)blockIdx.x * NACC, lane);
+  else
+    block_reduce_store<BT / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
 }
 
 __global__ __launch_bounds__(64) void batched_init_kernel(LmState* __restrict__ states, const clc_options opt,
