@@ -489,7 +489,9 @@ struct BatchedLaunch {
 int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunch* bl) {
   const size_t P = h->n_problems;
   bl->rows = use_brows(h);
-  bl->rows_wave = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_WG256) == 0;
+  // one wave per workgroup once the batch is many times wider than the chip (C4 shard: 8 192 problems, -5...7 % per
+  // batch); for batches of about a thousand problems the 256-thread form is 3-4 % ahead (scripts/r02_shard_step_timing.py)
+  bl->rows_wave = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_WG256) == 0 && (!h->launch_auto || P >= 8 * (size_t)h->num_cus);
   // enough workgroups to fill the chip: >= 2 per CU in total, never more than one per 4 tiles
   const size_t target_blocks = h->grid_override > 0 ? (size_t)h->grid_override : 4 * (size_t)h->num_cus;
   int bpp = (int)((target_blocks + P - 1) / P);
