@@ -456,10 +456,13 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
     rows_ok = R > 0 && (size_t)R * clc::ROW <= 3 * n_total + 64 * P;  // rows at least a third full on average
   }
   if (rows_ok) {
-    rc = ensure_bytes(T.d_rxy, T.rxy_cap, (size_t)R * clc::ROW_DOUBLES * sizeof(double));
+    // one padding row each: the streaming loop's prologue loads run unconditionally from clamped row indices
+    rc = ensure_bytes(T.d_rxy, T.rxy_cap, ((size_t)R + 1) * clc::ROW_DOUBLES * sizeof(double));
     if (rc != CLC_OK) return rc;
-    rc = ensure_bytes(T.d_rdesc, T.rdesc_cap, (size_t)R * sizeof(clc::RowDesc));
+    rc = ensure_bytes(T.d_rdesc, T.rdesc_cap, ((size_t)R + 1) * sizeof(clc::RowDesc));
     if (rc != CLC_OK) return rc;
+    CLC_HIP(hipMemsetAsync(*T.d_rxy + (size_t)R * clc::ROW_DOUBLES, 0, clc::ROW_DOUBLES * sizeof(double), h->stream));
+    CLC_HIP(hipMemsetAsync(reinterpret_cast<char*>(*T.d_rdesc) + (size_t)R * sizeof(clc::RowDesc), 0, sizeof(clc::RowDesc), h->stream));
     const long long slots = R * clc::ROW;
     hipLaunchKernelGGL(clc::build_rows_kernel, dim3((unsigned)((slots + threads - 1) / threads)), dim3(threads), 0, h->stream,
                        d_aos, bstarts.p, brbeg.p, (long long)G, R, *T.d_rxy, reinterpret_cast<clc::RowDesc*>(*T.d_rdesc));
@@ -967,10 +970,10 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
       double* r_out = rows_buf[k & 1];
 #define CLC_LAUNCH_STEP(LOSS, DEEP, MODE)                                                                     \
   hipLaunchKernelGGL((clc::step_kernel<LOSS, DEEP, MODE>), dim3(grid), dim3(512), 0, h->stream, r_in,            \
-                     h->d_ctiles, h->d_groups, (int)h->n_obs, grid | ((k & 1) << 30), r_out, h->d_block, prm)
+                     h->d_ctiles, h->d_groups, (int)h->n_obs, grid | ((k & 1) << 30), k, r_out, h->d_block, prm)
 #define CLC_LAUNCH_STEP_R(LOSS, NT, MODE, WG)                                                                 \
   hipLaunchKernelGGL((clc::step_kernel<LOSS, NT, MODE, 1, WG>), dim3(grid), dim3(512), 0, h->stream, r_in,       \
-                     h->d_rxy, h->d_rdesc, (int)h->n_rows, grid | ((k & 1) << 30), r_out, h->d_block, prm)
+                     h->d_rxy, h->d_rdesc, (int)h->n_rows, grid | ((k & 1) << 30), k, r_out, h->d_block, prm)
 #define CLC_LAUNCH_STEP_M(LOSS, DEEP)                                                                         \
   do { if (k == 0) CLC_LAUNCH_STEP(LOSS, DEEP, 0); else if (k == 1) CLC_LAUNCH_STEP(LOSS, DEEP, 1);             \
        else CLC_LAUNCH_STEP(LOSS, DEEP, 2); } while (0)

@@ -821,12 +821,17 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
   const RowDesc* __restrict__ desc = desc_all + r_begin;
   v2d buf[DEPTH];
   double dbuf[DEPTH];
+  // Prologue: DEPTH rows in flight, issued UNCONDITIONALLY from clamped row indices (the row arrays carry one padding
+  // row, so even an empty run reads mapped memory).  As `if (u < n) load` each load sat in its own branch, and the
+  // waits hipcc places at the joins made a wave stall on its first rows of points before it had issued the last ones —
+  // and before the barrier in front of the step kernel's controller.
+  const int n_last = n > 0 ? n - 1 : 0;
 #pragma unroll
-  for (int u = 0; u < DEPTH; ++u)
-    if (u < n) {
-      dbuf[u] = load_desc_lane(desc, u, lane);
-      buf[u] = load_row<NT>(xy, u, lane);
-    }
+  for (int u = 0; u < DEPTH; ++u) {
+    const int ru = u < n_last ? u : n_last;
+    dbuf[u] = load_desc_lane(desc, ru, lane);
+    buf[u] = load_row<NT>(xy, ru, lane);
+  }
   PoseU P;
   if (!get_pose(P)) return false;  // after the prologue loads are in flight (see stream_tiles)
   for (int base = 0; base < n; base += DEPTH) {
@@ -1287,9 +1292,7 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
   L.passes_before = 0;
   L.my_word = 0.0;
   if (threadIdx.x < HT) {  // wave-uniform
-    // a per-lane (vector) load: read through a uniform address this becomes a scalar load whose s_waitcnt sits in front
-    // of wave 1's row loads — the wave then reaches the row-sum barrier ~1 us after the others
-    if (!FIRST && threadIdx.x == 64) L.passes_before = (&state->n_evals)[threadIdx.x - 64];
+    if (!FIRST && threadIdx.x == 64) L.passes_before = state->n_evals;
     const int cw = threadIdx.x < LM_STATE_WORDS ? threadIdx.x : LM_STATE_WORDS - 1;
     L.my_word = reinterpret_cast<const double*>(state)[cw];
     const int cc = c < NACC ? c : NACC - 1;
@@ -1312,14 +1315,15 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
 // may issue further loads (the step kernel: its first rows of points) between this and lm_tail_finish.
 template <bool COHERENT, int HT>
 __device__ __forceinline__ void lm_tail_sums(const double* __restrict__ partials, int n_blocks, double (*red)[32],
-                                             double* sh_state, const LmLoads& L, long long* stamps /* nullable: [2] */) {
+                                             double* sh_state, const LmLoads& L, long long* stamps /* nullable: [2] */,
+                                             const int n_stage_words = LM_STATE_WORDS) {
   static_assert(LM_STATE_WORDS <= 256, "one state word per thread");
   const bool helper = threadIdx.x < HT;
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   if (helper) {  // wave-uniform
     const int cc = c < NACC ? c : NACC - 1;
     if (stamps && threadIdx.x == 0) stamps[0] = clock64();
-    if (threadIdx.x < LM_STATE_WORDS) sh_state[threadIdx.x] = L.my_word;
+    if (threadIdx.x < n_stage_words) sh_state[threadIdx.x] = L.my_word;
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s0 += (c < NACC && g + LM_GROUPS * j < n_blocks) ? L.v[j] : 0.0;
@@ -1347,6 +1351,12 @@ __device__ __forceinline__ void lm_tail_sums(const double* __restrict__ partials
   }
 }
 
+template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS>
+__device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict__ state, LmState* __restrict__ state_out,
+                                                      const clc_options& opt, clc_iteration* __restrict__ trace, int trace_cap,
+                                                      HostMailbox* mailbox, double (*red)[32], double* sh_state,
+                                                      const long long c0, const Pose7* init_pose, const LmLoads& L);
+
 // Phase B: barrier, ordered combination of the 16 row groups, LM controller, publication.
 template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS = false>
 __device__ __forceinline__ bool lm_tail_finish(const LmState* __restrict__ state, LmState* __restrict__ state_out,
@@ -1354,12 +1364,23 @@ __device__ __forceinline__ bool lm_tail_finish(const LmState* __restrict__ state
                                                clc_iteration* __restrict__ trace, int trace_cap,
                                                HostMailbox* mailbox, double (*red)[32], double* sh_state,
                                                const long long c0, const Pose7* init_pose, const LmLoads& L) {
-  // Called by every thread of the workgroup (it contains barriers).
+  __syncthreads();
+  return lm_tail_after_barrier<COHERENT, FIRST, HT, CHECK_STATUS>(state, state_out, opt, trace, trace_cap, mailbox, red, sh_state,
+                                                                  c0, init_pose, L);
+}
+
+// ... and what follows the barrier (the step kernel reads its options from LDS between the two).
+template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS>
+__device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict__ state, LmState* __restrict__ state_out,
+                                                      const clc_options& opt,
+                                                      clc_iteration* __restrict__ trace, int trace_cap,
+                                                      HostMailbox* mailbox, double (*red)[32], double* sh_state,
+                                                      const long long c0, const Pose7* init_pose, const LmLoads& L) {
+  // Called by every thread of the workgroup (it contains a barrier).
   // Progress for the host's launch-ahead metering is published EARLY, by the first lane of wave 1
   // (not the controller's wave): the ~1.5 us a store to pinned host memory needs to be
   // acknowledged then overlaps the controller instead of delaying the end of the launch.
   const long long passes_before = L.passes_before;
-  __syncthreads();
   if (CHECK_STATUS && !FIRST && reinterpret_cast<const LmState*>(sh_state)->status != CLC_RUNNING) return false;
   // the 16 row groups are combined in order by 28 lanes in parallel (one column each): done by the controller's
   // lane alone this was hundreds of serial FP64 adds behind LDS reads, ~0.4 us of the launch
@@ -1551,45 +1572,62 @@ struct SolveBlock {
   LmState st[2];
 };
 
+constexpr int PRM_WORDS = (int)(sizeof(SolveParams) / 8);
+static_assert(sizeof(SolveParams) % 8 == 0 && offsetof(SolveBlock, st) == sizeof(SolveParams), "SolveBlock is params, then states");
+static_assert(LM_STATE_WORDS + PRM_WORDS <= 256, "one block word per thread");
+
 // LAYOUT 0: compact tiles (ctiles + group table, n = observations); 1: row layout (ctiles = xy rows, groups = row
 // descriptors, n = rows; DEEP selects non-temporal loads, WEIGHTED the 3:2 old/young wave shares).
 template <bool WITH_LOSS, bool DEEP, int MODE, int LAYOUT = 0, bool WEIGHTED = true>
 __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ rows_in,
                                                    const double* __restrict__ ctiles,
                                                    const double* __restrict__ groups, const int n, const int grid_parity,
-                                                   double* __restrict__ rows_out, SolveBlock* __restrict__ blk,
-                                                   const SolveParams init) {
-  // Preloaded: rows_in, ctiles, groups, n, grid_parity, rows_out, blk = 12 dwords.  `init` is read by MODE 0 only (the
-  // other instantiations never touch it, so they never wait for the kernarg segment).
+                                                   const int launch_index, double* __restrict__ rows_out,
+                                                   SolveBlock* __restrict__ blk, const SolveParams init) {
+  // Preloaded: rows_in, ctiles, groups, n, grid_parity, launch_index, rows_out, blk = 13 dwords.  `init` is read by MODE 0
+  // only (the other instantiations never touch it, so they never wait for the kernarg segment).
   // grid_parity = number of workgroups | (launch index & 1) << 30: this launch reads LM state st[parity ^ 1], writes st[parity].
+  // The front of a steady-state launch is ONE memory round trip: every thread issues, back to back, its 16 partial-row
+  // loads and its word of {LM state, per-solve parameters} (vector loads; nothing waits on a scalar load), then the
+  // waves sum their rows, issue their first rows of points, and meet at the barrier in front of the controller.
   __shared__ double red[LM_GROUPS][32];
-  __shared__ double sh_state[LM_STATE_WORDS];
+  __shared__ double sh_state[LM_STATE_WORDS + PRM_WORDS];  // [0, LM_STATE_WORDS): LM state; then the SolveParams words
   const long long c0 = clock64();
   const bool leader = blockIdx.x == 0;
   const int grid = grid_parity & 0x3FFFFFFF;
   const int parity = (grid_parity >> 30) & 1;
-  const LmState* __restrict__ state_in = &blk->st[parity ^ 1];
   LmState* __restrict__ state_out = &blk->st[parity];
-  SolveParams* __restrict__ params = &blk->prm;
-  // the controller's loads go out first: its chain (rows -> combine -> LM step) is the long pole of the launch, the
-  // tile prologue loads issued next only have to be in flight before it ends
   LmLoads L;
-  if (MODE != 0) lm_issue_loads<false, MODE == 1, 512>(rows_in, state_in, L);
-  if (MODE == 0 && leader && threadIdx.x == 0) *params = init;  // for launches 1, 2, ... of this solve
-  const SolveParams* __restrict__ prm = params;
-  double inv_lf2 = 0.0;  // set by get_pose: it depends on the options, which must not be waited for before the loads go out
+  if (MODE != 0) {
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    // word t of the staging area: state word t (t < LM_STATE_WORDS) or parameter word t - LM_STATE_WORDS
+    const int t = threadIdx.x < LM_STATE_WORDS + PRM_WORDS ? (int)threadIdx.x : LM_STATE_WORDS + PRM_WORDS - 1;
+    const int w = t < LM_STATE_WORDS ? PRM_WORDS + LM_STATE_WORDS * (parity ^ 1) + t : t - LM_STATE_WORDS;
+    L.my_word = reinterpret_cast<const double*>(blk)[w];
+    L.passes_before = launch_index - 1;  // launch k consumes pass k - 1: no need to read the counter back
+    const int cc = c < NACC ? c : NACC - 1;
+    const double* base = rows_in + (size_t)g * NACC + cc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L.v[j] = base[(size_t)(LM_GROUPS * j) * NACC];
+    // nothing below may be scheduled in between the loads above (hipcc had pulled the first row add — and its
+    // s_waitcnt — in front of the last four loads: a second memory round trip on the critical path)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (MODE == 0 && leader && threadIdx.x == 0) blk->prm = init;  // for launches 1, 2, ... of this solve
+  const SolveParams* prm = reinterpret_cast<const SolveParams*>(sh_state + LM_STATE_WORDS);  // valid after the barrier
+  double inv_lf2 = 0.0;  // set by get_pose: it depends on the options, which arrive with the state
   auto get_pose = [&](PoseU& P) -> bool {
     if (MODE == 0) {
       load_pose(init.pose0.v, P);
       inv_lf2 = make_uniform(1.0 / (init.opt.loss_scale_factor * init.opt.loss_scale_factor));
       return true;
     }
-    const clc_options opt = prm->opt;  // wave-uniform, read-only: scalar loads from the device-resident block
+    __syncthreads();  // state, parameters and row-group sums of every wave are in LDS
+    const clc_options& opt = prm->opt;
     inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
-    const bool consumed = lm_tail_finish<false, MODE == 1, 512, true>(state_in, leader ? state_out : nullptr, opt,
-                                                                  leader ? prm->trace : nullptr, leader ? prm->trace_cap : 0,
-                                                                  leader ? prm->mailbox : nullptr, red, sh_state, c0,
-                                                                  &prm->pose0, L);
+    const bool consumed = lm_tail_after_barrier<false, MODE == 1, 512, true>(
+        nullptr, leader ? state_out : nullptr, opt, leader ? prm->trace : nullptr, leader ? prm->trace_cap : 0,
+        leader ? prm->mailbox : nullptr, red, sh_state, c0, &prm->pose0, L);
     if (!consumed) {
       // the solve had terminated before this launch: hand the state on (the launch queued behind this one reads
       // the other buffer) and leave; the host mailbox is NOT touched — it may already belong to the next solve
@@ -1611,10 +1649,8 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
   const WaveMap wm = make_wave_map<512, WEIGHTED>(blockIdx.x, grid, threadIdx.x >> 6);
   // Order of the memory traffic of a launch: every wave's share of the previous launch's rows FIRST (57 KB per
   // workgroup through a 64 B/clk vector cache: the controller waits for the slowest wave's rows), and only when a wave
-  // has summed its rows does it issue its first rows of points — those have the whole controller to arrive.  (Issued
-  // ahead of the row sums, as the tile prologue used to be, the 8 x 9 KB of points of the older waves sat in the queue in
-  // front of the younger waves' rows.)
-  if (MODE != 0) lm_tail_sums<false, 512>(rows_in, grid, red, sh_state, L, nullptr);
+  // has summed its rows does it issue its first rows of points — those have the whole controller to arrive.
+  if (MODE != 0) lm_tail_sums<false, 512>(rows_in, grid, red, sh_state, L, nullptr, LM_STATE_WORDS + PRM_WORDS);
   bool active;
   if (LAYOUT == 1)
     active = stream_rows<WITH_LOSS, DEEP>(ctiles, reinterpret_cast<const RowDesc*>(groups), wm.begin(n), wm.end(n), lane,
