@@ -252,7 +252,13 @@ int ensure_events(clc_handle* h, size_t n) {
 }
 
 // Row layout in use for the single-problem array?
-bool use_rows(const clc_handle* h) { return (h->launch_flags & clc::FLAG_ROWS) != 0 && h->rows_ok; }
+// With the library's default flags, arrays below ~2x10^5 observations keep the per-point compact layout: a launch is pure
+// fixed cost there and the row kernel's 16 prologue loads + per-scan expansion make it 0.4-0.5 us longer per LM iteration
+// (8.5 vs 9.0 us at 5.5x10^3 observations, 8.8 vs 9.2 at 10^5; 13.2 vs 11.1 at 10^6 — scripts/r02_ab.py).
+bool use_rows(const clc_handle* h) {
+  if ((h->launch_flags & clc::FLAG_ROWS) == 0 || !h->rows_ok) return false;
+  return !h->launch_auto || !h->compact_ok || h->n_obs >= 200000;
+}
 bool use_brows(const clc_handle* h) { return (h->launch_flags & clc::FLAG_ROWS) != 0 && h->brows_ok; }
 // Rows streamed from HBM rather than the Infinity Cache (> 1.5x its size) are loaded non-temporally.
 bool rows_nontemporal(const clc_handle* h, long long n_rows) {
@@ -961,7 +967,9 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
   for (;;) {
     status = __atomic_load_n(&mb->status, __ATOMIC_ACQUIRE);
     if (status != CLC_RUNNING) break;
-    const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);  // passes consumed = launches whose rows are used up
+    // passes consumed = launches whose rows are used up.  Clamped to what this solve has launched: the early progress
+    // store of the PREVIOUS solve's last launches is relaxed and may land after the reset above.
+    const int done = std::min(__atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE), launched);
     if (launched < max_launches && launched - done <= lookahead) {
       const int k = launched;
       if (win_ms && k == win_first) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
@@ -1130,7 +1138,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   for (;;) {
     status = __atomic_load_n(&mb->status, __ATOMIC_ACQUIRE);
     if (status != CLC_RUNNING) break;
-    const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
+    const int done = std::min(__atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE), launched);  // see solve_stepped
     if (launched < max_evals && launched - done < lookahead) {
       if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
       if (fused) {
