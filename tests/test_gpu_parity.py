@@ -425,12 +425,15 @@ def test_randomized_problems_step_vs_pair_vs_oracle(sv, oracle_mod):
         a = sv.solve(x0, o)
         sv.set_launch(0, 2 | 16 | 32)
         b = sv.solve(x0, o)
-        sv.set_launch(0, -1)  # library default: the row layout (per-scan moments) — equal to the others up to rounding only
+        sv.set_launch(0, 2 | 16 | 32 | 128 | 256)  # row layout (per-scan moments), step kernel — equal to the others up to rounding only
         d = sv.solve(x0, o)
         sv.set_launch(0, 2 | 32 | 256)  # row layout through the [evaluation, controller] launch pair
         e = sv.solve(x0, o)
         assert np.array_equal(d.pose, e.pose) and d.summary.final_cost == e.summary.final_cost, case
+        sv.set_launch(0, -1)  # library default (layout chosen by size)
+        f = sv.solve(x0, o)
         ref = oracle_mod.solve(rec, x0, options=oo, linear_solver="qr")
+        assert f.summary.num_iterations == ref.summary.num_iterations and abs(f.summary.final_cost - ref.summary.final_cost) <= COST_TOL, case
         assert np.array_equal(a.pose, b.pose) and a.summary.final_cost == b.summary.final_cost, case
         assert a.summary.termination == b.summary.termination == d.summary.termination == ref.summary.termination, case
         assert a.summary.num_iterations == b.summary.num_iterations == d.summary.num_iterations == ref.summary.num_iterations, (case, n)
