@@ -1500,7 +1500,7 @@ int clc_line_fit_batched(clc_handle* h, const clc_options* opt_in, const double*
   if (e == hipSuccess) e = hipMemcpyAsync(d_off, rel.data(), (n_scans + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_lines, lines, n_scans * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
-    const unsigned blocks = (unsigned)((n_scans + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64));
+    const unsigned blocks = (unsigned)((n_scans + clc::LINE_SCANS_PER_BLOCK - 1) / clc::LINE_SCANS_PER_BLOCK);
     if (opt.use_loss)
       hipLaunchKernelGGL((clc::line_fit_kernel<true>), dim3(blocks), dim3(clc::BLOCK), 0, h->stream, d_xy, d_off,
                          (int)n_scans, opt, d_lines, d_sum);
@@ -1571,7 +1571,7 @@ int clc_line_fit_batched_device(clc_handle* h, const clc_options* opt_in, const 
   if (n_scans > 0x7FFFFFF0ull) return fail(CLC_ERR_INVALID_ARG, "clc_line_fit_batched_device: too many scans");
   CLC_HIP(hipSetDevice(h->device));
   static_assert(sizeof(long long) == sizeof(int64_t), "offset type");
-  const unsigned blocks = (unsigned)((n_scans + (clc::BLOCK / 64) - 1) / (clc::BLOCK / 64));
+  const unsigned blocks = (unsigned)((n_scans + clc::LINE_SCANS_PER_BLOCK - 1) / clc::LINE_SCANS_PER_BLOCK);
   const long long* d_off = reinterpret_cast<const long long*>(offsets_dev);
   if (opt.use_loss)
     hipLaunchKernelGGL((clc::line_fit_kernel<true>), dim3(blocks), dim3(clc::BLOCK), 0, h->stream, xy_dev, d_off,

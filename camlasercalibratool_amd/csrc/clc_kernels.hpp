@@ -2036,20 +2036,30 @@ __global__ void pack_results_kernel(const double* __restrict__ results, long lon
 
 // ---------------------------------------------------------------------------------------
 // K6 — LineFittingCeres batched over scans (src/LaseCamCalCeres.cpp:385-433).
-// One wavefront per scan runs the whole <= 10-iteration LM loop in-kernel: the lanes stride over
+// A 16-lane row per scan runs the whole <= 10-iteration LM loop in-kernel: the lanes stride over
 // the scan's points (residual m0 x + m1 y + 1, Jacobian [x, y], Cauchy loss a, corrector as in K1),
-// an xor-butterfly leaves the identical {H00, H01, H11, g0, g1, cost} in every lane, and every
-// lane runs the 2-parameter controller redundantly in registers (SIMT: same cost as one lane, no
-// broadcast).  A scan is ~10^2 points = a few KiB re-read from L1/L2 per iteration: latency-bound,
-// parallel over scans (4 scans per workgroup).
+// a DPP all-reduce leaves the identical {H00, H01, H11, g0, g1, cost} in every lane of the row, and every
+// lane runs the 2-parameter controller redundantly in registers (SIMT: no broadcast needed).
+// A scan is ~10^2 points = a few KiB re-read from L1/L2 per iteration: latency-bound,
+// parallel over scans (16 scans per workgroup).
 // ---------------------------------------------------------------------------------------
+constexpr int LINE_LANES = 16;                    // lanes per scan: one DPP row
+constexpr int LINE_SCANS_PER_WAVE = 64 / LINE_LANES;
+constexpr int LINE_SCANS_PER_BLOCK = (BLOCK / 64) * LINE_SCANS_PER_WAVE;
+
+// Four scans per wavefront, 16 lanes (one DPP row) each: the in-wave LM controller — ~300 instructions per iteration,
+// what a scan of ~10^2 points costs most — then serves four scans per issue slot, and the reduction of
+// {H00, H01, H11, g0, g1, cost} is four DPP steps inside the row instead of six cross-lane shuffles
+// (one wave per scan: 490 us per 10^5 scans; this form: see DESIGN.md K6).  Rows whose scan has terminated (or does
+// not exist) are masked off as a whole, so the row-local DPP reads only ever see active lanes.
 template <bool WITH_LOSS>
 __global__ __launch_bounds__(BLOCK) void line_fit_kernel(const double* __restrict__ xy,
                                                          const long long* __restrict__ off, const int n_scans,
                                                          const clc_options opt, double* __restrict__ lines,
                                                          clc_summary* __restrict__ summaries) {
-  const int scan = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  const int sub = lane & (LINE_LANES - 1);
+  const int scan = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * LINE_SCANS_PER_WAVE + (lane / LINE_LANES);
   if (scan >= n_scans) return;
   const double2* pts = reinterpret_cast<const double2*>(xy) + off[scan];
   const long long n = off[scan + 1] - off[scan];
@@ -2063,7 +2073,7 @@ __global__ __launch_bounds__(BLOCK) void line_fit_kernel(const double* __restric
   while (st.status == CLC_RUNNING) {
     const double m0 = st.x_eval[0], m1 = st.x_eval[1];
     double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // H00 H01 H11 g0 g1 cost
-    for (long long k = lane; k < n; k += 64) {
+    for (long long k = sub; k < n; k += LINE_LANES) {
       const double2 p = pts[k];
       const double r = fma(m0, p.x, fma(m1, p.y, 1.0));  // :391
       double wt = 1.0;
@@ -2082,16 +2092,18 @@ __global__ __launch_bounds__(BLOCK) void line_fit_kernel(const double* __restric
       acc[4] = fma(wy, r, acc[4]);
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 6; ++i) {  // all-reduce inside the 16-lane row (commutative pairs: all lanes bitwise equal)
       double v = acc[i];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);  // commutative pairs: all lanes bitwise equal
+      v += dpp_read<0xB1>(v);   // quad_perm [1,0,3,2]
+      v += dpp_read<0x4E>(v);   // quad_perm [2,3,0,1]
+      v += dpp_read<0x141>(v);  // row_half_mirror
+      v += dpp_read<0x140>(v);  // row_mirror
       acc[i] = v;
     }
     const double cost = WITH_LOSS ? 0.5 * (a * a) * acc[5] : 0.5 * acc[5];
     lm_advance(st, w, opt, nullptr, 0, cost, acc + 3, acc);
   }
-  if (lane == 0) {
+  if (sub == 0) {
     lines[2 * (size_t)scan] = st.x_out[0];
     lines[2 * (size_t)scan + 1] = st.x_out[1];
     if (summaries != nullptr) {
