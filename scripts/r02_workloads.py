@@ -28,7 +28,7 @@ def block(label, **kw):
     return blocks[-1]
 
 
-LAYOUTS = [("rows", -1), ("compact28", 2 | 16 | 32), ("tiled64", 6)]
+LAYOUTS = [("rows", 2 | 16 | 32 | 128 | 256), ("compact28", 2 | 16 | 32), ("tiled64", 6)]
 for poses, pts in ((200, 500), (2000, 500), (8000, 500), (32000, 500), (64000, 500)):
     n = poses * pts
     if n > max_obs:
