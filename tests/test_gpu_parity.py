@@ -540,7 +540,7 @@ def test_c3_full_size_batch(sv, oracle_mod):
         assert sms[k].final_cost <= sms[k].initial_cost
         assert np.abs(sd.T_from_pose7(poses[k]) - gts[k]).max() < 0.02, k
         assert abs(np.linalg.norm(poses[k, 3:]) - 1) < 1e-14
-    for k in range(0, P, 97):
+    for k in range(0, P, 16):  # 64 of the 1 024 problems against the oracle's DENSE_QR solve
         ref = oracle_mod.solve(recs[k], x0[k], linear_solver="qr")
         assert sms[k].num_iterations == ref.summary.num_iterations
         assert _dT(poses[k], ref.pose) <= T_TOL and abs(sms[k].final_cost - ref.summary.final_cost) <= COST_TOL

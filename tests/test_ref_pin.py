@@ -257,7 +257,7 @@ def test_gpu_closed_form_line_fit_scan_match_reference_functions(sv):
     for c in G["closed_solution"]:
         Tlc = np.eye(4)
         clc.CamLaserCalClosedSolution(_sim(c), Tlc, solver=sv, verbose=False)
-        assert np.abs(Tlc - np.array(c["Tlc"])).max() < 1e-9
+        assert np.abs(Tlc - np.array(c["Tlc"])).max() < 1e-10  # same factorisations as the reference now (pivoted LDL^T, SVD)
     pts = [np.array(c["points"]) for c in G["line_fitting"]]
     off = np.zeros(len(pts) + 1, dtype=np.int64)
     off[1:] = np.cumsum([p.shape[0] for p in pts])
