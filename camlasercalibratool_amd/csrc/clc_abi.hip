@@ -1407,7 +1407,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   const int lm_threads = bl.lm_threads;
   const unsigned lm_blocks = bl.lm_blocks;
   hipLaunchKernelGGL(clc::batched_init_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
-                     opt, h->d_poses, (int)P);
+                     opt, h->d_poses, (int)P, h->d_queue, h->d_ticket);
   CLC_HIP(hipGetLastError());
   const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : default_lookahead();
   const int max_evals = opt.max_num_iterations + 1;
@@ -1415,8 +1415,6 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   mb->n_done = 0;
   mb->status = CLC_RUNNING;
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  CLC_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), h->stream));
-  CLC_HIP(hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned int), h->stream));
   int launched = 0;
   long long spins = 0;
   int last_done = 0;
@@ -1428,7 +1426,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
       launch_batched_eval(h, opt, bl);
       hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
                          h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue, h->d_ticket, launched,
-                         h->d_mailbox);
+                         h->d_mailbox, h->d_poses, h->d_summaries, h->d_results);
       ++launched;
       continue;
     }
@@ -1442,10 +1440,12 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     }
   }
   CLC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(clc::batched_finish_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
-                     (int)P, h->d_poses, h->d_summaries, h->d_results);
-  CLC_HIP(hipGetLastError());
-  CLC_HIP(hipStreamSynchronize(h->stream));
+  if (__atomic_load_n(&mb->status, __ATOMIC_ACQUIRE) == CLC_RUNNING) {  // iteration cap of this loop: some problem still runs
+    hipLaunchKernelGGL(clc::batched_finish_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,
+                       (int)P, h->d_poses, h->d_summaries, h->d_results);
+    CLC_HIP(hipGetLastError());
+  }
+  CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcomes written over PCIe visible
   h->results_valid = P;
   std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
   std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
@@ -1868,7 +1868,7 @@ int clc_time_batched_eval(clc_handle* h, const double* poses, int reps, double* 
   const size_t P = h->n_problems;
   std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
   hipLaunchKernelGGL(clc::batched_init_kernel, dim3(bl.lm_blocks), dim3(bl.lm_threads), 0, h->stream, h->d_states, opt,
-                     h->d_poses, (int)P);
+                     h->d_poses, (int)P, h->d_queue, h->d_ticket);
   for (int w = 0; w < 2; ++w) launch_batched_eval(h, opt, bl);
   CLC_HIP(hipEventRecord(h->ev[0], h->stream));
   for (int r = 0; r < reps; ++r) launch_batched_eval(h, opt, bl);

@@ -1940,8 +1940,10 @@ __global__ __launch_bounds__(BT) void batched_rows_eval_kernel(
 }
 
 __global__ __launch_bounds__(64) void batched_init_kernel(LmState* __restrict__ states, const clc_options opt,
-                                    const double* __restrict__ poses, int n_problems) {
+                                    const double* __restrict__ poses, int n_problems, unsigned int* __restrict__ active,
+                                    unsigned int* __restrict__ ticket) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) { *active = 0u; *ticket = 0u; }  // the counters of batched_lm_kernel (two memset launches less per batch)
   if (p >= n_problems) return;
   double x[7];
   for (int i = 0; i < 7; ++i) x[i] = poses[7 * (size_t)p + i];
@@ -1955,11 +1957,34 @@ __global__ __launch_bounds__(64) void batched_init_kernel(LmState* __restrict__ 
 // last-arriving workgroup (ticket pattern, agent-scope atomics) publishes that count and the
 // iteration index to the pinned host mailbox, so the host can run launch-ahead without
 // blocking (status flips to non-zero when no problem is left running).
+// Outcome of one problem: pose + summary to the (pinned, device-mapped) host arrays clc_solve_batched returns, and one
+// clc_result_record in DEVICE memory, where clc_gather_results picks it up for the RCCL all-gather (global_index holds
+// the local index here; the gather adds the shard's first global index).
+__device__ __forceinline__ void batched_write_outcome(const LmState& s, int p, double* __restrict__ poses,
+                                                      clc_summary* __restrict__ summaries, double* __restrict__ results) {
+  for (int i = 0; i < 7; ++i) poses[7 * (size_t)p + i] = s.x_out[i];
+  clc_summary sm;
+  lm_fill_summary(s, sm);
+  sm.solve_ms = 0.0;
+  sm.eval_kernel_ms = 0.0;
+  sm.eval_kernel_launches = 0;
+  summaries[p] = sm;
+  double* r = results + 12 * (size_t)p;
+  for (int i = 0; i < 7; ++i) r[i] = s.x_out[i];
+  r[7] = sm.final_cost;
+  r[8] = sm.initial_cost;
+  r[9] = (double)sm.num_iterations;
+  r[10] = (double)(sm.termination == CLC_RUNNING ? CLC_FAILURE : sm.termination);
+  r[11] = (double)p;
+}
+
+// A problem writes its outcome in the launch in which it terminates (no separate finish launch).
 __global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
                                   LmState* __restrict__ states, const clc_options opt,
                                   const int n_problems, unsigned int* __restrict__ active,
                                   unsigned int* __restrict__ ticket, const int launch_index,
-                                  HostMailbox* mailbox) {
+                                  HostMailbox* mailbox, double* __restrict__ poses, clc_summary* __restrict__ summaries,
+                                  double* __restrict__ results) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   bool still_running = false;
   if (p < n_problems && states[p].status == CLC_RUNNING) {
@@ -1974,6 +1999,7 @@ __global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict
     lm_advance(s, w, opt, nullptr, 0, finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
     states[p] = s;
     still_running = (s.status == CLC_RUNNING);
+    if (!still_running) batched_write_outcome(s, p, poses, summaries, results);
   }
   if (still_running) __hip_atomic_fetch_add(active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1992,29 +2018,15 @@ __global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict
   }
 }
 
-// poses / summaries: pinned host memory (what clc_solve_batched returns); results: the same outcome as one
-// clc_result_record per problem in DEVICE memory, where clc_gather_results picks it up for the RCCL all-gather
-// (global_index holds the local index here; the gather adds the shard's first global index).
+// Stragglers only: problems the host loop stopped launching for while they were still running (they are reported as
+// failures by clc_solve_batched).  Normally every problem has written its outcome in batched_lm_kernel already.
 __global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_problems,
                                       double* __restrict__ poses, clc_summary* __restrict__ summaries,
                                       double* __restrict__ results) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_problems) return;
-  const LmState* s = states + p;
-  for (int i = 0; i < 7; ++i) poses[7 * (size_t)p + i] = s->x_out[i];
-  clc_summary sm;
-  lm_fill_summary(*s, sm);
-  sm.solve_ms = 0.0;
-  sm.eval_kernel_ms = 0.0;
-  sm.eval_kernel_launches = 0;
-  summaries[p] = sm;
-  double* r = results + 12 * (size_t)p;
-  for (int i = 0; i < 7; ++i) r[i] = s->x_out[i];
-  r[7] = sm.final_cost;
-  r[8] = sm.initial_cost;
-  r[9] = (double)sm.num_iterations;
-  r[10] = (double)(sm.termination == CLC_RUNNING ? CLC_FAILURE : sm.termination);
-  r[11] = (double)p;
+  if (states[p].status != CLC_RUNNING) return;
+  batched_write_outcome(states[p], p, poses, summaries, results);
 }
 
 // Send buffer of the all-gather: cap records per rank, the first n_local real (global index = base + local index),
