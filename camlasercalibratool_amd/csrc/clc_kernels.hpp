@@ -882,7 +882,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_totals_kernel(const T
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int off = SCAN_THREADS / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x == 0) totals[blockIdx.x] = sh[0];
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(unsigned long
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-      const unsigned long long a = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      const unsigned long long a = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
       __syncthreads();
       sh[threadIdx.x] += a;
       __syncthreads();
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const TIn* __r
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-    const unsigned long long a = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+    const unsigned long long a = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
     __syncthreads();
     sh[threadIdx.x] += a;
     __syncthreads();
@@ -1323,7 +1323,7 @@ __device__ __forceinline__ void lm_tail_sums(const double* __restrict__ partials
   if (helper) {  // wave-uniform
     const int cc = c < NACC ? c : NACC - 1;
     if (stamps && threadIdx.x == 0) stamps[0] = clock64();
-    if (threadIdx.x < n_stage_words) sh_state[threadIdx.x] = L.my_word;
+    if ((int)threadIdx.x < n_stage_words) sh_state[threadIdx.x] = L.my_word;
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s0 += (c < NACC && g + LM_GROUPS * j < n_blocks) ? L.v[j] : 0.0;
@@ -1371,7 +1371,7 @@ __device__ __forceinline__ bool lm_tail_finish(const LmState* __restrict__ state
 
 // ... and what follows the barrier (the step kernel reads its options from LDS between the two).
 template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS>
-__device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict__ state, LmState* __restrict__ state_out,
+__device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict__ /*state*/, LmState* __restrict__ state_out,
                                                       const clc_options& opt,
                                                       clc_iteration* __restrict__ trace, int trace_cap,
                                                       HostMailbox* mailbox, double (*red)[32], double* sh_state,
