@@ -71,6 +71,21 @@ def test_no_cpu_fallback():
     assert e.value.code == -7
 
 
+def test_rccl_binding_fails_loudly_without_a_gpu():
+    """The multi-GPU entry points bind RCCL at run time (dlopen of the copy already mapped, else the system one).  Without
+    a GPU ncclGetUniqueId fails and the C-ABI reports CLC_ERR_COMM with RCCL's message — no fallback, no crash."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    from camlasercalibratool_amd import solver
+    with pytest.raises(clc.ClcError) as e:
+        solver.comm_unique_id()
+    assert e.value.code == -8 and ("nccl" in str(e.value).lower() or "rccl" in str(e.value).lower())
+
+
 def test_extension_is_in_tree_and_current():
     assert os.path.dirname(_build.LIB_PATH).endswith(os.path.join("camlasercalibratool_amd", "csrc"))
     assert os.path.exists(_build.LIB_PATH)
