@@ -1424,8 +1424,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     const int done = __atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE);
     if (launched < max_evals && launched - done < lookahead) {
       launch_batched_eval(h, opt, bl);
-      hipLaunchKernelGGL(clc::batched_lm_kernel, dim3((unsigned)((P + clc::BLM_PROBLEMS - 1) / clc::BLM_PROBLEMS)),
-                         dim3(clc::BLM_THREADS), 0, h->stream,
+      hipLaunchKernelGGL(clc::batched_lm_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream,
                          h->d_bpartials, bpp, h->d_states, opt, (int)P, h->d_queue, h->d_ticket, launched,
                          h->d_mailbox, h->d_poses, h->d_summaries, h->d_results);
       ++launched;

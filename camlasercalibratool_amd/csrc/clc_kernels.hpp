@@ -1952,6 +1952,11 @@ __global__ __launch_bounds__(64) void batched_init_kernel(LmState* __restrict__ 
   states[p] = s;
 }
 
+// One thread per problem: fixed-order sum of the problem's block partials, then the LM
+// controller.  The workgroups count the problems that still need another evaluation; the
+// last-arriving workgroup (ticket pattern, agent-scope atomics) publishes that count and the
+// iteration index to the pinned host mailbox, so the host can run launch-ahead without
+// blocking (status flips to non-zero when no problem is left running).
 // Outcome of one problem: pose + summary to the (pinned, device-mapped) host arrays clc_solve_batched returns, and one
 // clc_result_record in DEVICE memory, where clc_gather_results picks it up for the RCCL all-gather (global_index holds
 // the local index here; the gather adds the shard's first global index).
@@ -1973,55 +1978,29 @@ __device__ __forceinline__ void batched_write_outcome(const LmState& s, int p, d
   r[11] = (double)p;
 }
 
-// One thread per problem runs the LM controller; the data it needs is staged through LDS with coalesced traffic: a
-// workgroup of 256 threads serves 64 consecutive problems, loads their LM states (64 x 608 contiguous bytes) and sums
-// their partial rows (thread <-> (problem, column) pairs, fixed order over the rows of a problem) into LDS, then threads
-// 0..63 each advance their problem and the states go back the same way.  (One thread reading its own 608-byte state and
-// bpp x 224 bytes of rows touched 64 different cache lines per load instruction: 12-15 us per launch for 8 192
-// problems with four rows each, against ~6 this way.)  A problem writes its outcome in the launch in which it terminates
-// (no separate finish launch).  The workgroups count the problems that still need another evaluation; the last-arriving
-// workgroup (ticket pattern, agent-scope atomics) publishes that count and the iteration index to the pinned host
-// mailbox, so the host can run launch-ahead without blocking (status flips to non-zero when no problem is left running).
-constexpr int BLM_PROBLEMS = 64;
-constexpr int BLM_THREADS = 256;
-
-__global__ __launch_bounds__(BLM_THREADS) void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
+// A problem writes its outcome in the launch in which it terminates (no separate finish launch).
+__global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
                                   LmState* __restrict__ states, const clc_options opt,
                                   const int n_problems, unsigned int* __restrict__ active,
                                   unsigned int* __restrict__ ticket, const int launch_index,
                                   HostMailbox* mailbox, double* __restrict__ poses, clc_summary* __restrict__ summaries,
                                   double* __restrict__ results) {
-  __shared__ double sh_st[BLM_PROBLEMS][LM_STATE_WORDS + 1];  // +1: a thread's own row is read conflict-free
-  __shared__ double sh_tot[BLM_PROBLEMS][NACC + 1];
-  const int p0 = blockIdx.x * BLM_PROBLEMS;
-  const int np = n_problems - p0 < BLM_PROBLEMS ? n_problems - p0 : BLM_PROBLEMS;
-  double* gs = reinterpret_cast<double*>(states + p0);
-  for (int i = threadIdx.x; i < np * LM_STATE_WORDS; i += BLM_THREADS) sh_st[i / LM_STATE_WORDS][i % LM_STATE_WORDS] = gs[i];
-  for (int i = threadIdx.x; i < np * NACC; i += BLM_THREADS) {
-    const int pr = i / NACC, c = i - pr * NACC;
-    const double* pp = partials + ((size_t)(p0 + pr) * blocks_per_problem) * NACC + c;
-    double t = 0.0;
-    for (int j = 0; j < blocks_per_problem; ++j) t += pp[(size_t)j * NACC];  // rows of a terminated problem are stale: unused below
-    sh_tot[pr][c] = t;
-  }
-  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
   bool still_running = false;
-  if ((int)threadIdx.x < np) {
-    const int p = p0 + threadIdx.x;
-    LmState s;
-    for (int w = 0; w < LM_STATE_WORDS; ++w) reinterpret_cast<double*>(&s)[w] = sh_st[threadIdx.x][w];
-    if (s.status == CLC_RUNNING) {
-      double tot[NACC];
-      for (int c = 0; c < NACC; ++c) tot[c] = sh_tot[threadIdx.x][c];
-      LmScratch w;
-      lm_advance(s, w, opt, nullptr, 0, finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
-      for (int k = 0; k < LM_STATE_WORDS; ++k) sh_st[threadIdx.x][k] = reinterpret_cast<const double*>(&s)[k];
-      still_running = (s.status == CLC_RUNNING);
-      if (!still_running) batched_write_outcome(s, p, poses, summaries, results);
+  if (p < n_problems && states[p].status == CLC_RUNNING) {
+    double tot[NACC];
+    for (int c = 0; c < NACC; ++c) tot[c] = 0.0;
+    for (int j = 0; j < blocks_per_problem; ++j) {
+      const double* pp = partials + ((size_t)p * blocks_per_problem + j) * NACC;
+      for (int c = 0; c < NACC; ++c) tot[c] += pp[c];
     }
+    LmState s = states[p];
+    LmScratch w;
+    lm_advance(s, w, opt, nullptr, 0, finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
+    states[p] = s;
+    still_running = (s.status == CLC_RUNNING);
+    if (!still_running) batched_write_outcome(s, p, poses, summaries, results);
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < np * LM_STATE_WORDS; i += BLM_THREADS) gs[i] = sh_st[i / LM_STATE_WORDS][i % LM_STATE_WORDS];
   if (still_running) __hip_atomic_fetch_add(active, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
