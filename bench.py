@@ -170,8 +170,27 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
     return res
 
 
+_RESULT_FD = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries loaded below write banners to the process's stdout from C
+    (RCCL prints its version block when a communicator is created), so file descriptor 1 is pointed at stderr for the
+    duration of the run and the result line is written to the original stdout at the end."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(out):
+    sys.stdout.flush()
+    os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
+
+
 def main():
     args = parse()
+    _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,7 +236,7 @@ def main():
                 "batched_c4_shard": c4,
                 "single_gpu_base": "run `bench.py --gpus 1`: its `batched_c4_shard` sub-object is this workload on one GPU",
             }
-            print(json.dumps(out))
+            _emit(out)
         dist.destroy_process_group()
         return
 
@@ -506,7 +525,7 @@ def main():
         }
 
     if rank == 0:
-        print(json.dumps(out))
+        _emit(out)
     solver.close()
 
 

@@ -1914,3 +1914,15 @@ int clc_time_eval(clc_handle* h, const double pose[7], int with_loss, double lf,
 }
 
 }  // extern "C"
+
+#ifdef CLC_STAMPS
+// Debug build only: copy the step-kernel stamp buffer out and clear it.
+extern "C" int clc_debug_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(clc::clc_stamp_buf)) bytes = sizeof(clc::clc_stamp_buf);
+  if (hipDeviceSynchronize() != hipSuccess) return CLC_ERR_HIP;
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(clc::clc_stamp_buf), bytes) != hipSuccess) return CLC_ERR_HIP;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(clc::clc_stamp_buf)) != hipSuccess) return CLC_ERR_HIP;
+  return hipMemset(p, 0, sizeof(clc::clc_stamp_buf)) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
+}
+#endif

@@ -1306,6 +1306,340 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// lm_advance on a wavefront (the step kernel's controller)
+// ---------------------------------------------------------------------------------------
+// The serial controller (clc_lm.hpp, one lane, state in LDS) is a chain of dependent FP64 instructions and LDS round
+// trips: 7 300 cycles = 3.0 us of every step_kernel launch, in every workgroup (scripts/r02_stamps.py).  What the
+// instructions cost when ONE wave runs them alone (scripts/probes/latency_probe.hip, cycles): dependent FMA 4-6, the
+// same FMA in independent chains 1.3-1.7, a value through v_readlane into the next FMA 24-31, IEEE division 72-98, IEEE
+// sqrt 108-146, dependent LDS read 72-93, compare + select + add 40-50.  So the controller here is written for a short
+// critical path, not for few instructions:
+//   * the state is read from LDS once, up front, in one batch, and written back once; everything scalar (pose, costs,
+//     radius, gradient, Jacobi scales, the triangular solves' running values) is computed redundantly by all lanes
+//     ("uniform") from broadcast LDS reads — no cross-lane traffic for it;
+//   * lane i < 6 owns row i of the Gauss-Newton matrix: scaling, damping, the factorisation's column updates and the
+//     matrix-vector product of the model cost change are one instruction for all rows; the Cholesky factorisation is
+//     right-looking (column j scaled, then subtracted from the columns to its right) with the diagonal in its own
+//     register — per element the same subtractions in the same order as the left-looking serial loop — and the only
+//     values that cross lanes are the pivots, the column entries and the forward substitution's z (v_readlane);
+//   * the trust-region step is computed BEFORE the convergence tests that may make it unnecessary, so that the two
+//     Plus operations of an iteration — Plus(x, -g) for the projected gradient norm and Plus(x, step) for the
+//     candidate — run as one instruction stream in lanes 0 and 1, and so that the tests, the trace record and the
+//     bookkeeping overlap the solve.  Nothing of the speculative step is committed unless the serial controller would
+//     have computed it.  A step that turns out invalid (rare) is handed to the serial loop (lm_iterate).
+// Every expression keeps the operand order and the fused multiply-adds of clc_lm.hpp / clc_math.hpp: results, traces
+// and the state left in LDS are BIT-IDENTICAL to lm_advance<Se3Manifold> (the [evaluation, lm_kernel] launch pair
+// still runs the serial controller: test_step_kernel_solve_matches_two_kernel_path and the randomized problem test
+// compare the two bit for bit).
+// Called by all 64 lanes of one wave; `tot` (LDS): the 28 totals of this pass (H 0..20, g 21..26, cost sum 27), written
+// by this same wave (LDS operations of one wave execute in program order).
+template <bool FIRST>
+__device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o, clc_iteration* __restrict__ trace,
+                                                const int trace_cap, const double* tot, const int lane,
+                                                unsigned long long* stamp_row = nullptr /* debug builds */) {
+  // FIRST: the pass at the start point (state fresh from lm_init, phase 0); otherwise the pass at a candidate (phase 1 —
+  // the only other phase a running solve can be in).  The caller has checked that the solve is still running.
+  // Written without early exits and with selects instead of branches wherever both sides are cheap: a compare feeding a
+  // branch or a select costs a single wave 40-50 cycles (latency_probe), and there were ~35 of them.
+  constexpr int NP = 6, NA = 7;
+  constexpr double DMAX = 1.7976931348623157e308;
+#ifdef CLC_STAMPS
+  long long ck[10];
+  int nck = 0;
+#define CLC_CK() do { ck[nck++] = clock64(); } while (0)
+#else
+#define CLC_CK() do {} while (0)
+#endif
+  CLC_CK();
+  const unsigned i6 = lane < NP ? (unsigned)lane : NP - 1u;
+  // packed upper triangle: index of (a, b), a <= b, is a * (2 NP - 1 - a) / 2 + b
+  const unsigned rowbase = (i6 * (2u * NP - 1u - i6)) >> 1;
+  const unsigned dgi = rowbase + i6;  // H[i][i]
+  unsigned hidx[NP];
+#pragma unroll
+  for (unsigned b = 0; b < NP; ++b) hidx[b] = b < i6 ? ((b * (2u * NP - 1u - b)) >> 1) + i6 : rowbase + b;
+  // ---- everything that comes from LDS, in one batch: this pass ...
+  const double cost_acc = tot[27];
+  double g = tot[21 + i6], Hd = tot[dgi], Hrow[NP], gu[NP];  // lane i: g[i], H[i][i], row i of H; uniform: g
+#pragma unroll
+  for (int b = 0; b < NP; ++b) {
+    Hrow[b] = tot[hidx[b]];
+    gu[b] = tot[21 + b];
+  }
+  // ... and the state (for a candidate pass also g / H at the current iterate, should the step be rejected)
+  const int iteration = s.iteration, n_invalid_in = s.n_invalid, reuse_in = s.reuse_diagonal;
+  const int n_succ_in = s.num_successful, n_unsucc_in = s.num_unsuccessful, n_trace_in = s.n_trace;
+  const long long n_evals = s.n_evals + 1;
+  double x[NA], xe[NA], sc[NP];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) { x[i] = s.x[i]; xe[i] = s.x_eval[i]; }
+#pragma unroll
+  for (int b = 0; b < NP; ++b) sc[b] = s.scale[b];
+  double x_norm = s.x_norm, x_cost = s.x_cost, minimum_cost = s.minimum_cost, initial_cost = s.initial_cost;
+  double min_iter_cost = s.min_iter_cost, radius = s.radius, dfac = s.decrease_factor, gmax = s.gmax;
+  const double mcc = s.model_cost_change;
+  double scale = s.scale[i6];
+  const double diag = s.diag[i6];
+  double g_old = 0.0, Hd_old = 0.0, Hrow_old[NP], gu_old[NP];
+  if (!FIRST) {
+    g_old = s.g[i6];
+    Hd_old = s.H[dgi];
+#pragma unroll
+    for (int b = 0; b < NP; ++b) { Hrow_old[b] = s.H[hidx[b]]; gu_old[b] = s.g[b]; }
+  }
+  // every load above is issued before the first value is consumed: one LDS round trip, not three
+  __builtin_amdgcn_sched_barrier(0);
+  const double cost_e = finalize_cost(cost_acc, o.use_loss != 0, o.loss_scale_factor);
+  const bool finite_eval = fabs(cost_e) <= DMAX;
+  // ---- the pass just evaluated: early terminations (flags; nothing else of the state changes then), acceptance ----
+  int early = CLC_RUNNING;  // termination before the iteration is recorded
+  bool success = true;
+  int reuse = reuse_in;
+  int it_iteration = 0;
+  double it_cost, it_cost_change = 0.0, it_step_norm = 0.0, it_rel = 0.0;
+  if (FIRST) {
+    // ---- IterationZero ----
+    early = finite_eval ? CLC_RUNNING : CLC_FAILURE;
+    x_cost = cost_e;
+    if (o.jacobi_scaling) {
+      scale = 1.0 / (1.0 + sqrt(Hd));
+#pragma unroll
+      for (int b = 0; b < NP; ++b) sc[b] = 1.0 / (1.0 + sqrt(tot[b * NP - (b * (b - 1)) / 2]));
+    }
+    initial_cost = x_cost;
+    min_iter_cost = x_cost;
+    it_cost = x_cost;
+  } else {
+    it_iteration = iteration;
+    const double candidate_cost = finite_eval ? cost_e : DMAX;
+    // ---- ParameterToleranceReached, FunctionToleranceReached ----
+    double sn = 0.0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) sn += (x[i] - xe[i]) * (x[i] - xe[i]);
+    it_step_norm = sqrt_pos(sn);
+    it_cost_change = x_cost - candidate_cost;
+    const bool par_tol = it_step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance);
+    const bool fun_tol = fabs(it_cost_change) <= o.function_tolerance * x_cost;
+    early = par_tol ? CLC_CONVERGENCE_PARAMETER : (fun_tol ? CLC_CONVERGENCE_FUNCTION : CLC_RUNNING);
+    // ---- IsStepSuccessful; HandleSuccessfulStep / HandleUnsuccessfulStep as selects ----
+    it_rel = it_cost_change * rcp_pos(mcc);
+    success = it_rel > o.min_relative_decrease;
+    const double q = 2.0 * it_rel - 1.0;  // StepAccepted
+    double den = 1.0 - q * q * q;
+    den = den > (1.0 / 3.0) ? den : (1.0 / 3.0);
+    double r_acc = radius * rcp_pos(den);
+    r_acc = r_acc < o.max_trust_region_radius ? r_acc : o.max_trust_region_radius;
+    const double r_rej = radius * rcp_pos(dfac);  // StepRejected: radius / decrease_factor, exact (a power of two)
+    radius = success ? r_acc : r_rej;
+    dfac = success ? 2.0 : dfac * 2.0;
+    reuse = success ? 0 : 1;
+    it_cost = candidate_cost;
+    double xn2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) xn2 += xe[i] * xe[i];
+    const double xe_norm = sqrt_pos(xn2);
+    x_norm = success ? xe_norm : x_norm;
+    x_cost = success ? candidate_cost : x_cost;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) x[i] = success ? xe[i] : x[i];
+    // a rejected step is recomputed from the Gauss-Newton system at x
+    g = success ? g : g_old;
+    Hd = success ? Hd : Hd_old;
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      Hrow[b] = success ? Hrow[b] : Hrow_old[b];
+      gu[b] = success ? gu[b] : gu_old[b];
+    }
+  }
+  const int it_succ = success ? 1 : 0;
+  CLC_CK();
+  // ---- lm_compute_step, ahead of the tests that may make it unnecessary (committed after them) ----
+  double Hs[NP], A[NP], gsu[NP];
+#pragma unroll
+  for (int b = 0; b < NP; ++b) {
+    Hs[b] = Hrow[b] * (scale * sc[b]);  // entry b == lane is the diagonal, H[i][i] * (scale[i] * scale[i])
+    A[b] = Hs[b];                       // working copy for the factorisation; its diagonal entry is not used (Ad)
+    gsu[b] = gu[b] * sc[b];
+  }
+  const double gs = g * scale;
+  const double Hds = Hd * (scale * scale);
+  double dcl = Hds;
+  dcl = dcl > o.min_lm_diagonal ? dcl : o.min_lm_diagonal;
+  dcl = dcl < o.max_lm_diagonal ? dcl : o.max_lm_diagonal;
+  const double diag_n = reuse ? diag : dcl;
+  const double inv_radius = rcp_pos(radius);
+  double Ad = Hds + diag_n * inv_radius;  // lane i: the damped diagonal entry, updated in place by the factorisation
+  CLC_CK();
+  // Cholesky, right-looking: Lc[j] = column j of L (lane i: L[i][j], meaningful for i > j), inv[j] = 1 / L[j][j]
+  // (a pivot <= 0 or NaN makes its reciprocal square root, and with it y[j], NaN: the finiteness test of y below is the
+  // serial code's two tests in one)
+  double inv[NP], Lc[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const double d = readlane_d(Ad, j);
+    inv[j] = rsqrt_pos(d);
+    Lc[j] = A[j] * inv[j];
+    Ad -= Lc[j] * Lc[j];
+#pragma unroll
+    for (int k = j + 1; k < NP; ++k) A[k] -= Lc[j] * readlane_d(Lc[j], k);
+  }
+  CLC_CK();
+  // L z = gs: lane i carries row i's running value; z[k] is final after k subtractions
+  double z[NP], run = gs;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    z[k] = readlane_d(run * inv[k], k);
+    run -= Lc[k] * z[k];
+  }
+  // L^T y = z, uniform, subtractions in ascending k like the serial loop
+  double y[NP];
+#pragma unroll
+  for (int i = NP - 1; i >= 0; --i) {
+    double acc = z[i];
+#pragma unroll
+    for (int k = i + 1; k < NP; ++k) acc -= readlane_d(Lc[i], k) * y[k];
+    y[i] = acc * inv[i];
+  }
+  double fin = 0.0;  // 0 * y is (+-)0 for finite y and NaN otherwise
+#pragma unroll
+  for (int c = 0; c < NP; ++c) fin = fma(y[c], 0.0, fin);
+  const bool ok = fin == 0.0;
+  CLC_CK();
+  double step_n[NP], sg = 0.0, shs = 0.0, row = 0.0;
+#pragma unroll
+  for (int a = 0; a < NP; ++a) step_n[a] = -y[a];
+#pragma unroll
+  for (int b = 0; b < NP; ++b) row += Hs[b] * step_n[b];  // lane a: (Hs step)[a]
+#pragma unroll
+  for (int a = 0; a < NP; ++a) {
+    sg += step_n[a] * gsu[a];
+    shs += step_n[a] * readlane_d(row, a);
+  }
+  const double mcc_n = -(sg + 0.5 * shs);
+  const bool step_ok = ok && mcc_n > 0.0;
+  CLC_CK();
+  // ---- Plus: lane 0 the projected gradient (after a change of x / g), lane 1 the candidate ----
+  double cand[NA];
+  {
+    double dlt[NP];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+      const double ng = -gu[c];
+      const double dc = step_n[c] * sc[c];  // undo column scaling
+      dlt[c] = lane == 1 ? dc : ng;
+    }
+    pose_plus_rcp(x, dlt, cand);
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) m = fmax(m, fabs(x[i] - cand[i]));
+    const double gnew = readlane_d(m, 0);
+    gmax = success ? gnew : gmax;
+  }
+  const double it_gmax = gmax;
+  CLC_CK();
+  // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
+  const int n_succ = n_succ_in + it_succ, n_unsucc = n_unsucc_in + (1 - it_succ);
+  const bool xout_dirty = success && x_cost < minimum_cost;
+  minimum_cost = xout_dirty ? x_cost : minimum_cost;
+  min_iter_cost = it_cost < min_iter_cost ? it_cost : min_iter_cost;
+  const bool cap_hit = it_iteration >= o.max_num_iterations;
+  const bool grad_tol = success && it_gmax <= o.gradient_tolerance;
+  const bool rad_tol = radius <= o.min_trust_region_radius;
+  const int status = cap_hit ? CLC_NO_CONVERGENCE : (grad_tol ? CLC_CONVERGENCE_GRADIENT : (rad_tol ? CLC_CONVERGENCE_RADIUS : CLC_RUNNING));
+  // next iteration: the step computed above is the one the serial controller computes at this point
+  const bool cont = status == CLC_RUNNING;
+  const bool candidate_ready = cont && step_ok;
+  const bool invalid_step = cont && !step_ok;  // rare: handed to the serial loop below, once the state is back in LDS
+  const bool step_dirty = cont && ok;  // factorisation and solve went through: step and model cost change are stored
+  CLC_CK();
+  // ---- the state, written once ----
+  if (early != CLC_RUNNING) {  // terminated by a tolerance on the pass itself: nothing else changes, nothing is recorded
+    if (lane == 0) { s.status = early; s.n_evals = n_evals; }
+    return;
+  }
+  if (lane == 0) {
+    if (trace != nullptr && n_trace_in < trace_cap) {
+      clc_iteration it;
+      it.iteration = it_iteration;
+      it.step_is_valid = 1;
+      it.step_is_successful = it_succ;
+      it.pad_ = 0;
+      it.cost = it_cost;
+      it.cost_change = it_cost_change;
+      it.gradient_max_norm = it_gmax;
+      it.step_norm = it_step_norm;
+      it.relative_decrease = it_rel;
+      it.trust_region_radius = radius;
+      trace[n_trace_in] = it;
+    }
+    s.status = status;
+    s.phase = candidate_ready ? 1 : (FIRST ? 0 : 1);
+    s.iteration = candidate_ready ? it_iteration + 1 : iteration;
+    s.n_invalid = candidate_ready ? 0 : n_invalid_in;
+    s.reuse_diagonal = cont ? 1 : reuse;
+    s.num_successful = n_succ;
+    s.num_unsuccessful = n_unsucc;
+    s.n_trace = n_trace_in + 1;
+    s.n_evals = n_evals;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s.x[i] = x[i];
+    s.x_norm = x_norm;
+    s.x_cost = x_cost;
+    s.initial_cost = initial_cost;
+    s.minimum_cost = minimum_cost;
+    s.min_iter_cost = min_iter_cost;
+    s.radius = radius;
+    s.decrease_factor = dfac;
+    s.gmax = gmax;
+    if (xout_dirty) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) s.x_out[i] = x[i];
+    }
+    if (step_dirty) {
+#pragma unroll
+      for (int a = 0; a < NP; ++a) s.step[a] = step_n[a];
+      s.model_cost_change = mcc_n;
+    }
+  }
+  if (lane == 1 && candidate_ready) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s.x_eval[i] = cand[i];
+  }
+  if (lane < NP) {  // (a rejected step stores back what it loaded)
+    s.diag[lane] = cont ? diag_n : diag;
+    s.g[lane] = g;
+    s.scale[lane] = scale;
+#pragma unroll
+    for (int b = 0; b < NP; ++b)
+      if (b >= lane) s.H[hidx[b]] = Hrow[b];
+  }
+  CLC_CK();
+#ifdef CLC_STAMPS
+  if (stamp_row && lane == 0 && nck == 9) {
+    unsigned long long packed0 = 0, packed1 = 0;
+    for (int i = 0; i < 4; ++i) packed0 |= (unsigned long long)((ck[i + 1] - ck[i]) & 0xFFFF) << (16 * i);
+    for (int i = 0; i < 4; ++i) packed1 |= (unsigned long long)((ck[i + 5] - ck[i + 4]) & 0xFFFF) << (16 * i);
+    stamp_row[15] = packed0;
+    stamp_row[6] = packed1;
+  }
+#endif
+  if (invalid_step) {
+    // HandleInvalidStep and whatever follows it (shrunken radius, another step, ...) on the serial controller
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+      clc_iteration it;
+      it.iteration = it_iteration + 1; it.step_is_valid = 0; it.step_is_successful = 0; it.pad_ = 0;
+      it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0;
+      it.relative_decrease = 0.0; it.trust_region_radius = 0.0;
+      LmScratch w;
+      lm_iterate(s, w, o, trace, trace_cap, it, true);
+    }
+  }
+}
+
 // `state` is where the LM state is read from; it is written back to `state_out` (nullptr: not at all — the
 // step kernel's non-leading workgroups run the controller redundantly and keep the result in LDS only).
 // CHECK_STATUS: the staged state is inspected before anything is consumed or published; if the solve had already
@@ -1351,11 +1685,12 @@ __device__ __forceinline__ void lm_tail_sums(const double* __restrict__ partials
   }
 }
 
-template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS>
+template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS, bool WAVE = false>
 __device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict__ state, LmState* __restrict__ state_out,
                                                       const clc_options& opt, clc_iteration* __restrict__ trace, int trace_cap,
                                                       HostMailbox* mailbox, double (*red)[32], double* sh_state,
-                                                      const long long c0, const Pose7* init_pose, const LmLoads& L);
+                                                      const long long c0, const Pose7* init_pose, const LmLoads& L,
+                                                      unsigned long long* stamp_row = nullptr);
 
 // Phase B: barrier, ordered combination of the 16 row groups, LM controller, publication.
 template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS = false>
@@ -1370,12 +1705,13 @@ __device__ __forceinline__ bool lm_tail_finish(const LmState* __restrict__ state
 }
 
 // ... and what follows the barrier (the step kernel reads its options from LDS between the two).
-template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS>
+template <bool COHERENT, bool FIRST, int HT, bool CHECK_STATUS, bool WAVE>
 __device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict__ /*state*/, LmState* __restrict__ state_out,
                                                       const clc_options& opt,
                                                       clc_iteration* __restrict__ trace, int trace_cap,
                                                       HostMailbox* mailbox, double (*red)[32], double* sh_state,
-                                                      const long long c0, const Pose7* init_pose, const LmLoads& L) {
+                                                      const long long c0, const Pose7* init_pose, const LmLoads& L,
+                                                      unsigned long long* stamp_row /* debug builds; nullptr otherwise */) {
   // Called by every thread of the workgroup (it contains a barrier).
   // Progress for the host's launch-ahead metering is published EARLY, by the first lane of wave 1
   // (not the controller's wave): the ~1.5 us a store to pinned host memory needs to be
@@ -1393,22 +1729,43 @@ __device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict_
   }
   // no workgroup barrier here: the 28 lanes above and the controller's lane below are the same wave, whose LDS
   // operations execute in program order; the other waves go straight to the barrier at the end
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (threadIdx.x == 64 && mailbox != nullptr)
     __hip_atomic_store(&mailbox->n_done, (int32_t)(passes_before + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (threadIdx.x == 0) {
-    const long long c1 = clock64();
-    double tot[NACC];
-#pragma unroll
-    for (int cc = 0; cc < NACC; ++cc) tot[cc] = red[0][cc];
-    // The LM state is used in place in LDS: copied into registers and back it cost 256 VGPRs + 48 AGPRs
-    // (occupancy 1 for the fused kernel); in place 148-162, at the same controller time.
+  long long c1w = 0;
+  if (WAVE && threadIdx.x < 64) {  // the controller on all 64 lanes of wave 0 (lm_advance_wave)
+    c1w = clock64();
+    if (stamp_row && threadIdx.x == 0) stamp_row[11] = wall_clock64();
     LmState& st = *reinterpret_cast<LmState*>(sh_state);
-    if (FIRST) lm_init(st, opt, init_pose->v);  // first iteration of a solve: nothing to load
-    LmScratch scratch;
-    lm_advance(st, scratch, opt, trace, trace_cap,
-               finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
+    if (FIRST) {  // first iteration of a solve: nothing to load
+      if (threadIdx.x == 0) lm_init(st, opt, init_pose->v);
+      // lane 0's stores must be visible to the other lanes' loads below: without the fences hipcc is free to hoist those
+      // loads above the (for them never executed) stores — they then read the previous solve's terminated state
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    lm_advance_wave<FIRST>(st, opt, trace, trace_cap, &red[0][0], (int)threadIdx.x, stamp_row);
+  }
+  if (threadIdx.x == 0) {
+    const long long c1 = WAVE ? c1w : clock64();
+    LmState& st = *reinterpret_cast<LmState*>(sh_state);
+    if (!WAVE) {
+      if (stamp_row) stamp_row[11] = wall_clock64();
+      double tot[NACC];
+#pragma unroll
+      for (int cc = 0; cc < NACC; ++cc) tot[cc] = red[0][cc];
+      // The LM state is used in place in LDS: copied into registers and back it cost 256 VGPRs + 48 AGPRs
+      // (occupancy 1 for the fused kernel); in place 148-162, at the same controller time.
+      if (FIRST) lm_init(st, opt, init_pose->v);  // first iteration of a solve: nothing to load
+      LmScratch scratch;
+      lm_advance(st, scratch, opt, trace, trace_cap,
+                 finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
+    }
     const long long c2 = clock64();
+    if (stamp_row) { stamp_row[12] = wall_clock64(); stamp_row[13] = (unsigned long long)c1; stamp_row[14] = (unsigned long long)c2; }
     if (mailbox != nullptr) {
       if (opt.profile_events) { mailbox->prof[0] = c0; mailbox->prof[1] = c1; mailbox->prof[2] = c2; }
       if (st.status != CLC_RUNNING) {
@@ -1576,6 +1933,21 @@ constexpr int PRM_WORDS = (int)(sizeof(SolveParams) / 8);
 static_assert(sizeof(SolveParams) % 8 == 0 && offsetof(SolveBlock, st) == sizeof(SolveParams), "SolveBlock is params, then states");
 static_assert(LM_STATE_WORDS + PRM_WORDS <= 256, "one block word per thread");
 
+#ifdef CLC_STAMPS
+// Debug build only (scripts/r02_stamps.py): wall-clock (100 MHz) stamps of every workgroup of the first 64 launches.
+constexpr int STAMP_LAUNCHES = 64, STAMP_WGS = 512, STAMP_SLOTS = 16;
+__device__ unsigned long long clc_stamp_buf[STAMP_LAUNCHES][STAMP_WGS][STAMP_SLOTS];
+#define CLC_STAMP(slot, tid)                                                                                        \
+  do {                                                                                                              \
+    if (threadIdx.x == (tid) && blockIdx.x < STAMP_WGS && launch_index < STAMP_LAUNCHES)                            \
+      clc_stamp_buf[launch_index][blockIdx.x][slot] = wall_clock64();                                               \
+  } while (0)
+#define CLC_STAMP_ROW (blockIdx.x < STAMP_WGS && launch_index < STAMP_LAUNCHES ? &clc_stamp_buf[launch_index][blockIdx.x][0] : nullptr)
+#else
+#define CLC_STAMP(slot, tid) do {} while (0)
+#define CLC_STAMP_ROW nullptr
+#endif
+
 // LAYOUT 0: compact tiles (ctiles + group table, n = observations); 1: row layout (ctiles = xy rows, groups = row
 // descriptors, n = rows; DEEP selects non-temporal loads, WEIGHTED the 3:2 old/young wave shares).
 template <bool WITH_LOSS, bool DEEP, int MODE, int LAYOUT = 0, bool WEIGHTED = true>
@@ -1593,6 +1965,7 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
   __shared__ double red[LM_GROUPS][32];
   __shared__ double sh_state[LM_STATE_WORDS + PRM_WORDS];  // [0, LM_STATE_WORDS): LM state; then the SolveParams words
   const long long c0 = clock64();
+  CLC_STAMP(0, 0);
   const bool leader = blockIdx.x == 0;
   const int grid = grid_parity & 0x3FFFFFFF;
   const int parity = (grid_parity >> 30) & 1;
@@ -1622,18 +1995,21 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
       inv_lf2 = make_uniform(1.0 / (init.opt.loss_scale_factor * init.opt.loss_scale_factor));
       return true;
     }
+    CLC_STAMP(1, 0);
     __syncthreads();  // state, parameters and row-group sums of every wave are in LDS
+    CLC_STAMP(2, 0);
     const clc_options& opt = prm->opt;
     inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
-    const bool consumed = lm_tail_after_barrier<false, MODE == 1, 512, true>(
+    const bool consumed = lm_tail_after_barrier<false, MODE == 1, 512, true, true>(
         nullptr, leader ? state_out : nullptr, opt, leader ? prm->trace : nullptr, leader ? prm->trace_cap : 0,
-        leader ? prm->mailbox : nullptr, red, sh_state, c0, &prm->pose0, L);
+        leader ? prm->mailbox : nullptr, red, sh_state, c0, &prm->pose0, L, CLC_STAMP_ROW);
     if (!consumed) {
       // the solve had terminated before this launch: hand the state on (the launch queued behind this one reads
       // the other buffer) and leave; the host mailbox is NOT touched — it may already belong to the next solve
       if (leader && threadIdx.x < LM_STATE_WORDS) reinterpret_cast<double*>(state_out)[threadIdx.x] = sh_state[threadIdx.x];
       return false;
     }
+    CLC_STAMP(3, 0);
     const LmState* st = reinterpret_cast<const LmState*>(sh_state);
     const bool running = st->status == CLC_RUNNING;
     double x[7];
@@ -1658,7 +2034,27 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
   else if (DEEP) active = stream_ctiles_deep<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else active = stream_ctiles<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   if (!active) return;  // the controller terminated the solve: nothing to evaluate
+  CLC_STAMP(4, 0);
+  CLC_STAMP(8, 448);
+#ifdef CLC_STAMPS
+  {  // block_reduce_store<8>, stamped
+    __shared__ double wsum_dbg[8][NACC];
+    wave_reduce_butterfly(acc, wsum_dbg[threadIdx.x >> 6], lane);
+    CLC_STAMP(9, 0);
+    __syncthreads();
+    CLC_STAMP(10, 0);
+    if (threadIdx.x < NACC) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += wsum_dbg[w][threadIdx.x];
+      rows_out[(size_t)blockIdx.x * NACC + threadIdx.x] = s;
+    }
+  }
+#else
   block_reduce_store<8>(acc, 0, rows_out + (size_t)blockIdx.x * NACC);
+#endif
+  CLC_STAMP(5, 0);
+  CLC_STAMP(7, 448);
 }
 
 __global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0,

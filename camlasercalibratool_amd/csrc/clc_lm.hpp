@@ -109,8 +109,7 @@ CLC_HD double gradient_max_norm(const double* x, const double* g, LmScratchT<M>&
   M::plus(x, w.ng, w.proj);
   double m = 0.0;
   CLC_ROLLED for (int i = 0; i < M::NA; ++i) {
-    const double a = fabs(x[i] - w.proj[i]);
-    m = a > m ? a : m;
+    m = fmax(m, fabs(x[i] - w.proj[i]));
   }
   return m;
 }
@@ -122,7 +121,7 @@ CLC_HD bool lm_compute_step(LmStateT<M>& s, const clc_options& o, LmScratchT<M>&
   int idx = 0;
   CLC_ROLLED for (int a = 0; a < NP; ++a)
     CLC_ROLLED for (int b = a; b < NP; ++b) {
-      const double v = s.H[idx++] * s.scale[a] * s.scale[b];
+      const double v = s.H[idx++] * (s.scale[a] * s.scale[b]);
       w.Hs[NP * a + b] = v;
       w.Hs[NP * b + a] = v;
     }
@@ -138,7 +137,7 @@ CLC_HD bool lm_compute_step(LmStateT<M>& s, const clc_options& o, LmScratchT<M>&
   CLC_ROLLED for (int i = 0; i < NP * NP; ++i) w.A[i] = w.Hs[i];
   // Ceres appends lm_diagonal = sqrt(diag / radius) as rows of [J; D]; in the normal
   // equations that is + D^2 = diag / radius on the diagonal.
-  const double inv_radius = 1.0 / s.radius;
+  const double inv_radius = rcp_pos(s.radius);
   CLC_ROLLED for (int c = 0; c < NP; ++c) w.A[NP * c + c] += s.diag[c] * inv_radius;
   bool ok = chol_solve<NP>(w.A, w.gs, w.y, w.L, w.z);
   s.reuse_diagonal = 1;
@@ -165,6 +164,62 @@ CLC_HD void lm_record(LmStateT<M>& s, clc_iteration* trace, int trace_cap, const
   if (trace && s.n_trace < trace_cap) trace[s.n_trace] = it;
   s.n_trace++;
   s.min_iter_cost = it.cost < s.min_iter_cost ? it.cost : s.min_iter_cost;
+}
+
+// The loop of TrustRegionMinimizer::Minimize between two evaluations, entered either at the top (`it` = the iteration
+// just evaluated: finalize, record, test, compute the next step) or — `at_invalid_step` — right after a step computation
+// that failed for iteration it.iteration (`it` otherwise zeroed; used by the wavefront controller of the step kernel,
+// which runs the first round itself and hands the rare invalid step over to this serial code).
+template <class M>
+CLC_HD void lm_iterate(LmStateT<M>& s, LmScratchT<M>& w, const clc_options& o, clc_iteration* trace, int trace_cap,
+                       clc_iteration& it, bool at_invalid_step) {
+  constexpr int NP = M::NP, NA = M::NA;
+  for (;;) {
+    if (!at_invalid_step) {
+      // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
+      if (it.step_is_successful) {
+        s.num_successful++;
+        if (s.x_cost < s.minimum_cost) {
+          s.minimum_cost = s.x_cost;
+          CLC_ROLLED for (int i = 0; i < NA; ++i) s.x_out[i] = s.x[i];
+        }
+      } else {
+        s.num_unsuccessful++;
+      }
+      it.trust_region_radius = s.radius;
+      lm_record(s, trace, trace_cap, it);
+      if (it.iteration >= o.max_num_iterations) { s.status = CLC_NO_CONVERGENCE; return; }
+      if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) {
+        s.status = CLC_CONVERGENCE_GRADIENT;
+        return;
+      }
+      if (it.trust_region_radius <= o.min_trust_region_radius) {
+        s.status = CLC_CONVERGENCE_RADIUS;
+        return;
+      }
+      // ---- next iteration: ComputeTrustRegionStep ----
+      const int next = it.iteration + 1;
+      it.iteration = next; it.step_is_valid = 0; it.step_is_successful = 0;
+      it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0;
+      it.relative_decrease = 0.0; it.trust_region_radius = 0.0;
+      if (lm_compute_step(s, o, w)) {
+        s.n_invalid = 0;
+        CLC_ROLLED for (int c = 0; c < NP; ++c) w.delta[c] = s.step[c] * s.scale[c];  // undo column scaling
+        M::plus(s.x, w.delta, s.x_eval);  // candidate
+        s.phase = 1;
+        s.iteration = next;
+        return;  // request an evaluation at x_eval
+      }
+    }
+    at_invalid_step = false;
+    // ---- HandleInvalidStep ----
+    if (++s.n_invalid >= o.max_num_consecutive_invalid_steps) { s.status = CLC_FAILURE; return; }
+    s.radius = s.radius / s.decrease_factor;  // StepIsInvalid == StepRejected(0)
+    s.decrease_factor *= 2.0;
+    s.reuse_diagonal = 1;
+    it.cost = s.x_cost;
+    it.gradient_max_norm = s.gmax;
+  }
 }
 
 // Consume one evaluation {cost, g[NP], H[NH]} taken at s.x_eval and advance to the next
@@ -205,7 +260,7 @@ CLC_HD void lm_advance(LmStateT<M>& s, LmScratchT<M>& w, const clc_options& o, c
     // ---- ParameterToleranceReached ----
     double sn = 0.0;
     CLC_ROLLED for (int i = 0; i < NA; ++i) sn += (s.x[i] - s.x_eval[i]) * (s.x[i] - s.x_eval[i]);
-    it.step_norm = sqrt(sn);
+    it.step_norm = sqrt_pos(sn);
     if (it.step_norm <= o.parameter_tolerance * (s.x_norm + o.parameter_tolerance)) {
       s.status = CLC_CONVERGENCE_PARAMETER;
       return;
@@ -217,7 +272,7 @@ CLC_HD void lm_advance(LmStateT<M>& s, LmScratchT<M>& w, const clc_options& o, c
       return;
     }
     // ---- IsStepSuccessful (monotonic step evaluator) ----
-    it.relative_decrease = it.cost_change / s.model_cost_change;
+    it.relative_decrease = it.cost_change * rcp_pos(s.model_cost_change);  // model_cost_change > 0 (lm_compute_step)
     if (it.relative_decrease > o.min_relative_decrease) {
       // ---- HandleSuccessfulStep: the fused pass already produced g,H at the candidate ----
       CLC_ROLLED for (int i = 0; i < NA; ++i) s.x[i] = s.x_eval[i];
@@ -232,7 +287,7 @@ CLC_HD void lm_advance(LmStateT<M>& s, LmScratchT<M>& w, const clc_options& o, c
       const double q = 2.0 * it.relative_decrease - 1.0;  // StepAccepted
       double den = 1.0 - q * q * q;
       den = den > (1.0 / 3.0) ? den : (1.0 / 3.0);
-      s.radius = s.radius / den;
+      s.radius = s.radius * rcp_pos(den);  // den >= 1/3
       s.radius = s.radius < o.max_trust_region_radius ? s.radius : o.max_trust_region_radius;
       s.decrease_factor = 2.0;
       s.reuse_diagonal = 0;
@@ -247,49 +302,7 @@ CLC_HD void lm_advance(LmStateT<M>& s, LmScratchT<M>& w, const clc_options& o, c
     }
   }
 
-  for (;;) {
-    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
-    if (it.step_is_successful) {
-      s.num_successful++;
-      if (s.x_cost < s.minimum_cost) {
-        s.minimum_cost = s.x_cost;
-        CLC_ROLLED for (int i = 0; i < NA; ++i) s.x_out[i] = s.x[i];
-      }
-    } else {
-      s.num_unsuccessful++;
-    }
-    it.trust_region_radius = s.radius;
-    lm_record(s, trace, trace_cap, it);
-    if (it.iteration >= o.max_num_iterations) { s.status = CLC_NO_CONVERGENCE; return; }
-    if (it.step_is_successful && it.gradient_max_norm <= o.gradient_tolerance) {
-      s.status = CLC_CONVERGENCE_GRADIENT;
-      return;
-    }
-    if (it.trust_region_radius <= o.min_trust_region_radius) {
-      s.status = CLC_CONVERGENCE_RADIUS;
-      return;
-    }
-    // ---- next iteration: ComputeTrustRegionStep ----
-    const int next = it.iteration + 1;
-    it.iteration = next; it.step_is_valid = 0; it.step_is_successful = 0;
-    it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0;
-    it.relative_decrease = 0.0; it.trust_region_radius = 0.0;
-    if (lm_compute_step(s, o, w)) {
-      s.n_invalid = 0;
-      CLC_ROLLED for (int c = 0; c < NP; ++c) w.delta[c] = s.step[c] * s.scale[c];  // undo column scaling
-      M::plus(s.x, w.delta, s.x_eval);  // candidate
-      s.phase = 1;
-      s.iteration = next;
-      return;  // request an evaluation at x_eval
-    }
-    // ---- HandleInvalidStep ----
-    if (++s.n_invalid >= o.max_num_consecutive_invalid_steps) { s.status = CLC_FAILURE; return; }
-    s.radius = s.radius / s.decrease_factor;  // StepIsInvalid == StepRejected(0)
-    s.decrease_factor *= 2.0;
-    s.reuse_diagonal = 1;
-    it.cost = s.x_cost;
-    it.gradient_max_norm = s.gmax;
-  }
+  lm_iterate(s, w, o, trace, trace_cap, it, false);
 }
 
 template <class M>

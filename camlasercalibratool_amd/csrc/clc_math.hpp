@@ -36,6 +36,30 @@ CLC_HD double rsqrt_pos(double x) {
 #endif
 }
 
+// 1/x for x > 0 (<= 1 ulp): v_rcp_f64 seed + two Newton steps, 5 instructions (~40 cycles of dependent latency)
+// instead of the ~10-instruction, 70-100-cycle IEEE division sequence (scripts/probes/latency_probe.hip) — the
+// controller's divisions (1/radius, cost_change/model_cost_change, radius/den) sit on its critical path.
+CLC_HD double rcp_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+#else
+  return 1.0 / x;
+#endif
+}
+
+// sqrt(x) for x >= 0 as x * rsqrt(x) (<= 2 ulp; 0 for 0): used for norms that only feed tolerance tests and the trace.
+CLC_HD double sqrt_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r = x * rsqrt_pos(x);  // NaN for x == 0 (0 * inf): selected away, no branch
+  return x > 0.0 ? r : 0.0;
+#else
+  return sqrt(x);
+#endif
+}
+
 // q = (x,y,z,w) as stored in the 7-vector (src/LaseCamCalCeres.cpp:219); R row-major.
 // No normalisation, like Eigen.
 CLC_HD void quat_to_rot(const double* q, double* R) {
@@ -90,7 +114,7 @@ template <int N>
 CLC_HD double norm_n(const double* x) {
   double s = 0.0;
   CLC_ROLLED for (int i = 0; i < N; ++i) s += x[i] * x[i];
-  return sqrt(s);
+  return sqrt_pos(s);
 }
 CLC_HD double norm7(const double* x) { return norm_n<7>(x); }
 
