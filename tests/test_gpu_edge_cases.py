@@ -62,6 +62,40 @@ def test_unobservable_only_pitch_configuration(sv, oracle_mod):
     assert res.summary.num_iterations == ref.summary.num_iterations
 
 
+@pytest.mark.parametrize("max_invalid", [5, 2])
+def test_invalid_steps_take_the_same_path_in_the_wavefront_and_the_serial_controller(sv, oracle_mod, max_invalid):
+    """Rank-deficient problems (k distinct points of one scan, repeated) with the LM diagonal clamp opened to [0, 0]:
+    the undamped normal matrix is exactly singular up to rounding, so step computations fail (non-positive pivot,
+    non-finite solution or non-positive model cost change), the radius shrinks, and after
+    max_num_consecutive_invalid_steps the solve stops with FAILURE.  The step kernel's wavefront controller hands an
+    invalid step to the serial loop (lm_iterate): pose, summary and the whole iteration trace must equal the
+    [evaluation, lm_kernel] launch pair's (serial controller throughout) bit for bit."""
+    S = sd.sim_fixed_count(5, 1, 300, noise_sigma=0.0)
+    base = clc.flatten_observations(S, False)
+    o = clc.default_options()
+    o.min_lm_diagonal = 0.0
+    o.max_lm_diagonal = 0.0
+    o.max_num_consecutive_invalid_steps = max_invalid
+    seen_invalid = 0
+    for k in (1, 2, 3, 5):
+        rec = np.ascontiguousarray(np.tile(base[:k], (200 // k, 1)))
+        sv.upload(rec)
+        res = {}
+        for name, fl in (("pair_compact", 2 | 16 | 32), ("step_compact", 2 | 16 | 32 | 128), ("pair_rows", 2 | 32 | 256), ("step_rows", 2 | 32 | 128 | 256)):
+            sv.set_launch(0, fl)
+            res[name] = sv.solve(X0, o)
+        sv.set_launch(0, -1)
+        for a, b in (("step_compact", "pair_compact"), ("step_rows", "pair_rows")):
+            ra, rb = res[a], res[b]
+            assert np.array_equal(ra.pose, rb.pose, equal_nan=True) and ra.summary.termination == rb.summary.termination, (k, a)
+            assert ra.summary.num_iterations == rb.summary.num_iterations and ra.summary.num_evaluations == rb.summary.num_evaluations, (k, a)
+            assert ra.summary.final_cost == rb.summary.final_cost
+            assert [(t.iteration, t.cost, t.step_is_valid, t.step_is_successful, t.trust_region_radius, t.gradient_max_norm) for t in ra.trace] == \
+                   [(t.iteration, t.cost, t.step_is_valid, t.step_is_successful, t.trust_region_radius, t.gradient_max_norm) for t in rb.trace], (k, a)
+        seen_invalid += sum(t.step_is_valid == 0 for t in res["step_rows"].trace) + sum(t.step_is_valid == 0 for t in res["step_compact"].trace)
+    assert seen_invalid > 0, "the configurations are meant to produce invalid steps"
+
+
 def test_gross_outliers_cauchy_loss(sv, oracle_mod):
     """10 % of the scan points are off by up to 1 m: the Cauchy loss (LaseCamCalCeres.cpp:249)
     keeps the estimate at the ground truth; with the loss disabled it is pulled away."""
