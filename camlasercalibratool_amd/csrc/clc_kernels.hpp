@@ -1345,7 +1345,7 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   constexpr int NP = 6, NA = 7;
   constexpr double DMAX = 1.7976931348623157e308;
 #ifdef CLC_STAMPS
-  long long ck[10];
+  long long ck[12];
   int nck = 0;
 #define CLC_CK() do { ck[nck++] = clock64(); } while (0)
 #else
@@ -1553,79 +1553,75 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   const bool invalid_step = cont && !step_ok;  // rare: handed to the serial loop below, once the state is back in LDS
   const bool step_dirty = cont && ok;  // factorisation and solve went through: step and model cost change are stored
   CLC_CK();
-  // ---- the state, written once ----
-  if (early != CLC_RUNNING) {  // terminated by a tolerance on the pass itself: nothing else changes, nothing is recorded
-    if (lane == 0) { s.status = early; s.n_evals = n_evals; }
-    return;
-  }
+  // ---- what the other waves wait for — the next point to evaluate and whether the solve goes on — first; they leave
+  // for their rows at the barrier below while this wave writes the rest of the state back (the trace record, ~45 LDS
+  // words, the bookkeeping's selects: ~0.7 us that used to sit in front of every wave's first row) ----
+  auto write_back = [&]() {
+    if (lane == 0) {
+      if (trace != nullptr && n_trace_in < trace_cap) {
+        clc_iteration it;
+        it.iteration = it_iteration;
+        it.step_is_valid = 1;
+        it.step_is_successful = it_succ;
+        it.pad_ = 0;
+        it.cost = it_cost;
+        it.cost_change = it_cost_change;
+        it.gradient_max_norm = it_gmax;
+        it.step_norm = it_step_norm;
+        it.relative_decrease = it_rel;
+        it.trust_region_radius = radius;
+        trace[n_trace_in] = it;
+      }
+      s.phase = candidate_ready ? 1 : (FIRST ? 0 : 1);
+      s.iteration = candidate_ready ? it_iteration + 1 : iteration;
+      s.n_invalid = candidate_ready ? 0 : n_invalid_in;
+      s.reuse_diagonal = cont ? 1 : reuse;
+      s.num_successful = n_succ;
+      s.num_unsuccessful = n_unsucc;
+      s.n_trace = n_trace_in + 1;
+      s.n_evals = n_evals;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) s.x[i] = x[i];
+      s.x_norm = x_norm;
+      s.x_cost = x_cost;
+      s.initial_cost = initial_cost;
+      s.minimum_cost = minimum_cost;
+      s.min_iter_cost = min_iter_cost;
+      s.radius = radius;
+      s.decrease_factor = dfac;
+      s.gmax = gmax;
+      if (xout_dirty) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) s.x_out[i] = x[i];
+      }
+      if (step_dirty) {
+#pragma unroll
+        for (int a = 0; a < NP; ++a) s.step[a] = step_n[a];
+        s.model_cost_change = mcc_n;
+      }
+    }
+    if (lane < NP) {  // (a rejected step stores back what it loaded)
+      s.diag[lane] = cont ? diag_n : diag;
+      s.g[lane] = g;
+      s.scale[lane] = scale;
+#pragma unroll
+      for (int b = 0; b < NP; ++b)
+        if (b >= lane) s.H[hidx[b]] = Hrow[b];
+    }
+  };
+  const bool slow_path = early == CLC_RUNNING && invalid_step;
   if (lane == 0) {
-    if (trace != nullptr && n_trace_in < trace_cap) {
-      clc_iteration it;
-      it.iteration = it_iteration;
-      it.step_is_valid = 1;
-      it.step_is_successful = it_succ;
-      it.pad_ = 0;
-      it.cost = it_cost;
-      it.cost_change = it_cost_change;
-      it.gradient_max_norm = it_gmax;
-      it.step_norm = it_step_norm;
-      it.relative_decrease = it_rel;
-      it.trust_region_radius = radius;
-      trace[n_trace_in] = it;
-    }
-    s.status = status;
-    s.phase = candidate_ready ? 1 : (FIRST ? 0 : 1);
-    s.iteration = candidate_ready ? it_iteration + 1 : iteration;
-    s.n_invalid = candidate_ready ? 0 : n_invalid_in;
-    s.reuse_diagonal = cont ? 1 : reuse;
-    s.num_successful = n_succ;
-    s.num_unsuccessful = n_unsucc;
-    s.n_trace = n_trace_in + 1;
-    s.n_evals = n_evals;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) s.x[i] = x[i];
-    s.x_norm = x_norm;
-    s.x_cost = x_cost;
-    s.initial_cost = initial_cost;
-    s.minimum_cost = minimum_cost;
-    s.min_iter_cost = min_iter_cost;
-    s.radius = radius;
-    s.decrease_factor = dfac;
-    s.gmax = gmax;
-    if (xout_dirty) {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) s.x_out[i] = x[i];
-    }
-    if (step_dirty) {
-#pragma unroll
-      for (int a = 0; a < NP; ++a) s.step[a] = step_n[a];
-      s.model_cost_change = mcc_n;
-    }
+    s.status = early != CLC_RUNNING ? early : status;
+    if (early != CLC_RUNNING) s.n_evals = n_evals;  // terminated by a tolerance on the pass itself: nothing else changes
   }
-  if (lane == 1 && candidate_ready) {
+  if (lane == 1 && early == CLC_RUNNING && candidate_ready) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) s.x_eval[i] = cand[i];
   }
-  if (lane < NP) {  // (a rejected step stores back what it loaded)
-    s.diag[lane] = cont ? diag_n : diag;
-    s.g[lane] = g;
-    s.scale[lane] = scale;
-#pragma unroll
-    for (int b = 0; b < NP; ++b)
-      if (b >= lane) s.H[hidx[b]] = Hrow[b];
-  }
-  CLC_CK();
-#ifdef CLC_STAMPS
-  if (stamp_row && lane == 0 && nck == 9) {
-    unsigned long long packed0 = 0, packed1 = 0;
-    for (int i = 0; i < 4; ++i) packed0 |= (unsigned long long)((ck[i + 1] - ck[i]) & 0xFFFF) << (16 * i);
-    for (int i = 0; i < 4; ++i) packed1 |= (unsigned long long)((ck[i + 5] - ck[i + 4]) & 0xFFFF) << (16 * i);
-    stamp_row[15] = packed0;
-    stamp_row[6] = packed1;
-  }
-#endif
-  if (invalid_step) {
-    // HandleInvalidStep and whatever follows it (shrunken radius, another step, ...) on the serial controller
+  if (slow_path) {
+    // rare: HandleInvalidStep and whatever follows it (shrunken radius, another step, ...) on the serial controller,
+    // which works on the complete state in LDS and decides status and candidate — before anybody leaves
+    write_back();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1638,6 +1634,19 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
       lm_iterate(s, w, o, trace, trace_cap, it, true);
     }
   }
+  CLC_CK();
+  __syncthreads();  // pairs with the barrier the other waves of the workgroup execute in lm_tail_after_barrier
+  if (early == CLC_RUNNING && !slow_path) write_back();
+  CLC_CK();
+#ifdef CLC_STAMPS
+  if (stamp_row && lane == 0 && nck == 10) {
+    unsigned long long packed0 = 0, packed1 = 0;
+    for (int i = 0; i < 4; ++i) packed0 |= (unsigned long long)((ck[i + 1] - ck[i]) & 0xFFFF) << (16 * i);
+    for (int i = 0; i < 4; ++i) packed1 |= (unsigned long long)((ck[i + 5] - ck[i + 4]) & 0xFFFF) << (16 * i);
+    stamp_row[15] = packed0;
+    stamp_row[6] = packed1;
+  }
+#endif
 }
 
 // `state` is where the LM state is read from; it is written back to `state_out` (nullptr: not at all — the
@@ -1734,36 +1743,67 @@ __device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict_
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (threadIdx.x == 64 && mailbox != nullptr)
     __hip_atomic_store(&mailbox->n_done, (int32_t)(passes_before + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  long long c1w = 0;
-  if (WAVE && threadIdx.x < 64) {  // the controller on all 64 lanes of wave 0 (lm_advance_wave)
-    c1w = clock64();
-    if (stamp_row && threadIdx.x == 0) stamp_row[11] = wall_clock64();
-    LmState& st = *reinterpret_cast<LmState*>(sh_state);
-    if (FIRST) {  // first iteration of a solve: nothing to load
-      if (threadIdx.x == 0) lm_init(st, opt, init_pose->v);
-      // lane 0's stores must be visible to the other lanes' loads below: without the fences hipcc is free to hoist those
-      // loads above the (for them never executed) stores — they then read the previous solve's terminated state
+  if (WAVE) {
+    // The controller on all 64 lanes of wave 0 (lm_advance_wave).  It publishes the next point / the status, meets the
+    // other waves at ONE workgroup barrier — from which they leave for their rows — and only then writes the rest of
+    // the state back, publishes a termination to the host and (leading workgroup) copies the state to device memory.
+    if (threadIdx.x < 64) {
+      const long long c1 = clock64();
+      if (stamp_row && threadIdx.x == 0) stamp_row[11] = wall_clock64();
+      LmState& st = *reinterpret_cast<LmState*>(sh_state);
+      if (FIRST) {  // first iteration of a solve: nothing to load
+        if (threadIdx.x == 0) lm_init(st, opt, init_pose->v);
+        // lane 0's stores must be visible to the other lanes' loads below: without the fences hipcc is free to hoist those
+        // loads above the (for them never executed) stores — they then read the previous solve's terminated state
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      lm_advance_wave<FIRST>(st, opt, trace, trace_cap, &red[0][0], (int)threadIdx.x, stamp_row);  // contains the barrier
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (threadIdx.x == 0) {
+        const long long c2 = clock64();
+        if (stamp_row) { stamp_row[12] = wall_clock64(); stamp_row[13] = (unsigned long long)c1; stamp_row[14] = (unsigned long long)c2; }
+        if (mailbox != nullptr) {
+          if (opt.profile_events) { mailbox->prof[0] = c0; mailbox->prof[1] = c1; mailbox->prof[2] = c2; }
+          if (st.status != CLC_RUNNING) {
+            // termination: payload first, then system-scope release stores of the flags
+            clc_summary sm;
+            lm_fill_summary(st, sm);
+            sm.solve_ms = 0.0;
+            sm.eval_kernel_ms = 0.0;
+            sm.eval_kernel_launches = 0;
+            mailbox->summary = sm;
+            for (int i = 0; i < 7; ++i) mailbox->pose[i] = st.x_out[i];
+            __hip_atomic_store(&mailbox->n_done, (int32_t)st.n_evals, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mailbox->status, st.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          if (opt.profile_events) mailbox->prof[3] = clock64();
+        }
+      }
+      if (state_out != nullptr) {
+        for (int w = threadIdx.x; w < LM_STATE_WORDS; w += 64) reinterpret_cast<double*>(state_out)[w] = sh_state[w];
+      }
+    } else {
+      __syncthreads();  // the barrier inside lm_advance_wave
     }
-    lm_advance_wave<FIRST>(st, opt, trace, trace_cap, &red[0][0], (int)threadIdx.x, stamp_row);
+    return true;
   }
   if (threadIdx.x == 0) {
-    const long long c1 = WAVE ? c1w : clock64();
+    const long long c1 = clock64();
     LmState& st = *reinterpret_cast<LmState*>(sh_state);
-    if (!WAVE) {
-      if (stamp_row) stamp_row[11] = wall_clock64();
-      double tot[NACC];
+    if (stamp_row) stamp_row[11] = wall_clock64();
+    double tot[NACC];
 #pragma unroll
-      for (int cc = 0; cc < NACC; ++cc) tot[cc] = red[0][cc];
-      // The LM state is used in place in LDS: copied into registers and back it cost 256 VGPRs + 48 AGPRs
-      // (occupancy 1 for the fused kernel); in place 148-162, at the same controller time.
-      if (FIRST) lm_init(st, opt, init_pose->v);  // first iteration of a solve: nothing to load
-      LmScratch scratch;
-      lm_advance(st, scratch, opt, trace, trace_cap,
-                 finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
-    }
+    for (int cc = 0; cc < NACC; ++cc) tot[cc] = red[0][cc];
+    // The LM state is used in place in LDS: copied into registers and back it cost 256 VGPRs + 48 AGPRs
+    // (occupancy 1 for the fused kernel); in place 148-162, at the same controller time.
+    if (FIRST) lm_init(st, opt, init_pose->v);  // first iteration of a solve: nothing to load
+    LmScratch scratch;
+    lm_advance(st, scratch, opt, trace, trace_cap,
+               finalize_cost(tot[27], opt.use_loss != 0, opt.loss_scale_factor), tot + 21, tot);
     const long long c2 = clock64();
     if (stamp_row) { stamp_row[12] = wall_clock64(); stamp_row[13] = (unsigned long long)c1; stamp_row[14] = (unsigned long long)c2; }
     if (mailbox != nullptr) {

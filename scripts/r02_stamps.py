@@ -60,6 +60,6 @@ for k in range(1, min(npass, NL)):
           f"butterfly {np.median(us(e9 - e4)):5.2f} | barrier wait {np.median(us(e10 - e9)):5.2f} | sum+store {np.median(us(e5 - e10)):5.2f}")
     p0 = t[k, 5, 15]; p1 = t[k, 5, 6]
     seg = [(int(p0) >> (16 * i)) & 0xFFFF for i in range(4)] + [(int(p1) >> (16 * i)) & 0xFFFF for i in range(4)]
-    print("      controller cycles (workgroup 5): load+prelude %d | Hs/A %d | cholesky %d | solves %d | model %d | plus+gmax %d | finalize+record %d | write-back %d" % tuple(seg))
+    print("      controller cycles (workgroup 5): load+prelude %d | Hs/A %d | cholesky %d | solves %d | model %d | plus+gmax %d | finalize %d | publish %d (then barrier + write-back, off the other waves' path)" % tuple(seg))
 if "--dump" in sys.argv:
     np.save(os.path.join(ROOT, "gpurun_out", "r02_stamps.npy"), t)
