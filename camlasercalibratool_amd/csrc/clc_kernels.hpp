@@ -1336,8 +1336,10 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
 // by this same wave (LDS operations of one wave execute in program order).
 template <bool FIRST>
 __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o, clc_iteration* __restrict__ trace,
-                                                const int trace_cap, const double* tot, const int lane,
+                                                const int trace_cap, const double* tot, double* park, const int lane,
                                                 unsigned long long* stamp_row = nullptr /* debug builds */) {
+  // `park`: LDS nobody else touches; 32 doubles in, room for the serial controller's temporaries (LmScratch) on the
+  // invalid-step path — held in registers they made hipcc spill the whole kernel's controller.
   // FIRST: the pass at the start point (state fresh from lm_init, phase 0); otherwise the pass at a candidate (phase 1 —
   // the only other phase a running solve can be in).  The caller has checked that the solve is still running.
   // Written without early exits and with selects instead of branches wherever both sides are cheap: a compare feeding a
@@ -1361,13 +1363,10 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   for (unsigned b = 0; b < NP; ++b) hidx[b] = b < i6 ? ((b * (2u * NP - 1u - b)) >> 1) + i6 : rowbase + b;
   // ---- everything that comes from LDS, in one batch: this pass ...
   const double cost_acc = tot[27];
-  double g = tot[21 + i6], Hd = tot[dgi], Hrow[NP], gu[NP];  // lane i: g[i], H[i][i], row i of H; uniform: g
+  double g = tot[21 + i6], Hd = tot[dgi], Hrow[NP];  // lane i: g[i], H[i][i], row i of H
 #pragma unroll
-  for (int b = 0; b < NP; ++b) {
-    Hrow[b] = tot[hidx[b]];
-    gu[b] = tot[21 + b];
-  }
-  // ... and the state (for a candidate pass also g / H at the current iterate, should the step be rejected)
+  for (int b = 0; b < NP; ++b) Hrow[b] = tot[hidx[b]];
+  // ... and the state
   const int iteration = s.iteration, n_invalid_in = s.n_invalid, reuse_in = s.reuse_diagonal;
   const int n_succ_in = s.num_successful, n_unsucc_in = s.num_unsuccessful, n_trace_in = s.n_trace;
   const long long n_evals = s.n_evals + 1;
@@ -1381,13 +1380,6 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   const double mcc = s.model_cost_change;
   double scale = s.scale[i6];
   const double diag = s.diag[i6];
-  double g_old = 0.0, Hd_old = 0.0, Hrow_old[NP], gu_old[NP];
-  if (!FIRST) {
-    g_old = s.g[i6];
-    Hd_old = s.H[dgi];
-#pragma unroll
-    for (int b = 0; b < NP; ++b) { Hrow_old[b] = s.H[hidx[b]]; gu_old[b] = s.g[b]; }
-  }
   // every load above is issued before the first value is consumed: one LDS round trip, not three
   __builtin_amdgcn_sched_barrier(0);
   const double cost_e = finalize_cost(cost_acc, o.use_loss != 0, o.loss_scale_factor);
@@ -1402,10 +1394,14 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
     // ---- IterationZero ----
     early = finite_eval ? CLC_RUNNING : CLC_FAILURE;
     x_cost = cost_e;
-    if (o.jacobi_scaling) {
+    if (o.jacobi_scaling) {  // once per solve: computed by the lane that owns the column, broadcast through LDS
       scale = 1.0 / (1.0 + sqrt(Hd));
+      if (lane < NP) s.scale[lane] = scale;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int b = 0; b < NP; ++b) sc[b] = 1.0 / (1.0 + sqrt(tot[b * NP - (b * (b - 1)) / 2]));
+      for (int b = 0; b < NP; ++b) sc[b] = s.scale[b];
     }
     initial_cost = x_cost;
     min_iter_cost = x_cost;
@@ -1443,24 +1439,49 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
     x_cost = success ? candidate_cost : x_cost;
 #pragma unroll
     for (int i = 0; i < NA; ++i) x[i] = success ? xe[i] : x[i];
-    // a rejected step is recomputed from the Gauss-Newton system at x
-    g = success ? g : g_old;
-    Hd = success ? Hd : Hd_old;
+    if (!success) {
+      // a rejected step (the minority) is recomputed from the Gauss-Newton system at x: one more LDS round trip on this
+      // branch instead of 8 more doubles loaded and selected on every pass (the kernel has no registers to spare)
+      g = s.g[i6];
+      Hd = s.H[dgi];
 #pragma unroll
-    for (int b = 0; b < NP; ++b) {
-      Hrow[b] = success ? Hrow[b] : Hrow_old[b];
-      gu[b] = success ? gu[b] : gu_old[b];
+      for (int b = 0; b < NP; ++b) Hrow[b] = s.H[hidx[b]];
     }
   }
   const int it_succ = success ? 1 : 0;
+  const int n_succ = n_succ_in + it_succ, n_unsucc = n_unsucc_in + (1 - it_succ);
+  const bool xout_dirty = success && x_cost < minimum_cost;
+  minimum_cost = xout_dirty ? x_cost : minimum_cost;
+  min_iter_cost = it_cost < min_iter_cost ? it_cost : min_iter_cost;
+  // What is final already and not part of a solve's outputs goes back to LDS now, unconditionally (after an early
+  // termination nobody reads it): the stores overlap the solve below and free their registers — with everything held
+  // until the write-back the kernel spilled.  The trace record's fields wait in `park`.
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s.x[i] = x[i];
+    s.x_norm = x_norm;
+    s.x_cost = x_cost;
+    s.decrease_factor = dfac;
+    s.radius = radius;
+    park[0] = it_cost;
+    park[1] = it_cost_change;
+    park[2] = it_step_norm;
+    park[3] = it_rel;
+  }
+  if (lane < NP) {  // (a rejected step stores back what it loaded)
+    s.g[lane] = g;
+    s.scale[lane] = scale;
+#pragma unroll
+    for (int b = 0; b < NP; ++b)
+      if (b >= lane) s.H[hidx[b]] = Hrow[b];
+  }
   CLC_CK();
   // ---- lm_compute_step, ahead of the tests that may make it unnecessary (committed after them) ----
-  double Hs[NP], A[NP], gsu[NP];
+  double Hs[NP], A[NP];
 #pragma unroll
   for (int b = 0; b < NP; ++b) {
     Hs[b] = Hrow[b] * (scale * sc[b]);  // entry b == lane is the diagonal, H[i][i] * (scale[i] * scale[i])
     A[b] = Hs[b];                       // working copy for the factorisation; its diagonal entry is not used (Ad)
-    gsu[b] = gu[b] * sc[b];
   }
   const double gs = g * scale;
   const double Hds = Hd * (scale * scale);
@@ -1513,7 +1534,7 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   for (int b = 0; b < NP; ++b) row += Hs[b] * step_n[b];  // lane a: (Hs step)[a]
 #pragma unroll
   for (int a = 0; a < NP; ++a) {
-    sg += step_n[a] * gsu[a];
+    sg += step_n[a] * readlane_d(gs, a);
     shs += step_n[a] * readlane_d(row, a);
   }
   const double mcc_n = -(sg + 0.5 * shs);
@@ -1525,7 +1546,7 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
     double dlt[NP];
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
-      const double ng = -gu[c];
+      const double ng = -readlane_d(g, c);
       const double dc = step_n[c] * sc[c];  // undo column scaling
       dlt[c] = lane == 1 ? dc : ng;
     }
@@ -1539,10 +1560,6 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   const double it_gmax = gmax;
   CLC_CK();
   // ---- FinalizeIterationAndCheckIfMinimizerCanContinue ----
-  const int n_succ = n_succ_in + it_succ, n_unsucc = n_unsucc_in + (1 - it_succ);
-  const bool xout_dirty = success && x_cost < minimum_cost;
-  minimum_cost = xout_dirty ? x_cost : minimum_cost;
-  min_iter_cost = it_cost < min_iter_cost ? it_cost : min_iter_cost;
   const bool cap_hit = it_iteration >= o.max_num_iterations;
   const bool grad_tol = success && it_gmax <= o.gradient_tolerance;
   const bool rad_tol = radius <= o.min_trust_region_radius;
@@ -1564,11 +1581,11 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
         it.step_is_valid = 1;
         it.step_is_successful = it_succ;
         it.pad_ = 0;
-        it.cost = it_cost;
-        it.cost_change = it_cost_change;
+        it.cost = park[0];
+        it.cost_change = park[1];
         it.gradient_max_norm = it_gmax;
-        it.step_norm = it_step_norm;
-        it.relative_decrease = it_rel;
+        it.step_norm = park[2];
+        it.relative_decrease = park[3];
         it.trust_region_radius = radius;
         trace[n_trace_in] = it;
       }
@@ -1580,15 +1597,9 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
       s.num_unsuccessful = n_unsucc;
       s.n_trace = n_trace_in + 1;
       s.n_evals = n_evals;
-#pragma unroll
-      for (int i = 0; i < NA; ++i) s.x[i] = x[i];
-      s.x_norm = x_norm;
-      s.x_cost = x_cost;
       s.initial_cost = initial_cost;
       s.minimum_cost = minimum_cost;
       s.min_iter_cost = min_iter_cost;
-      s.radius = radius;
-      s.decrease_factor = dfac;
       s.gmax = gmax;
       if (xout_dirty) {
 #pragma unroll
@@ -1600,14 +1611,7 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
         s.model_cost_change = mcc_n;
       }
     }
-    if (lane < NP) {  // (a rejected step stores back what it loaded)
-      s.diag[lane] = cont ? diag_n : diag;
-      s.g[lane] = g;
-      s.scale[lane] = scale;
-#pragma unroll
-      for (int b = 0; b < NP; ++b)
-        if (b >= lane) s.H[hidx[b]] = Hrow[b];
-    }
+    if (lane < NP) s.diag[lane] = cont ? diag_n : diag;
   };
   const bool slow_path = early == CLC_RUNNING && invalid_step;
   if (lane == 0) {
@@ -1630,7 +1634,7 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
       it.iteration = it_iteration + 1; it.step_is_valid = 0; it.step_is_successful = 0; it.pad_ = 0;
       it.cost = 0.0; it.cost_change = 0.0; it.gradient_max_norm = 0.0; it.step_norm = 0.0;
       it.relative_decrease = 0.0; it.trust_region_radius = 0.0;
-      LmScratch w;
+      LmScratch& w = *reinterpret_cast<LmScratch*>(park + 32);  // temporaries in LDS: this path must not cost registers
       lm_iterate(s, w, o, trace, trace_cap, it, true);
     }
   }
@@ -1759,7 +1763,8 @@ __device__ __forceinline__ bool lm_tail_after_barrier(const LmState* __restrict_
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      lm_advance_wave<FIRST>(st, opt, trace, trace_cap, &red[0][0], (int)threadIdx.x, stamp_row);  // contains the barrier
+      static_assert(sizeof(LmScratch) <= (LM_GROUPS - 2) * 32 * sizeof(double), "LmScratch fits rows 2.. of red");
+      lm_advance_wave<FIRST>(st, opt, trace, trace_cap, &red[0][0], &red[1][0], (int)threadIdx.x, stamp_row);  // contains the barrier
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
