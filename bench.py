@@ -359,7 +359,7 @@ def main():
                            "frac": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "64-byte records streamed as stored: achieved == actual HBM rate"}
         roof["note"] = (f"{streamed / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state passes are served on-die, and "
-                        "~8 us of every launch is fixed cost (launch boundary, the previous launch's 57 KB of partial rows, the LM controller); "
+                        "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 2.5, the LM controller 1.7, reductions 0.7: scripts/r02_stamps.py); "
                         "`frac` prices the launch at the contract's 64 algorithmic bytes per evaluation, `frac_streamed` at the bytes the "
                         "layout moves; see roofline_large for a working set beyond the cache")
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
