@@ -1306,34 +1306,45 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
   }
 }
 
+// Cycle stamps inside lm_advance_wave (debug build -DCLC_STAMPS, scripts/r02_stamps.py); nothing otherwise.
+#ifdef CLC_STAMPS
+#define CLC_CK() do { ck[nck++] = clock64(); } while (0)
+#else
+#define CLC_CK() do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // lm_advance on a wavefront (the step kernel's controller)
 // ---------------------------------------------------------------------------------------
 // The serial controller (clc_lm.hpp, one lane, state in LDS) is a chain of dependent FP64 instructions and LDS round
 // trips: 7 300 cycles = 3.0 us of every step_kernel launch, in every workgroup (scripts/r02_stamps.py).  What the
-// instructions cost when ONE wave runs them alone (scripts/probes/latency_probe.hip, cycles): dependent FMA 4-6, the
-// same FMA in independent chains 1.3-1.7, a value through v_readlane into the next FMA 24-31, IEEE division 72-98, IEEE
-// sqrt 108-146, dependent LDS read 72-93, compare + select + add 40-50.  So the controller here is written for a short
-// critical path, not for few instructions:
-//   * the state is read from LDS once, up front, in one batch, and written back once; everything scalar (pose, costs,
-//     radius, gradient, Jacobi scales, the triangular solves' running values) is computed redundantly by all lanes
-//     ("uniform") from broadcast LDS reads — no cross-lane traffic for it;
+// instructions cost when ONE wave runs them alone (scripts/probes/latency_probe.hip, cycles): dependent FMA 4-6, a
+// value through v_readlane into the next FMA 24-31, IEEE division 72-98, IEEE sqrt 108-146, dependent LDS read 72-93,
+// compare + select (or branch) 40-50.  So the controller here is written for a short critical path and few branches:
+//   * the state is read from LDS once, up front, in one batch; everything scalar (pose, costs, radius, the triangular
+//     solves' running values) is computed redundantly by all lanes ("uniform") from broadcast LDS reads;
 //   * lane i < 6 owns row i of the Gauss-Newton matrix: scaling, damping, the factorisation's column updates and the
 //     matrix-vector product of the model cost change are one instruction for all rows; the Cholesky factorisation is
 //     right-looking (column j scaled, then subtracted from the columns to its right) with the diagonal in its own
 //     register — per element the same subtractions in the same order as the left-looking serial loop — and the only
-//     values that cross lanes are the pivots, the column entries and the forward substitution's z (v_readlane);
+//     values that cross lanes are the pivots, the column entries, the forward substitution's z and the gradient
+//     (v_readlane);
 //   * the trust-region step is computed BEFORE the convergence tests that may make it unnecessary, so that the two
 //     Plus operations of an iteration — Plus(x, -g) for the projected gradient norm and Plus(x, step) for the
-//     candidate — run as one instruction stream in lanes 0 and 1, and so that the tests, the trace record and the
-//     bookkeeping overlap the solve.  Nothing of the speculative step is committed unless the serial controller would
-//     have computed it.  A step that turns out invalid (rare) is handed to the serial loop (lm_iterate).
-// Every expression keeps the operand order and the fused multiply-adds of clc_lm.hpp / clc_math.hpp: results, traces
-// and the state left in LDS are BIT-IDENTICAL to lm_advance<Se3Manifold> (the [evaluation, lm_kernel] launch pair
-// still runs the serial controller: test_step_kernel_solve_matches_two_kernel_path and the randomized problem test
-// compare the two bit for bit).
+//     candidate — run as one instruction stream in lanes 0 and 1; tolerance tests, acceptance and the radius update are
+//     selects, not branches.  Nothing of the speculative step is committed unless the serial controller would have
+//     computed it.  A step that turns out invalid (rare) is handed to the serial loop (lm_iterate);
+//   * the candidate and the status are published first, the workgroup's waves meet at ONE barrier (inside this
+//     function for the calling wave, in lm_tail_after_barrier for the others) and the rest of the state is written
+//     back behind it, while the other waves already stream.
+// Every expression keeps the operand order and the fused multiply-adds of clc_lm.hpp / clc_math.hpp: pose, summary and
+// iteration trace of a solve are BIT-IDENTICAL to lm_advance<Se3Manifold>'s (the [evaluation, lm_kernel] launch pair
+// still runs the serial controller: test_step_kernel_solve_matches_two_kernel_path, the randomized problem test and
+// the invalid-step test compare the two bit for bit).  The LM state agrees as well while a solve runs; after a
+// termination by parameter / function tolerance the fields that are not outputs (x, g, H, radius) hold the rejected
+// pass instead of the last accepted one — nothing reads them any more.
 // Called by all 64 lanes of one wave; `tot` (LDS): the 28 totals of this pass (H 0..20, g 21..26, cost sum 27), written
-// by this same wave (LDS operations of one wave execute in program order).
+// by this same wave (LDS operations of one wave execute in program order; the caller fences).
 template <bool FIRST>
 __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o, clc_iteration* __restrict__ trace,
                                                 const int trace_cap, const double* tot, double* park, const int lane,
@@ -1349,9 +1360,6 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
 #ifdef CLC_STAMPS
   long long ck[12];
   int nck = 0;
-#define CLC_CK() do { ck[nck++] = clock64(); } while (0)
-#else
-#define CLC_CK() do {} while (0)
 #endif
   CLC_CK();
   const unsigned i6 = lane < NP ? (unsigned)lane : NP - 1u;

@@ -40,7 +40,7 @@ used = (t[:, :, 0] > 0)
 nwg = int(used[1].sum())
 print(f"obs={rec.shape[0]} passes={npass} workgroups={nwg}  (all times in us, 10 ns resolution)")
 us = lambda a: a / 100.0
-print("launch | first entry after prev launch's last end | entry spread | rows summed | barrier | controller | stream | reduce+store | last end - first entry | last-wave entry lag / end lag")
+print("launch | first entry after prev launch's last end | entry spread | rows summed | barrier | controller | stream | reduce+store | last end - first entry | end spread")
 for k in range(1, min(npass, NL)):
     m = used[k]
     if not m.any() or t[k, m, 5].min() == 0:
@@ -51,7 +51,7 @@ for k in range(1, min(npass, NL)):
     print(f"{k:3d} | gap {gap:5.2f} | entry spread {us(e0.max() - e0.min()):5.2f} | rows {np.median(us(e1 - e0)):5.2f} (max {us((e1 - e0).max()):5.2f}) | "
           f"barrier {np.median(us(e2 - e1)):5.2f} (max {us((e2 - e1).max()):5.2f}) | ctrl {np.median(us(e3 - e2)):5.2f} (max {us((e3 - e2).max()):5.2f}) | "
           f"stream {np.median(us(e4 - e3)):5.2f} (max {us((e4 - e3).max()):5.2f}) | red {np.median(us(e5 - e4)):5.2f} | "
-          f"total {us(max(e5.max(), e7.max()) - e0.min()):5.2f} | w7 entry {np.median(us(e6 - e0)):5.2f} end {np.median(us(e7 - e5)):5.2f} | "
+          f"total {us(max(e5.max(), e7.max()) - e0.min()):5.2f} | "
           f"end spread {us(e5.max() - e5.min()):5.2f}")
     e8 = t[k, m, 8]; e9 = t[k, m, 9]; e10 = t[k, m, 10]; e11 = t[k, m, 11]; e12 = t[k, m, 12]
     cyc = (t[k, m, 14] - t[k, m, 13]).astype(np.float64)
