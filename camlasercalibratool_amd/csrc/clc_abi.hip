@@ -107,7 +107,7 @@ int default_lookahead() {
   return v;
 }
 constexpr size_t kInfinityCacheBytes = 256u << 20;  // MI355X memory-side cache (MI355X_MICROARCH.md)
-constexpr int kDefaultLaunchFlags = 2 | 16 | 32 | 128 | 256;  // prefetch + compact layout + 512-thread weighted workgroups + step kernel (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py, scripts/step_check.py)
+constexpr int kDefaultLaunchFlags = 2 | 16 | 32 | 128 | 256 | 512;  // prefetch + compact layout + 512-thread weighted workgroups + step kernel (clc::FLAG_*), tuned on MI355X (scripts/tune_eval.py, scripts/step_check.py)
 constexpr int kDefaultBlocksPerCU = 1;   // 4 waves per CU with 2 tiles in flight each     // single-problem solver: launch-ahead depth
 constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfers
 
@@ -137,6 +137,7 @@ struct clc_handle {
   size_t rdesc_cap_bytes = 0;
   long long n_rows = 0;
   bool rows_ok = false;
+  int split_grid = -1;  // grid the wave split table behind d_rdesc was built for (-1: none)
   // resident pose-major scans (clc_store_observations): device copies + the host-side CSR offsets
   double* d_sq = nullptr; size_t sq_cap = 0;     // tag_q (w,x,y,z) [P*4]
   double* d_st = nullptr; size_t st_cap = 0;     // tag_t [P*3]
@@ -266,6 +267,18 @@ bool rows_nontemporal(const clc_handle* h, long long n_rows) {
   return (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 || (h->launch_auto && bytes > kInfinityCacheBytes + kInfinityCacheBytes / 2);
 }
 
+// The wave split table of the row layout's equal-shares mode (clc_kernels.hpp wave_split_kernel): rebuilt, on the
+// handle's stream in front of the launches that read it, when the grid changed since the last upload.
+void ensure_wave_split(clc_handle* h, int grid) {
+  if (h->split_grid == grid) return;
+  const clc::RowDesc* desc = reinterpret_cast<const clc::RowDesc*>(h->d_rdesc);
+  int* table = reinterpret_cast<int*>(reinterpret_cast<char*>(h->d_rdesc) + ((size_t)h->n_rows + 1) * sizeof(clc::RowDesc));
+  const int total = grid * 8 + 1;
+  hipLaunchKernelGGL(clc::wave_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, desc, (int)h->n_rows,
+                     grid, table);
+  h->split_grid = grid;
+}
+
 template <bool WITH_LOSS, bool WITH_JAC>
 void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t* d_status, double lf,
                    const clc::Pose7& pose_arg, int use_pose_arg) {
@@ -279,12 +292,16 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
   const bool big = (fl & clc::FLAG_WG512) != 0;
   if (use_rows(h)) {  // row layout: the Jacobian comes with the moments, a cost-only pass would save nothing
     const bool rnt = rows_nontemporal(h, h->n_rows);
-    const bool eq = (fl & clc::FLAG_EQUAL_WAVES) != 0;
+    // Equal, scan-aligned shares (flag 512) pay where a wave's share is a few scans; the evaluation kernel ALONE on an
+    // array that streams from HBM (hundreds of rows per wave) is 3-7 % faster with the 3:2 old/young shares
+    // (scripts/r02_ab.py: 42.1 vs 45.1 us at 1.6e7 observations) — the step kernel is not (its wave 0 starts late).
+    const bool eq = (fl & clc::FLAG_EQUAL_WAVES) != 0 && !(h->launch_auto && h->n_rows > 256LL * 8 * grid);
 #define CLC_LAUNCH_R(NT, BT, WG)                                                                              \
   hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, NT, BT, WG>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy, \
                      reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl,       \
                      h->d_partials, pose_arg, use_pose_arg)
     if (big) {
+      if (eq) ensure_wave_split(h, grid);
       if (eq) { if (rnt) CLC_LAUNCH_R(true, 512, false); else CLC_LAUNCH_R(false, 512, false); }
       else { if (rnt) CLC_LAUNCH_R(true, 512, true); else CLC_LAUNCH_R(false, 512, true); }
     } else {
@@ -465,7 +482,7 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
     // one padding row each: the streaming loop's prologue loads run unconditionally from clamped row indices
     rc = ensure_bytes(T.d_rxy, T.rxy_cap, ((size_t)R + 1) * clc::ROW_DOUBLES * sizeof(double));
     if (rc != CLC_OK) return rc;
-    rc = ensure_bytes(T.d_rdesc, T.rdesc_cap, ((size_t)R + 1) * sizeof(clc::RowDesc));
+    rc = ensure_bytes(T.d_rdesc, T.rdesc_cap, ((size_t)R + 1) * sizeof(clc::RowDesc) + clc::wave_split_bytes(R));  // + the wave split table
     if (rc != CLC_OK) return rc;
     CLC_HIP(hipMemsetAsync(*T.d_rxy + (size_t)R * clc::ROW_DOUBLES, 0, clc::ROW_DOUBLES * sizeof(double), h->stream));
     CLC_HIP(hipMemsetAsync(reinterpret_cast<char*>(*T.d_rdesc) + (size_t)R * sizeof(clc::RowDesc), 0, sizeof(clc::RowDesc), h->stream));
@@ -699,6 +716,7 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
   CLC_HIP(hipSetDevice(h->device));
   h->compact_ok = false;
   h->rows_ok = false;
+  h->split_grid = -1;
   int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
   if (rc != CLC_OK) return rc;
   CLC_HIP(hipStreamSynchronize(h->stream));
@@ -960,6 +978,7 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
   const bool rows = use_rows(h);
   const bool rows_nt = rows && rows_nontemporal(h, h->n_rows);
   const bool rows_eq = (h->launch_flags & clc::FLAG_EQUAL_WAVES) != 0;
+  if (rows && rows_eq) ensure_wave_split(h, grid);
   double* rows_buf[2] = {h->d_partials, h->d_partials_b};
   int launched = 0, status = CLC_RUNNING, last_done = 0;
   long long spins = 0;
@@ -1830,6 +1849,26 @@ int clc_debug_rows(clc_handle* h, int* rows, long long* n_rows, int* brows, long
   if (n_rows) *n_rows = h->n_rows;
   if (brows) *brows = h->brows_ok ? 1 : 0;
   if (bn_rows) *bn_rows = h->bn_rows;
+  return CLC_OK;
+}
+
+// Test hook (not part of include/clc.h): the wave split table of the row layout for `grid` workgroups — grid * 8 + 1 row
+// indices — and, per row, whether it starts a scan (first[n_rows], may be NULL).
+int clc_debug_wave_split(clc_handle* h, int grid, int* split, int* first) {
+  if (!h || grid < 1 || !split) return fail(CLC_ERR_INVALID_ARG, "clc_debug_wave_split: bad arguments");
+  if (!h->rows_ok) return fail(CLC_ERR_NO_DATA, "clc_debug_wave_split: no row layout");
+  CLC_HIP(hipSetDevice(h->device));
+  h->split_grid = -1;
+  ensure_wave_split(h, grid);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  const char* base = reinterpret_cast<const char*>(h->d_rdesc);
+  CLC_HIP(hipMemcpy(split, base + ((size_t)h->n_rows + 1) * sizeof(clc::RowDesc), sizeof(int) * ((size_t)grid * 8 + 1), hipMemcpyDeviceToHost));
+  if (first) {
+    std::vector<clc::RowDesc> d((size_t)h->n_rows);
+    CLC_HIP(hipMemcpy(d.data(), base, sizeof(clc::RowDesc) * (size_t)h->n_rows, hipMemcpyDeviceToHost));
+    for (long long r = 0; r < h->n_rows; ++r) first[r] = d[(size_t)r].first;
+  }
   return CLC_OK;
 }
 

@@ -377,6 +377,47 @@ __device__ __forceinline__ WaveMap make_wave_map(int block, int n_blocks, int wa
   return m;
 }
 
+// ---------------------------------------------------------------------------------------
+// Scan-aligned wave shares of the row layout (equal-shares mode, flag 512 — the default)
+// ---------------------------------------------------------------------------------------
+// A wave whose run of rows begins or ends inside a scan pays one more per-scan expansion (~130 instructions) than a
+// wave that owns whole scans; with scans about as long as a wave's share — C2: 500-point scans = 8 rows, 7.6 rows per
+// wave — that was two expansions per wave instead of one, 0.7 us of a 9.9 us launch (scripts/probes/align_exp.py).
+// So the boundaries of the equal split are moved to the nearest scan start within half a share, once per (upload,
+// grid), into a table of n_blocks * 8 + 1 row indices that lives behind the descriptor array (its own padding row
+// included): `wave_split(desc, n_rows)`.  Half a share (rounded up) keeps the boundaries ordered; a boundary with no
+// scan start that close stays where the arithmetic split puts it.  Kernels of this mode read their run from the table
+// (wave_run), so the step kernel and the [evaluation, controller] launch pair still sum in the same order.
+__host__ __device__ inline size_t wave_split_bytes(long long n_rows) { return 16 * ((size_t)n_rows + 1) + 64; }
+__device__ __forceinline__ const int* wave_split(const RowDesc* __restrict__ desc, long long n_rows) {
+  return reinterpret_cast<const int*>(desc + n_rows + 1);
+}
+struct WaveRun { long long begin, end; };
+__device__ __forceinline__ WaveRun wave_run(const RowDesc* __restrict__ desc, long long n_rows, int block, int wave) {
+  const int* __restrict__ sp = wave_split(desc, n_rows) + (__builtin_amdgcn_readfirstlane(block) * 8 + __builtin_amdgcn_readfirstlane(wave));
+  WaveRun r;
+  r.begin = sp[0];
+  r.end = sp[1];
+  return r;
+}
+__global__ void wave_split_kernel(const RowDesc* __restrict__ desc, const int n_rows, const int n_blocks, int* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, total = n_blocks * 8 + 1;
+  if (t >= total) return;
+  if (t == total - 1) { out[t] = n_rows; return; }
+  const WaveMap m = make_wave_map<512, false>(t >> 3, n_blocks, t & 7);
+  const int nominal = (int)m.begin(n_rows);
+  const int window = ((n_rows / n_blocks) / 8 + 1) / 2;  // <= the smallest share: nearest-start maps of ordered points stay ordered
+  int best = nominal;
+  if (nominal > 0 && nominal < n_rows) {
+    for (int j = 0; j <= window; ++j) {
+      const int lo = nominal - j, hi = nominal + j;
+      if (lo >= 1 && desc[lo].first != 0) { best = lo; break; }
+      if (hi < n_rows && desc[hi].first != 0) { best = hi; break; }
+    }
+  }
+  out[t] = best;
+}
+
 template <bool NT>
 __device__ __forceinline__ void load_tile(const double* __restrict__ tiles, long long tile, int lane,
                                           double2 (&f)[8]) {
@@ -1128,8 +1169,17 @@ __global__ __launch_bounds__(BT) void eval_rows_kernel(const double* __restrict_
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   const int lane = threadIdx.x & 63;
-  const WaveMap wm = make_wave_map<BT, WEIGHTED>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
-  if (!stream_rows<WITH_LOSS, NT>(xy, desc, wm.begin(n_rows), wm.end(n_rows), lane, get_pose, inv_lf2, acc)) return;
+  long long r0, r1;
+  if (BT == 512 && !WEIGHTED) {  // equal shares, boundaries at scan starts (wave_split_kernel)
+    const WaveRun run = wave_run(desc, n_rows, blockIdx.x, threadIdx.x >> 6);
+    r0 = run.begin;
+    r1 = run.end;
+  } else {
+    const WaveMap wm = make_wave_map<BT, WEIGHTED>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
+    r0 = wm.begin(n_rows);
+    r1 = wm.end(n_rows);
+  }
+  if (!stream_rows<WITH_LOSS, NT>(xy, desc, r0, r1, lane, get_pose, inv_lf2, acc)) return;
   block_reduce_store<BT / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 
@@ -2081,9 +2131,16 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
   // has summed its rows does it issue its first rows of points — those have the whole controller to arrive.
   if (MODE != 0) lm_tail_sums<false, 512>(rows_in, grid, red, sh_state, L, nullptr, LM_STATE_WORDS + PRM_WORDS);
   bool active;
-  if (LAYOUT == 1)
-    active = stream_rows<WITH_LOSS, DEEP>(ctiles, reinterpret_cast<const RowDesc*>(groups), wm.begin(n), wm.end(n), lane,
-                                          get_pose, inv_lf2, acc);
+  if (LAYOUT == 1) {
+    const RowDesc* desc = reinterpret_cast<const RowDesc*>(groups);
+    long long r0 = wm.begin(n), r1 = wm.end(n);
+    if (!WEIGHTED) {  // equal shares, boundaries at scan starts (wave_split_kernel)
+      const WaveRun run = wave_run(desc, n, blockIdx.x, threadIdx.x >> 6);
+      r0 = run.begin;
+      r1 = run.end;
+    }
+    active = stream_rows<WITH_LOSS, DEEP>(ctiles, desc, r0, r1, lane, get_pose, inv_lf2, acc);
+  }
   else if (DEEP) active = stream_ctiles_deep<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else active = stream_ctiles<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   if (!active) return;  // the controller terminated the solve: nothing to evaluate

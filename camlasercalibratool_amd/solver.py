@@ -306,6 +306,15 @@ class Solver:
         check(self._L.clc_debug_rows(self._h, C.byref(r), C.byref(n), C.byref(br), C.byref(bn)), "clc_debug_rows")
         return bool(r.value), n.value, bool(br.value), bn.value
 
+    def debug_wave_split(self, grid: int):
+        """Wave split table of the row layout for `grid` workgroups -> (split[grid * 8 + 1], first[n_rows])."""
+        n_rows = self.debug_rows()[1]
+        split = np.zeros(grid * 8 + 1, dtype=np.int32)
+        first = np.zeros(max(n_rows, 1), dtype=np.int32)
+        self._L.clc_debug_wave_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        check(self._L.clc_debug_wave_split(self._h, C.c_int(grid), split.ctypes.data, first.ctypes.data), "clc_debug_wave_split")
+        return split, first[:n_rows]
+
     def time_steps(self, pose: np.ndarray, first: int, last: int) -> Tuple[float, int]:
         """Mean period [ms] of the step_kernel launches first..last of one default solve (HIP events on the handle's
         stream right before launch `first` and right after launch `last`) and the solve's number of passes."""

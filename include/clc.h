@@ -141,9 +141,10 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
  * runs the controller on the previous launch's partial rows before it streams; needs 32 and 16 or 256),
  * 256 = row layout (every scan padded to rows of 64 points, 16-byte (x, y) stream + one 64-byte
  * descriptor per row, per-scan moment accumulation; used when every record has p.z == 0, else the
- * flags without it apply), 512 = row layout with equal tile shares per wave, 1024 = batched row
+ * flags without it apply), 512 = row layout with equal row shares per wave whose boundaries are moved to
+ * the nearest scan start (instead of 3:2 old/young shares cut anywhere), 1024 = batched row
  * kernel in 256-thread workgroups (default: one wave per workgroup for batches of >= 8 problems per CU);
- * -1 = library default (2|16|32|128|256; non-temporal loads / the deep pipeline chosen per launch when
+ * -1 = library default (2|16|32|128|256|512; non-temporal loads / the deep pipeline chosen per launch when
  * the array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 

@@ -246,6 +246,40 @@ def test_row_layout_matches_oracle_and_the_per_point_paths(sv, oracle_mod):
     assert _dT(res.pose, ref.pose) <= T_TOL and res.summary.num_iterations == ref.summary.num_iterations
 
 
+@pytest.mark.parametrize("n_poses,pts", [(2000, 500), (300, 130), (97, 333), (50, 30)])
+def test_wave_split_table_moves_boundaries_to_scan_starts_only(sv, n_poses, pts):
+    """Equal-shares mode of the row layout (flag 512, the default): wave w streams rows [split[w], split[w+1]).  The
+    table must be a partition of [0, n_rows) in order, every boundary either where the arithmetic split puts it or on a
+    scan start at most half a share (rounded up) away; with 500-point scans (8 rows) and 2 048 waves — C2 — every wave
+    owns whole scans."""
+    S = sd.sim_fixed_count(3, n_poses, pts, noise_sigma=0.01)
+    rec = clc.flatten_observations(S, False)
+    sv.upload(rec)
+    ok, n_rows = sv.debug_rows()[:2]
+    assert ok
+    for grid in (1, 3, 64, 256, 1000):
+        g = min(grid, (rec.shape[0] + 127) // 128)  # never more workgroups than 128-record tiles (eval_grid)
+        split, first = sv.debug_wave_split(g)
+        assert split[0] == 0 and split[-1] == n_rows and np.all(np.diff(split) >= 0), g
+        q, r = divmod(n_rows, g)
+        window = (q // 8 + 1) // 2
+        b = np.repeat(np.arange(g), 8)
+        w = np.tile(np.arange(8), g)
+        wgn = q + (b < r)
+        nominal = b * q + np.minimum(b, r) + (wgn * w) // 8
+        s = split[:-1].astype(np.int64)
+        moved = s != nominal
+        assert np.all(np.abs(s[moved] - nominal[moved]) <= window) and np.all(first[s[moved]] == 1), g
+        # kept in place although not on a scan start: there is none within the window
+        for k in np.nonzero(~moved & (nominal > 0) & (nominal < n_rows))[0]:
+            if first[nominal[k]] != 1:
+                lo, hi = max(1, nominal[k] - window), min(n_rows - 1, nominal[k] + window)
+                assert not first[lo:hi + 1].any(), (g, k)
+        if (n_poses, pts, g) == (2000, 500, 256):
+            inner = split[1:-1]
+            assert np.all(first[inner[inner < n_rows]] == 1)  # whole scans only
+
+
 @pytest.mark.parametrize("grid", [1, 2, 3, 7])
 @pytest.mark.parametrize("n_poses,pts", [(40, 500), (97, 333), (260, 65)])
 def test_row_layout_long_runs_per_wave(sv, oracle_mod, grid, n_poses, pts):
