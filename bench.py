@@ -329,7 +329,7 @@ def main():
         layout = ("rows (16 B point + 64 B descriptor per row of 64 points, per-scan moments)" if rows_ok
                   else "compact (24 B point + 4 B group id per observation; group table per scan)")
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "kernel": ("clc::step_kernel<loss=1,nt=0,mode=2,layout=rows,weighted=1>" if rows_ok else "clc::step_kernel<loss=1,deep=0,mode=2,layout=compact>")
+                "kernel": ("clc::step_kernel<loss=1,nt=0,mode=2,layout=rows,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::step_kernel<loss=1,deep=0,mode=2,layout=compact>")
                           + " (controller prologue + streaming loop)",
                 "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs,
                 "achieved": BYTES_PER_EVAL * n_obs / (step_ms * 1e-3) / 1e9, "avg_kernel_ms": step_ms,
@@ -337,7 +337,7 @@ def main():
                           "clc_solve, / number of launches (best of 5)",
                 "timed_region_wall_ms_per_pass": wall_ms_per_pass,
                 "layout": layout, "streamed_bytes_per_launch": int(streamed),
-                "streaming_alone": {"kernel": "clc::eval_rows_kernel<loss=1,nt=0,512,weighted=1>" if rows_ok else "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
+                "streaming_alone": {"kernel": "clc::eval_rows_kernel<loss=1,nt=0,512,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
                                     "avg_kernel_ms": b2b, "achieved": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9,
                                     "frac": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "achieved_streamed": streamed / (b2b * 1e-3) / 1e9,

@@ -292,10 +292,11 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
   const bool big = (fl & clc::FLAG_WG512) != 0;
   if (use_rows(h)) {  // row layout: the Jacobian comes with the moments, a cost-only pass would save nothing
     const bool rnt = rows_nontemporal(h, h->n_rows);
-    // Equal, scan-aligned shares (flag 512) pay where a wave's share is a few scans; the evaluation kernel ALONE on an
-    // array that streams from HBM (hundreds of rows per wave) is 3-7 % faster with the 3:2 old/young shares
-    // (scripts/r02_ab.py: 42.1 vs 45.1 us at 1.6e7 observations) — the step kernel is not (its wave 0 starts late).
-    const bool eq = (fl & clc::FLAG_EQUAL_WAVES) != 0 && !(h->launch_auto && h->n_rows > 256LL * 8 * grid);
+    // Equal, scan-aligned shares (flag 512) pay where a wave's share is a scan or two; the evaluation kernel ALONE with
+    // tens of rows per wave and more is 3-7 % faster with the 3:2 old/young shares (scripts/r02_ab.py: 6.2 vs 6.8 us at
+    // 1e6 observations, but 15.4 vs 14.7 at 4e6 and 45.1 vs 42.1 at 1.6e7) — the step kernel is not (its wave 0 starts
+    // late anyway): it keeps the equal shares at every size.
+    const bool eq = (fl & clc::FLAG_EQUAL_WAVES) != 0 && !(h->launch_auto && h->n_rows > 16LL * 8 * grid);
 #define CLC_LAUNCH_R(NT, BT, WG)                                                                              \
   hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, NT, BT, WG>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy, \
                      reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl,       \
