@@ -150,7 +150,9 @@ md = ["# Evaluation kernel across sizes and layouts (MI355X, round 2)", "",
       "per-point compact layout (24 B point + 4 B group id), `tiled64` = the 64-byte records as handed over the C-ABI.  `rocprof` = mean duration of",
       "the dispatches (kernel trace), `hipEvent` = launch period measured inside the run (events around the block, launch gaps included),",
       "`streamed` = bytes the layout moves per launch, `alg` = the contract's 64 B per evaluation.  The 256 MiB Infinity Cache holds the row layout up to",
-      "1.5e7 observations; PMC bytes are fabric-side requests (Infinity-Cache hits included).", "",
+      "1.5e7 observations; PMC bytes are fabric-side requests (Infinity-Cache hits included).  The `rows` blocks run with the 3:2 old/young wave",
+      "shares (flags 2|16|32|128|256) — what the library picks for the evaluation kernel alone once a wave owns more than 16 rows; at 10^6 observations",
+      "and below the default is the equal split cut at scan starts (flag 512), 6.1-6.2 us instead of 6.7-7.2 (`scripts/r02_ab.py`).", "",
       "| observations | layout | streamed MB | rocprof us | hipEvent us | streamed GB/s | of 8 TB/s | alg GB/s (64 B) | PMC read MB | PMC write KB | PMC / streamed |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 for r in sweep[1:]:
     md.append(f"| {int(r[0]):,} | {r[1]} | {int(r[3]) / 1e6:.1f} | {r[4]} | {r[6]} | {r[8]} | {r[9]} | {r[7]} | {float(r[10]) / 1e6:.1f} | {float(r[11]) / 1e3:.0f} | {r[12]} |")
