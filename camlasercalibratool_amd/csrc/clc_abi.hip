@@ -512,6 +512,7 @@ struct BatchedLaunch {
   bool compact = false, deep = false, nt = false;
   bool rows = false, rows_nt = false, rows_wave = false;
   bool one_wave = false;  // rows_wave with exactly one wave per problem
+  bool whole_solve = false;  // batched_solve_kernel: one workgroup per problem, the whole solve in one launch
 };
 
 int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunch* bl) {
@@ -549,6 +550,17 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
             h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes + kInfinityCacheBytes / 2);
   bl->deep = (h->launch_flags & clc::FLAG_DEEP) != 0 || bbeyond;
   bl->rows_nt = bl->rows && rows_nontemporal(h, h->bn_rows);
+  // One workgroup per problem running the problem's WHOLE solve in one launch (batched_solve_kernel) beats the lockstep
+  // launches wherever a pass over the batch is not bandwidth-bound anyway — per evaluation pass, 10^4-observation
+  // problems: 17 vs 69 us at 24 problems, 28 vs 52 at 512, 49 vs 65 at 1 024 (C3), 96 vs 115 at 2 048, a tie at 4 096
+  // (0.7 GB), 390 vs 370 at 8 192 (1.4 GB); 10^5-observation problems: 91 vs 138 us at 24, a tie at 256
+  // (scripts/probes/c3_exp.py).  So: unless the rows exceed 1 GiB (a C4 shard: lockstep, one wave per problem) or a
+  // single problem is so long (> 4 096 rows, ~2.6e5 observations) that four waves are too few for it.
+  {
+    const size_t row_bytes = (size_t)h->bn_rows * (clc::ROW_DOUBLES * sizeof(double) + sizeof(clc::RowDesc));
+    const long long est_rows_pp = h->batch_total_tiles > 0 ? (long long)((double)h->batch_max_tiles * (double)h->bn_rows / (double)h->batch_total_tiles) : 0;
+    bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && est_rows_pp <= 4096;
+  }
   return CLC_OK;
 }
 
@@ -686,7 +698,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 2047)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 4095)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
@@ -1429,6 +1441,24 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   const int bpp = bl.bpp;
   // (the previous batch ended with a stream synchronisation: nothing still reads or writes the staging buffers)
   std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
+  if (bl.whole_solve) {
+    // one 256-thread workgroup per problem: the whole solve of every problem in ONE launch (batched_solve_kernel)
+    const clc::RowDesc* bdesc = reinterpret_cast<const clc::RowDesc*>(h->d_brdesc);
+#define CLC_LAUNCH_SOLVE(LOSS, NT)                                                                                      \
+  hipLaunchKernelGGL((clc::batched_solve_kernel<LOSS, NT>), dim3((unsigned)P), dim3(clc::BLOCK), 0, h->stream, h->d_brxy, \
+                     bdesc, h->d_prob_row, opt, h->d_poses, h->d_summaries, h->d_results)
+    if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_SOLVE(true, true); else CLC_LAUNCH_SOLVE(true, false); }
+    else { if (bl.rows_nt) CLC_LAUNCH_SOLVE(false, true); else CLC_LAUNCH_SOLVE(false, false); }
+#undef CLC_LAUNCH_SOLVE
+    CLC_HIP(hipGetLastError());
+    CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcomes written over PCIe visible
+    h->results_valid = P;
+    std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
+    std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t k = 0; k < P; ++k) summaries[k].solve_ms = ms;
+    return CLC_OK;
+  }
   const int lm_threads = bl.lm_threads;
   const unsigned lm_blocks = bl.lm_blocks;
   hipLaunchKernelGGL(clc::batched_init_kernel, dim3(lm_blocks), dim3(lm_threads), 0, h->stream, h->d_states,

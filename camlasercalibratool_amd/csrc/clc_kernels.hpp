@@ -324,7 +324,8 @@ constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 3:2 ol
 constexpr int FLAG_STEP = 128;          // clc_solve: one step_kernel launch per LM iteration (compact or row layout)
 constexpr int FLAG_ROWS = 256;          // row layout (clc_rows.hpp): 16 B/observation + 64 B/row, per-scan moments
 constexpr int FLAG_EQUAL_WAVES = 512;
-constexpr int FLAG_BATCHED_WG256 = 1024;  // batched row kernel: 256-thread workgroups + block reduction instead of one wave per workgroup   // row layout, 512-thread workgroups: equal shares per wave instead of the 3:2 old/young weighting
+constexpr int FLAG_BATCHED_WG256 = 1024;
+constexpr int FLAG_BATCHED_LOCKSTEP = 2048;  // one-workgroup-per-problem batches: lockstep launches instead of batched_solve_kernel  // batched row kernel: 256-thread workgroups + block reduction instead of one wave per workgroup   // row layout, 512-thread workgroups: equal shares per wave instead of the 3:2 old/young weighting
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -2520,6 +2521,70 @@ __global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict
         __hip_atomic_store(&mailbox->n_done, (int32_t)(launch_index + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (a == 0u) __hip_atomic_store(&mailbox->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+    }
+  }
+}
+
+// K4, one workgroup per problem (batches of about a thousand problems, C3): the WHOLE solve of a problem in one launch.
+// The problem's four waves stream its rows at the candidate, reduce through LDS (block_reduce_store: the same order as
+// the lockstep form's single partial row), wave 0 runs the wavefront controller on the state in LDS — the other waves
+// start on the next pass at its barrier — until the controller stops.  No kernel boundary between LM iterations, no
+// controller launches, no partial rows or LM states through memory, and no lockstep: a problem that needs three
+// iterations leaves after three.  Same arithmetic as the lockstep form (bit-identical results).  The loop is bounded by
+// the iteration cap whatever the controller does.
+template <bool WITH_LOSS, bool NT>
+__global__ __launch_bounds__(BLOCK, 2) void batched_solve_kernel(
+    const double* __restrict__ xy, const RowDesc* __restrict__ desc, const long long* __restrict__ prob_row,
+    const clc_options opt, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results) {
+  __shared__ double sh_state[LM_STATE_WORDS];
+  __shared__ double sh_tot[32];
+  __shared__ double sh_park[32 + (sizeof(LmScratch) + 7) / 8];
+  const int prob = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LmState& st = *reinterpret_cast<LmState*>(sh_state);
+  if (threadIdx.x == 0) lm_init(st, opt, poses + 7 * (size_t)prob);
+  __syncthreads();
+  const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
+  const long long r0 = prob_row[prob], n_rows = prob_row[prob + 1] - r0;
+  const WaveMap wm = make_wave_map<BLOCK>(0, 1, wave);
+  const long long rb = r0 + wm.begin(n_rows), re = r0 + wm.end(n_rows);
+  auto get_pose = [&](PoseU& P) -> bool {
+    double x[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = st.x_eval[i];
+    load_pose(x, P);
+    return true;
+  };
+  // one evaluation pass + the controller; FIRST: the pass at the start point
+  auto pass_first = [&]() {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    stream_rows<WITH_LOSS, NT>(xy, desc, rb, re, lane, get_pose, inv_lf2, acc);
+    block_reduce_store<BLOCK / 64>(acc, 0, sh_tot);
+    __syncthreads();
+    if (wave == 0) lm_advance_wave<true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);  // contains the barrier ...
+    else __syncthreads();                                                                // ... the other waves meet here
+  };
+  auto pass_next = [&]() {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    stream_rows<WITH_LOSS, NT>(xy, desc, rb, re, lane, get_pose, inv_lf2, acc);
+    block_reduce_store<BLOCK / 64>(acc, 0, sh_tot);
+    __syncthreads();
+    if (wave == 0) lm_advance_wave<false>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+    else __syncthreads();
+  };
+  pass_first();
+  const int cap = opt.max_num_iterations + 2;
+  for (int pass = 0; pass < cap && st.status == CLC_RUNNING; ++pass) pass_next();  // (status: published before the barrier)
+  if (wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+      if (st.status == CLC_RUNNING) st.status = CLC_FAILURE;  // unreachable: the controller stops at the iteration cap
+      batched_write_outcome(st, prob, poses, summaries, results);
     }
   }
 }

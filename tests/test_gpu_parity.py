@@ -556,10 +556,11 @@ def test_c3_batched_problems_match_oracle(sv, oracle_mod):
 
 
 def test_wide_ragged_batch_one_wave_per_problem(sv, oracle_mod):
-    """8 192 small problems (>= 32 per CU: the batched solver gives each problem ONE single-wave workgroup), ragged: 6
+    """8 192 small problems (>= 32 per CU: the lockstep solver gives each problem ONE single-wave workgroup), ragged: 6
     poses x 80 points cut to random lengths, some down to one observation, some empty.  The one-wave form must agree
     with the 256-thread-workgroup form (flag 1024) to rounding on every problem — same termination and iteration
-    count, pose and cost within the BASELINE gates — and with the oracle on a sample."""
+    count, pose and cost within the BASELINE gates — and with the oracle on a sample; the default (whole solve per
+    launch) must equal the 256-thread lockstep form bit for bit."""
     P, n_poses, K = 8192, 6, 80
     rec, off, x0, gt = sd.sim_shard_records(4242, 0, P, n_poses, K, 0.01)
     per = n_poses * K
@@ -573,11 +574,16 @@ def test_wide_ragged_batch_one_wave_per_problem(sv, oracle_mod):
     off2[1:] = np.cumsum(keep)
     sv.upload_batched(rec2, off2)
     assert sv.debug_rows()[2]  # batched row layout in use
-    sv.set_launch(0, -1)
+    sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 2048)  # lockstep launches: one single-wave workgroup per problem
     pa, sa = sv.solve_batched(x0)
-    sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 1024)
+    sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 2048 | 1024)  # lockstep launches, 256-thread workgroups
     pb, sb = sv.solve_batched(x0)
-    sv.set_launch(0, -1)
+    sv.set_launch(0, -1)  # default at this size: every problem's whole solve in one launch, one workgroup per problem
+    pc, sc = sv.solve_batched(x0)
+    # ... which sums like the 256-thread lockstep form: bit-identical to it
+    assert np.array_equal(pc, pb, equal_nan=True)
+    assert [(s.final_cost, s.num_iterations, s.termination, s.num_evaluations) for s in sc] == \
+           [(s.final_cost, s.num_iterations, s.termination, s.num_evaluations) for s in sb]
     n_diff = 0
     for k in range(P):
         if sa[k].termination != sb[k].termination or sa[k].num_iterations != sb[k].num_iterations:
@@ -610,6 +616,14 @@ def test_c3_full_size_batch(sv, oracle_mod):
     x0 = sv.pose_plus(np.stack([sd.pose7_from_T(g) for g in gts]), rng.normal(size=(P, 6)) * 0.05)
     sv.upload_batched(np.concatenate(recs), off)
     poses, sms = sv.solve_batched(x0)
+    # the default at this batch size is the whole solve of every problem in one launch (batched_solve_kernel); flag
+    # 2048 = the same workgroups in lockstep launches with the serial controller: bit-identical
+    sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 2048)
+    poses_l, sms_l = sv.solve_batched(x0)
+    sv.set_launch(0, -1)
+    assert np.array_equal(poses, poses_l)
+    assert [(s.final_cost, s.initial_cost, s.num_iterations, s.termination, s.num_evaluations, s.num_successful_steps) for s in sms] == \
+           [(s.final_cost, s.initial_cost, s.num_iterations, s.termination, s.num_evaluations, s.num_successful_steps) for s in sms_l]
     for k in range(P):
         assert sms[k].termination in (1, 2, 3), k
         assert sms[k].final_cost <= sms[k].initial_cost
