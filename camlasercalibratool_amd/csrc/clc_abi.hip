@@ -527,6 +527,9 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
   const long long max_tiles = h->batch_max_tiles;
   const int bpp_cap = (int)std::max<long long>(1, max_tiles / 4);
   bpp = std::max(1, std::min(bpp, bpp_cap));
+  // batched_lm_kernel sums a problem's partial rows in ONE thread: with hundreds of rows per problem (a handful of long
+  // problems) that sum took longer than the evaluation (393 us per pass at 4 problems x 9.6e4 observations, 256 rows each)
+  bpp = std::min(bpp, 16);
   // single-wave workgroups: as many waves as the 256-thread form would have — except for batches at least four times
   // wider than the chip's resident waves (C4 shard), where ONE wave per problem is faster still (224-235 vs 239-245 us
   // per launch, 1.52 vs 1.60 ms per batch): no partial rows to combine, scans never cut
@@ -553,13 +556,13 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
   // One workgroup per problem running the problem's WHOLE solve in one launch (batched_solve_kernel) beats the lockstep
   // launches wherever a pass over the batch is not bandwidth-bound anyway — per evaluation pass, 10^4-observation
   // problems: 17 vs 69 us at 24 problems, 28 vs 52 at 512, 49 vs 65 at 1 024 (C3), 96 vs 115 at 2 048, a tie at 4 096
-  // (0.7 GB), 390 vs 370 at 8 192 (1.4 GB); 10^5-observation problems: 91 vs 138 us at 24, a tie at 256
-  // (scripts/probes/c3_exp.py).  So: unless the rows exceed 1 GiB (a C4 shard: lockstep, one wave per problem) or a
-  // single problem is so long (> 4 096 rows, ~2.6e5 observations) that four waves are too few for it.
+  // (0.7 GB), 390 vs 370 at 8 192 (1.4 GB); 10^5-observation problems (1 500 rows each): 78 vs 54 us at 4 problems,
+  // 91 vs 70 at 24, a tie at 256 (scripts/probes/c3_exp.py).  So: unless the rows exceed 1 GiB (a C4 shard: lockstep, one
+  // wave per problem) or a single problem is so long (> 1 024 rows, ~6.5e4 observations) that four waves are too few.
   {
     const size_t row_bytes = (size_t)h->bn_rows * (clc::ROW_DOUBLES * sizeof(double) + sizeof(clc::RowDesc));
     const long long est_rows_pp = h->batch_total_tiles > 0 ? (long long)((double)h->batch_max_tiles * (double)h->bn_rows / (double)h->batch_total_tiles) : 0;
-    bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && est_rows_pp <= 4096;
+    bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && est_rows_pp <= 1024;
   }
   return CLC_OK;
 }

@@ -146,7 +146,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
  * kernel in 256-thread workgroups (default: one wave per workgroup for batches of >= 8 problems per CU),
  * 2048 = batched solver: lockstep [evaluation, controller] launches per LM iteration even where the default
  * is one workgroup per problem running the problem's whole solve in ONE launch (row layout of at most 1 GiB,
- * problems of at most ~2.6e5 observations);
+ * problems of at most ~6.5e4 observations);
  * -1 = library default (2|16|32|128|256|512; non-temporal loads / the deep pipeline chosen per launch when
  * the array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
