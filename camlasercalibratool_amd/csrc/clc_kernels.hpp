@@ -1443,7 +1443,7 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   __builtin_amdgcn_sched_barrier(0);
   const double cost_e = finalize_cost(cost_acc, o.use_loss != 0, o.loss_scale_factor);
   const bool finite_eval = fabs(cost_e) <= DMAX;
-  // ---- the pass just evaluated: early terminations (flags; nothing else of the state changes then), acceptance ----
+  // ---- the pass just evaluated: early terminations (flags; no output of the solve changes then), acceptance ----
   int early = CLC_RUNNING;  // termination before the iteration is recorded
   bool success = true;
   int reuse = reuse_in;
