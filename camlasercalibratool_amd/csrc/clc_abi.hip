@@ -20,6 +20,7 @@
 #include "../../include/clc.h"
 #include "clc_host.hpp"
 #include "clc_kernels.hpp"
+#include "clc_resident.hpp"
 
 namespace {
 
@@ -179,6 +180,17 @@ struct clc_handle {
   long long bn_rows = 0;
   bool brows_ok = false;
   long long* d_prob_row = nullptr;  // [P+1] first row of every problem
+  // resident ("lane") layout of the batched problems (clc_resident.hpp): j-major point rows, lane descriptors, row offsets
+  double* d_bres_xy = nullptr;
+  size_t bres_xy_cap = 0;
+  double* d_bres_desc = nullptr;   // clc::ResLane [P * lanes]
+  size_t bres_desc_cap = 0;
+  double* d_bres_row = nullptr;    // unsigned int [P + 1]
+  size_t bres_row_cap = 0;
+  int bres_lanes = 0;              // lanes per problem of the built layout (256 / 512)
+  int bres_max_ppl = 0;            // largest points-per-lane over the problems
+  long long bres_rows = 0;         // j-rows in all
+  bool bres_ok = false;
   long long* d_tile_off = nullptr;
   long long* d_nobs = nullptr;
   // batched poses / summaries live in pinned, device-mapped host memory: the init kernel reads the start poses and the
@@ -397,7 +409,76 @@ struct LayoutTargets {
   double** d_ct; size_t* ct_cap; double** d_gr; size_t* gr_cap; long long* n_groups; bool* compact_ok;
   double** d_rxy; size_t* rxy_cap; double** d_rdesc; size_t* rdesc_cap; long long* n_rows; bool* rows_ok;
   long long** d_prob_row;  // nullptr for the single-problem array
+  bool resident = false;   // batched uploads: also build the on-chip resident ("lane") layout (clc_resident.hpp)
 };
+
+// Resident layout limits: what the instantiations of resident_solve_kernel hold per lane (registers + LDS).
+constexpr int kResPR = 4, kResPL = 18, kResMaxPpl = kResPR + kResPL;  // 512-lane form (one workgroup per CU)
+
+// The lane layout of the batched problems (clc_resident.hpp) from the staged records and their scan structure: plan
+// (points per lane of every problem, on the device), offsets (O(P) on the host), lane descriptors + j-major point rows.
+// Leaves h->bres_ok false — and the other batched layouts in charge — when some problem does not fit a workgroup.
+int build_resident(clc_handle* h, const double* d_aos, long long n, size_t P, size_t G, const long long* d_rec_off,
+                   const unsigned int* d_gid, const long long* d_starts) {
+  h->bres_ok = false;
+  h->bres_lanes = 0;
+  h->bres_max_ppl = 0;
+  h->bres_rows = 0;
+  if ((h->launch_flags & clc::FLAG_NO_RESIDENT) != 0) return CLC_OK;
+  const int threads = 256;
+  DevBuf<unsigned int> bppl(&h->pool), bfail(&h->pool);
+  CLC_HIP(bppl.alloc(P));
+  CLC_HIP(bfail.alloc(1));
+  std::vector<unsigned int> ppl(P);
+  int lanes = 0;
+  const int first_try = 512;
+  for (int nl = first_try; nl <= 512 && lanes == 0; nl *= 2) {
+    unsigned int failed = 0;
+    CLC_HIP(hipMemsetAsync(bfail.p, 0, sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(clc::res_plan_kernel, dim3((unsigned)((P + threads - 1) / threads)), dim3(threads), 0, h->stream, d_rec_off,
+                       d_gid, d_starts, (long long)P, n, (long long)G, nl, kResMaxPpl, bppl.p, bfail.p);
+    CLC_HIP(hipGetLastError());
+    CLC_HIP(hipMemcpyAsync(&failed, bfail.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    CLC_HIP(hipMemcpyAsync(ppl.data(), bppl.p, sizeof(unsigned int) * P, hipMemcpyDeviceToHost, h->stream));
+    CLC_HIP(hipStreamSynchronize(h->stream));
+    if (!failed) lanes = nl;
+  }
+  if (lanes == 0) return CLC_OK;  // some problem is too long (or has too many scans) for one workgroup
+  std::vector<unsigned int> row(P + 1, 0u);
+  unsigned long long total = 0;
+  unsigned int max_ppl = 0;
+  for (size_t k = 0; k < P; ++k) {
+    row[k] = (unsigned int)total;
+    total += ppl[k];
+    max_ppl = std::max(max_ppl, ppl[k]);
+  }
+  if (total >= 0xFFFFFFF0ull) return CLC_OK;
+  row[P] = (unsigned int)total;
+  int rc = ensure_bytes(&h->d_bres_row, &h->bres_row_cap, (P + 1) * sizeof(unsigned int));
+  if (rc != CLC_OK) return rc;
+  rc = ensure_bytes(&h->d_bres_desc, &h->bres_desc_cap, P * (size_t)lanes * sizeof(clc::ResLane));
+  if (rc != CLC_OK) return rc;
+  // one padding row: the kernel's loads run unconditionally from clamped row indices (an empty last problem reads it)
+  rc = ensure_bytes(&h->d_bres_xy, &h->bres_xy_cap, ((size_t)total + 1) * (size_t)lanes * 2 * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  CLC_HIP(hipMemcpyAsync(h->d_bres_row, row.data(), (P + 1) * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemsetAsync(h->d_bres_xy + (size_t)total * (size_t)lanes * 2, 0, (size_t)lanes * 2 * sizeof(double), h->stream));
+  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->d_bres_row);
+  clc::ResLane* d_desc = reinterpret_cast<clc::ResLane*>(h->d_bres_desc);
+  if (lanes == 256)
+    hipLaunchKernelGGL((clc::res_build_kernel<256>), dim3((unsigned)P), dim3(256), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
+                       (long long)G, d_row, d_desc, h->d_bres_xy);
+  else
+    hipLaunchKernelGGL((clc::res_build_kernel<512>), dim3((unsigned)P), dim3(512), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
+                       (long long)G, d_row, d_desc, h->d_bres_xy);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));  // `row` is a host temporary
+  h->bres_lanes = lanes;
+  h->bres_max_ppl = (int)max_ppl;
+  h->bres_rows = (long long)total;
+  h->bres_ok = true;
+  return CLC_OK;
+}
 
 int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std::vector<long long>& rec_off,
                   const std::vector<long long>& tile_off, const LayoutTargets& T) {
@@ -495,6 +576,10 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
                          h->stream, broff.p, bgid.p, brbeg.p, (long long)P, n, R, *T.d_prob_row);
     CLC_HIP(hipGetLastError());
   }
+  if (T.resident && !any_z) {
+    rc = build_resident(h, d_aos, n, P, G, broff.p, bgid.p, bstarts.p);
+    if (rc != CLC_OK) return rc;
+  }
   CLC_HIP(hipStreamSynchronize(h->stream));  // the temporaries above are freed on return
   *T.n_groups = (long long)G;
   *T.compact_ok = true;
@@ -513,6 +598,8 @@ struct BatchedLaunch {
   bool rows = false, rows_nt = false, rows_wave = false;
   bool one_wave = false;  // rows_wave with exactly one wave per problem
   bool whole_solve = false;  // batched_solve_kernel: one workgroup per problem, the whole solve in one launch
+  bool resident = false;     // resident_solve_kernel: the same with the problem read from HBM once and kept on chip
+  bool res_nt = false;
 };
 
 int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunch* bl) {
@@ -563,6 +650,12 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
     const size_t row_bytes = (size_t)h->bn_rows * (clc::ROW_DOUBLES * sizeof(double) + sizeof(clc::RowDesc));
     const long long est_rows_pp = h->batch_total_tiles > 0 ? (long long)((double)h->batch_max_tiles * (double)h->bn_rows / (double)h->batch_total_tiles) : 0;
     bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && est_rows_pp <= 1024;
+  }
+  // Problems that fit a workgroup's registers + LDS are read from HBM once and solved on chip (clc_resident.hpp).
+  bl->resident = h->bres_ok && (h->launch_flags & (clc::FLAG_NO_RESIDENT | clc::FLAG_BATCHED_LOCKSTEP)) == 0;
+  {
+    const size_t res_bytes = (size_t)h->bres_rows * (size_t)h->bres_lanes * 2 * sizeof(double);
+    bl->res_nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 || (h->launch_auto && res_bytes > kInfinityCacheBytes + kInfinityCacheBytes / 2);
   }
   return CLC_OK;
 }
@@ -676,7 +769,7 @@ void clc_destroy(clc_handle* h) {
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_block, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
                   h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results,
-                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
+                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->d_bres_xy, h->d_bres_desc, h->d_bres_row, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->pool.clear();
@@ -701,7 +794,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags) {
-  if (!h || grid_blocks < 0 || flags < -1 || flags > 4095)
+  if (!h || grid_blocks < 0 || flags < -1 || flags > 16383)
     return fail(CLC_ERR_INVALID_ARG, "clc_set_launch: bad argument");
   h->grid_override = grid_blocks;
   h->launch_flags = flags < 0 ? kDefaultLaunchFlags : flags;
@@ -1399,11 +1492,12 @@ int upload_batched_impl(clc_handle* h, const clc_observation* records, bool on_d
   int crc = CLC_OK;
   h->bcompact_ok = false;
   h->brows_ok = false;
+  h->bres_ok = false;
   h->results_valid = 0;
   if (e == hipSuccess && d_aos) {
     const LayoutTargets T = {&h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups, &h->bgroups_cap_bytes, &h->bn_groups,
                              &h->bcompact_ok, &h->d_brxy, &h->brxy_cap_bytes, &h->d_brdesc, &h->brdesc_cap_bytes, &h->bn_rows,
-                             &h->brows_ok, &h->d_prob_row};
+                             &h->brows_ok, &h->d_prob_row, true};
     crc = build_layouts(h, d_aos, n_total, rel, tile_off, T);
   }
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
@@ -1444,6 +1538,30 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   const int bpp = bl.bpp;
   // (the previous batch ended with a stream synchronisation: nothing still reads or writes the staging buffers)
   std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
+  if (bl.resident) {
+    // one workgroup per problem, the problem read from HBM once and kept in registers + LDS for its whole solve
+    const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->d_bres_row);
+    const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->d_bres_desc);
+#define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
+  hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream,        \
+                     h->d_bres_xy, d_row, d_desc, h->d_bgroups, opt, h->d_poses, h->d_summaries, h->d_results)
+#define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
+  do {                                                                                                                        \
+    if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
+    else { if (bl.res_nt) CLC_LAUNCH_RES(false, true, NW, PR, PL); else CLC_LAUNCH_RES(false, false, NW, PR, PL); }            \
+  } while (0)
+    CLC_LAUNCH_RES_V(8, kResPR, kResPL);
+#undef CLC_LAUNCH_RES_V
+#undef CLC_LAUNCH_RES
+    CLC_HIP(hipGetLastError());
+    CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcomes written over PCIe visible
+    h->results_valid = P;
+    std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
+    std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t k = 0; k < P; ++k) summaries[k].solve_ms = ms;
+    return CLC_OK;
+  }
   if (bl.whole_solve) {
     // one 256-thread workgroup per problem: the whole solve of every problem in ONE launch (batched_solve_kernel)
     const clc::RowDesc* bdesc = reinterpret_cast<const clc::RowDesc*>(h->d_brdesc);
@@ -1908,6 +2026,16 @@ int clc_debug_wave_split(clc_handle* h, int grid, int* split, int* first) {
     CLC_HIP(hipMemcpy(d.data(), base, sizeof(clc::RowDesc) * (size_t)h->n_rows, hipMemcpyDeviceToHost));
     for (long long r = 0; r < h->n_rows; ++r) first[r] = d[(size_t)r].first;
   }
+  return CLC_OK;
+}
+
+// Resident-layout report of the batch: built[0/1], lanes per problem, largest points-per-lane, j-rows in all.
+int clc_debug_resident(clc_handle* h, int* ok, int* lanes, int* max_ppl, long long* rows) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_resident: NULL handle");
+  if (ok) *ok = h->bres_ok ? 1 : 0;
+  if (lanes) *lanes = h->bres_lanes;
+  if (max_ppl) *max_ppl = h->bres_max_ppl;
+  if (rows) *rows = h->bres_rows;
   return CLC_OK;
 }
 

@@ -323,9 +323,11 @@ constexpr int FLAG_DEEP = 64;            // compact layout: two tiles of points 
 constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 3:2 old/young wave tile weighting
 constexpr int FLAG_STEP = 128;          // clc_solve: one step_kernel launch per LM iteration (compact or row layout)
 constexpr int FLAG_ROWS = 256;          // row layout (clc_rows.hpp): 16 B/observation + 64 B/row, per-scan moments
-constexpr int FLAG_EQUAL_WAVES = 512;
-constexpr int FLAG_BATCHED_WG256 = 1024;
-constexpr int FLAG_BATCHED_LOCKSTEP = 2048;  // one-workgroup-per-problem batches: lockstep launches instead of batched_solve_kernel  // batched row kernel: 256-thread workgroups + block reduction instead of one wave per workgroup   // row layout, 512-thread workgroups: equal shares per wave instead of the 3:2 old/young weighting
+constexpr int FLAG_EQUAL_WAVES = 512;        // row layout, 512-thread workgroups: equal shares per wave, cut at scan starts, instead of the 3:2 old/young weighting
+constexpr int FLAG_BATCHED_WG256 = 1024;     // batched row kernel: 256-thread workgroups + block reduction instead of one wave per workgroup
+constexpr int FLAG_BATCHED_LOCKSTEP = 2048;  // one-workgroup-per-problem batches: lockstep launches instead of batched_solve_kernel
+constexpr int FLAG_NO_RESIDENT = 4096;       // batched solver: not the on-chip resident kernel (clc_resident.hpp) even where the problems fit
+constexpr int FLAG_RESIDENT_WG512 = 8192;    // resident layout over 512 lanes per problem (one workgroup per CU) even where 256 lanes hold it
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 

@@ -1,0 +1,289 @@
+// clc_resident.hpp — K4r: batched independent problems kept ON CHIP across their LM iterations.
+//
+// The reference solves every problem with one ceres::Solve (src/LaseCamCalCeres.cpp:301-307): the observations are
+// read once into the ceres::Problem and every LM iteration works on them in place.  The lockstep batched path
+// (clc_kernels.hpp K4) streams every still-running problem from HBM once per LM iteration instead — 5.6 passes over a
+// C4 shard's 1.43 GB.  Here ONE workgroup owns ONE problem for its whole solve and reads the problem's scan points from
+// HBM exactly once, into registers (PR points per lane) and LDS (PL points per lane); every evaluation pass of the
+// solve then runs on chip, and so do the reduction and the wavefront LM controller (lm_advance_wave) between passes.
+//
+// "Lane layout" (built at upload, res_build_kernel): a problem is dealt to the NL = 64 NW lanes of its workgroup so
+// that every lane holds points of ONE scan only — scan s with c_s points takes L_s = ceil(c_s / ppl) lanes with
+// floor/ceil(c_s / L_s) points each, ppl = the smallest points-per-lane for which the problem's scans fit NL lanes —
+// and is stored j-major: xyl[(row0 + j) * NL + lane] = j-th (x, y) of the lane, zero-padded to ppl.  So
+//   * a lane's plane (n, d, scale; m = R^T n, c0 = n.t + d per pass) lives in ITS registers: no wave-uniform scan
+//     bookkeeping, no scan-change branches, no descriptors in the point loop;
+//   * the per-scan moment expansion (rows_flush, ~130 instructions) runs ONCE per lane per pass instead of once per
+//     scan segment per wave (2.5-3.5 times per 20 rows in the row kernel);
+//   * the point loop has no masks at all: every lane processes exactly ppl points; the zero padding (x = y = 0)
+//     touches only S0, T0 and the cost product — by the same amount per padded point, w(c0), w(c0) c0 and
+//     1 + c0^2/lf^2 — which is taken out analytically once per pass.
+// Sums are taken in a different order than on the row layout, so results agree with the other batched paths to
+// rounding (reduction tolerance 1e-11), not bit for bit; iteration counts and terminations are the same
+// (tests/test_gpu_resident.py).
+//
+// Occupancy: two waves per SIMD.  <NW=4, PR=26, PL=18>: 256-thread workgroups, TWO problems resident per CU (73.7 KB
+// of LDS + 104 VGPRs of points each): while one problem's wave 0 runs the serial controller (~4 000 cycles on one
+// SIMD), the other problem's waves stream.  Capacity 256 lanes x 44 points.  <8, 26, 18>: one 512-thread workgroup per
+// CU for problems of up to 512 x 44 points.
+#pragma once
+#include "clc_kernels.hpp"
+
+namespace clc {
+
+struct ResLane {   // per lane of a problem's workgroup
+  int32_t gid;     // scan (group table index: {n.x, n.y, n.z, d, scale, 0})
+  int32_t cnt;     // valid points of the lane, <= ppl; 0: idle lane
+};
+
+// scans [g0, g1) of problem p (a problem never shares a scan with its neighbours: mark_problem_starts_kernel)
+__device__ __forceinline__ void res_problem_scans(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
+                                                  long long p, long long n, long long n_groups, long long& g0, long long& g1) {
+  const long long r0 = rec_off[p], r1 = rec_off[p + 1];
+  if (r1 <= r0) { g0 = g1 = 0; return; }
+  g0 = gid[r0];
+  g1 = r1 < n ? (long long)gid[r1] : n_groups;
+}
+
+// One thread per problem: ppl[p] = the smallest points-per-lane (<= max_ppl) with sum_s ceil(c_s / ppl) <= n_lanes;
+// 0 for an empty problem.  *fail is set when some problem does not fit.
+__global__ void res_plan_kernel(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
+                                const long long* __restrict__ starts, long long n_problems, long long n, long long n_groups,
+                                int n_lanes, int max_ppl, unsigned int* __restrict__ ppl_out, unsigned int* __restrict__ fail) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_problems) return;
+  long long g0, g1;
+  res_problem_scans(rec_off, gid, p, n, n_groups, g0, g1);
+  const long long n_p = rec_off[p + 1] - rec_off[p];
+  unsigned int ppl = 0;
+  if (n_p > 0) {
+    bool found = false;
+    if (g1 - g0 <= n_lanes) {
+      long long lo = (n_p + n_lanes - 1) / n_lanes;
+      if (lo < 1) lo = 1;
+      for (long long c = lo; c <= max_ppl && !found; ++c) {
+        long long lanes = 0;
+        for (long long g = g0; g < g1 && lanes <= n_lanes; ++g) lanes += (starts[g + 1] - starts[g] + c - 1) / c;
+        if (lanes <= n_lanes) { ppl = (unsigned int)c; found = true; }
+      }
+    }
+    if (!found) { atomicOr(fail, 1u); ppl = 0; }
+  }
+  ppl_out[p] = ppl;
+}
+
+// One workgroup of NL threads per problem: lane descriptors + the j-major point rows.
+template <int NL>
+__global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict__ aos, const long long* __restrict__ rec_off,
+                                                       const unsigned int* __restrict__ gid, const long long* __restrict__ starts,
+                                                       long long n, long long n_groups, const unsigned int* __restrict__ res_row,
+                                                       ResLane* __restrict__ desc, double* __restrict__ xyl) {
+  __shared__ int lane_first[NL + 1];
+  const long long p = blockIdx.x;
+  const int t = threadIdx.x;
+  const unsigned int row0 = res_row[p];
+  const int ppl = (int)(res_row[p + 1] - row0);
+  long long g0, g1;
+  res_problem_scans(rec_off, gid, p, n, n_groups, g0, g1);
+  const int ns = ppl > 0 ? (int)(g1 - g0) : 0;  // <= NL (res_plan_kernel)
+  int L = 0;
+  if (t < ns) L = (int)((starts[g0 + t + 1] - starts[g0 + t] + ppl - 1) / ppl);
+  lane_first[t + 1] = L;
+  if (t == 0) lane_first[0] = 0;
+  __syncthreads();
+  for (int off = 1; off < NL; off <<= 1) {  // inclusive scan of lane_first[1..NL]
+    const int a = t >= off ? lane_first[t + 1 - off] : 0;
+    __syncthreads();
+    lane_first[t + 1] += a;
+    __syncthreads();
+  }
+  const int total = lane_first[ns];
+  ResLane dl;
+  dl.gid = 0;
+  dl.cnt = 0;
+  long long k0 = 0;
+  if (t < total) {
+    int lo = 0, hi = ns;  // lane_first[lo] <= t < lane_first[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (lane_first[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int i = t - lane_first[lo], Ls = lane_first[lo + 1] - lane_first[lo];
+    const long long s0 = starts[g0 + lo], c = starts[g0 + lo + 1] - s0;
+    const long long q = c / Ls, r = c % Ls;
+    dl.gid = (int32_t)(g0 + lo);
+    dl.cnt = (int32_t)(q + (i < r ? 1 : 0));
+    k0 = s0 + (long long)i * q + (i < r ? i : r);
+  }
+  desc[(size_t)p * NL + t] = dl;
+  v2d* out = reinterpret_cast<v2d*>(xyl) + (size_t)row0 * NL + t;
+  for (int j = 0; j < ppl; ++j) {
+    v2d v;
+    v[0] = 0.0;
+    v[1] = 0.0;
+    if (j < dl.cnt) {
+      const v2d* rec = reinterpret_cast<const v2d*>(aos + 8 * (k0 + j));
+      v = rec[2];  // p.x, p.y
+    }
+    out[(size_t)j * NL] = v;
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ v2d res_load(const v2d* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
+template <bool WITH_LOSS, bool NT, int NW, int PR, int PL>
+__global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
+    const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
+    const double* __restrict__ groups, const clc_options opt, double* __restrict__ poses,
+    clc_summary* __restrict__ summaries, double* __restrict__ results) {
+  constexpr int NL = NW * 64;
+  constexpr int CH = 6;  // LDS points are consumed in chunks of CH (one chunk of reads in flight ahead of the arithmetic)
+  static_assert(PL % CH == 0, "PL is a whole number of chunks");
+  __shared__ v2d sh_pts[(PL > 0 ? PL : 1) * NL];
+  __shared__ double sh_state[LM_STATE_WORDS];
+  __shared__ double sh_tot[32];
+  __shared__ double sh_wsum[NW][NACC];
+  __shared__ double sh_park[32 + (sizeof(LmScratch) + 7) / 8];
+  const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  LmState& st = *reinterpret_cast<LmState*>(sh_state);
+  const unsigned int row0 = res_row[prob];
+  const int ppl = __builtin_amdgcn_readfirstlane((int)(res_row[prob + 1] - row0));
+  // ---- the problem's points: HBM -> registers / LDS, once.  Unconditional loads from clamped row indices (the array
+  // carries one padding row): a load inside `if (j < ppl)` sits in its own branch with its own wait at the join.
+  const v2d* __restrict__ src = reinterpret_cast<const v2d*>(xyl) + (size_t)row0 * NL + tid;
+  const int j_last = ppl > 0 ? ppl - 1 : 0;
+  v2d reg[PR];
+#pragma unroll
+  for (int j = 0; j < PR; ++j) reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+  const ResLane dl = lane_desc[(size_t)prob * NL + tid];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int j = PR + i;
+    sh_pts[i * NL + tid] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+  }
+  // the lane's plane (idle lanes: zeros, scale 0 — their moments are finite and expand to nothing)
+  double nx = 0.0, ny = 0.0, nz = 0.0, pd = 0.0, ps = 0.0;
+  {
+    const double* gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
+    const v2d a = *reinterpret_cast<const v2d*>(gp);
+    const v2d b = *reinterpret_cast<const v2d*>(gp + 2);
+    const double s = gp[4];
+    if (dl.cnt > 0) { nx = a[0]; ny = a[1]; nz = b[0]; pd = b[1]; ps = s; }
+  }
+  const int npad = ppl - dl.cnt;
+  const double np = (double)npad;
+  if (tid == 0) lm_init(st, opt, poses + 7 * (size_t)prob);
+  const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
+  __syncthreads();
+
+  // one evaluation pass at st.x_eval: the wave's 28 totals -> sh_wsum[wave]
+  auto pass = [&]() {
+    PoseU P;
+    {
+      double x[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) x[i] = st.x_eval[i];
+      load_pose(x, P);
+    }
+    RowPlane q;
+    rows_plane_setup(P.R, P.t, nx, ny, nz, pd, ps, q);
+    RowMoments M;
+    rows_moments_reset<WITH_LOSS>(M);
+    if (PL > 0) {
+      // chunk 0 of the LDS points is read before the register points are consumed
+      v2d buf[2][CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) buf[0][u] = sh_pts[u * NL + tid];
+#pragma unroll
+      for (int j = 0; j < PR; ++j)
+        if (j < ppl) rows_point<WITH_LOSS>(q, inv_lf2, reg[j][0], reg[j][1], M);
+#pragma unroll
+      for (int c = 0; c < PL / CH; ++c) {
+        if (c + 1 < PL / CH) {
+#pragma unroll
+          for (int u = 0; u < CH; ++u) buf[(c + 1) & 1][u] = sh_pts[((c + 1) * CH + u) * NL + tid];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (PR + c * CH + u < ppl) rows_point<WITH_LOSS>(q, inv_lf2, buf[c & 1][u][0], buf[c & 1][u][1], M);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PR; ++j)
+        if (j < ppl) rows_point<WITH_LOSS>(q, inv_lf2, reg[j][0], reg[j][1], M);
+    }
+    // the zero padding out again: npad points (0, 0) with r0 = c0 each
+    double lp = 0.0;
+    {
+      const double c0 = q.c0;
+      if (WITH_LOSS) {
+        const double sum_p = fma(c0 * c0, inv_lf2, 1.0);
+        const double w_p = fmax(2.2250738585072014e-308, rcp_ge1(sum_p));
+        const double cs = npad > 0 ? np * w_p : 0.0;
+        M.S0 -= cs;
+        M.T0 = fma(-cs, c0, M.T0);
+        int e;
+        const double m = frexp_pos(sum_p, e);
+        lp = npad > 0 ? np * log_mant_exp(m, e) : 0.0;
+      } else {
+        const double cs = npad > 0 ? np : 0.0;
+        M.S0 -= cs;
+        M.T0 = fma(-cs, c0, M.T0);
+        M.prod = fma(-cs * c0, c0, M.prod);
+      }
+    }
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    rows_flush<WITH_LOSS>(q, M, acc);
+    if (WITH_LOSS) acc[27] = fma(-q.s2, lp, acc[27]);
+    wave_reduce_butterfly(acc, sh_wsum[wave], lane);
+  };
+  // totals of the pass (fixed order) + the controller, on wave 0; the other waves leave from its barrier
+  auto totals = [&]() {
+    if (lane < NACC) {
+      double s = sh_wsum[0][lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) s += sh_wsum[w][lane];
+      sh_tot[lane] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  pass();
+  __syncthreads();
+  if (wave == 0) {
+    totals();
+    lm_advance_wave<true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);  // contains the barrier ...
+  } else {
+    __syncthreads();  // ... the other waves meet here
+  }
+  const int cap = opt.max_num_iterations + 2;
+  for (int k = 0; k < cap && st.status == CLC_RUNNING; ++k) {  // (status: published before the barrier)
+    pass();
+    __syncthreads();
+    if (wave == 0) {
+      totals();
+      lm_advance_wave<false>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+    } else {
+      __syncthreads();
+    }
+  }
+  if (wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+      if (st.status == CLC_RUNNING) st.status = CLC_FAILURE;  // unreachable: the controller stops at the iteration cap
+      batched_write_outcome(st, prob, poses, summaries, results);
+    }
+  }
+}
+
+}  // namespace clc

@@ -306,6 +306,13 @@ class Solver:
         check(self._L.clc_debug_rows(self._h, C.byref(r), C.byref(n), C.byref(br), C.byref(bn)), "clc_debug_rows")
         return bool(r.value), n.value, bool(br.value), bn.value
 
+    def debug_resident(self):
+        """Resident ("lane") layout report of the uploaded batch -> (built, lanes per problem, largest points per lane,
+        j-rows in all); built = the batched solver keeps every problem on chip for its whole solve (clc_resident.hpp)."""
+        ok, lanes, ppl, rows = C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
+        check(self._L.clc_debug_resident(self._h, C.byref(ok), C.byref(lanes), C.byref(ppl), C.byref(rows)), "clc_debug_resident")
+        return bool(ok.value), lanes.value, ppl.value, rows.value
+
     def debug_wave_split(self, grid: int):
         """Wave split table of the row layout for `grid` workgroups -> (split[grid * 8 + 1], first[n_rows])."""
         n_rows = self.debug_rows()[1]

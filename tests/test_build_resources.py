@@ -44,7 +44,8 @@ def _find(usage, *frags):
 def test_hot_kernels_do_not_spill(usage):
     hot = (_find(usage, "11eval_kernel") + _find(usage, "9lm_kernel") + _find(usage, "19batched_eval_kernel") +
            _find(usage, "17batched_lm_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "15line_fit_kernel") +
-           _find(usage, "14normal9_kernel") + _find(usage, "11step_kernel") + _find(usage, "20batched_solve_kernel"))
+           _find(usage, "14normal9_kernel") + _find(usage, "11step_kernel") + _find(usage, "20batched_solve_kernel") +
+           _find(usage, "21resident_solve_kernel"))
     for k in hot:
         assert usage[k]["ScratchSize"] == 0, (k, usage[k])
         assert usage[k]["VGPRs"] <= 256, (k, usage[k])
@@ -55,5 +56,5 @@ def test_default_evaluation_kernel_occupancy(usage):
     (k,) = _find(usage, "11eval_kernelILb1ELb1ELb1ELb0ELb1ELi512E")
     assert usage[k]["Occupancy"] >= 2 and usage[k]["VGPRs"] <= 256
     assert usage[k]["TotalSGPRs"] <= 102
-    for k in _find(usage, "19batched_eval_kernel") + _find(usage, "11step_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "20batched_solve_kernel"):
+    for k in _find(usage, "19batched_eval_kernel") + _find(usage, "11step_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "20batched_solve_kernel") + _find(usage, "21resident_solve_kernel"):
         assert usage[k]["Occupancy"] >= 2, (k, usage[k])  # the controller inside must not cost the streaming loop its occupancy

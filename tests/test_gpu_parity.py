@@ -578,8 +578,9 @@ def test_wide_ragged_batch_one_wave_per_problem(sv, oracle_mod):
     pa, sa = sv.solve_batched(x0)
     sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 2048 | 1024)  # lockstep launches, 256-thread workgroups
     pb, sb = sv.solve_batched(x0)
-    sv.set_launch(0, -1)  # default at this size: every problem's whole solve in one launch, one workgroup per problem
+    sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 4096)  # every problem's whole solve in one launch on the row layout
     pc, sc = sv.solve_batched(x0)
+    sv.set_launch(0, -1)  # (the default is the on-chip resident kernel: tests/test_gpu_resident.py)
     # ... which sums like the 256-thread lockstep form: bit-identical to it
     assert np.array_equal(pc, pb, equal_nan=True)
     assert [(s.final_cost, s.num_iterations, s.termination, s.num_evaluations) for s in sc] == \
@@ -615,15 +616,23 @@ def test_c3_full_size_batch(sv, oracle_mod):
     rng = np.random.default_rng(1)
     x0 = sv.pose_plus(np.stack([sd.pose7_from_T(g) for g in gts]), rng.normal(size=(P, 6)) * 0.05)
     sv.upload_batched(np.concatenate(recs), off)
-    poses, sms = sv.solve_batched(x0)
-    # the default at this batch size is the whole solve of every problem in one launch (batched_solve_kernel); flag
-    # 2048 = the same workgroups in lockstep launches with the serial controller: bit-identical
+    assert sv.debug_resident()[0]
+    poses, sms = sv.solve_batched(x0)  # default: every problem resident on chip for its whole solve (clc_resident.hpp)
+    # flag 4096 = the whole solve of every problem in one launch on the row layout (batched_solve_kernel); flag
+    # 2048 = the same workgroups in lockstep launches with the serial controller: bit-identical to each other
+    sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 4096)
+    poses_w, sms_w = sv.solve_batched(x0)
     sv.set_launch(0, 2 | 16 | 32 | 128 | 256 | 512 | 2048)
     poses_l, sms_l = sv.solve_batched(x0)
     sv.set_launch(0, -1)
-    assert np.array_equal(poses, poses_l)
-    assert [(s.final_cost, s.initial_cost, s.num_iterations, s.termination, s.num_evaluations, s.num_successful_steps) for s in sms] == \
+    assert np.array_equal(poses_w, poses_l)
+    assert [(s.final_cost, s.initial_cost, s.num_iterations, s.termination, s.num_evaluations, s.num_successful_steps) for s in sms_w] == \
            [(s.final_cost, s.initial_cost, s.num_iterations, s.termination, s.num_evaluations, s.num_successful_steps) for s in sms_l]
+    # the resident kernel sums in another order: same decisions, results to rounding
+    for k in range(P):
+        assert (sms[k].num_iterations, sms[k].termination, sms[k].num_evaluations) == \
+               (sms_l[k].num_iterations, sms_l[k].termination, sms_l[k].num_evaluations), k
+        assert np.abs(poses[k] - poses_l[k]).max() <= 1e-9 and abs(sms[k].final_cost - sms_l[k].final_cost) <= 1e-11, k
     for k in range(P):
         assert sms[k].termination in (1, 2, 3), k
         assert sms[k].final_cost <= sms[k].initial_cost
