@@ -413,7 +413,9 @@ struct LayoutTargets {
 };
 
 // Resident layout limits: what the instantiations of resident_solve_kernel hold per lane (registers + LDS).
-constexpr int kResPR = 4, kResPL = 18, kResMaxPpl = kResPR + kResPL;  // 512-lane form (one workgroup per CU)
+// 256-lane form: 256-thread workgroups, two problems per CU; 512-lane form: one 512-thread workgroup per CU (problems with more
+// than 256 scans, or flag 8192).  Both hold 512 x 22 = 256 x 44 - 512 points at most.
+constexpr int kResPR256 = 23, kResPL256 = 19, kResPR512 = 4, kResPL512 = 18;
 
 // The lane layout of the batched problems (clc_resident.hpp) from the staged records and their scan structure: plan
 // (points per lane of every problem, on the device), offsets (O(P) on the host), lane descriptors + j-major point rows.
@@ -431,12 +433,12 @@ int build_resident(clc_handle* h, const double* d_aos, long long n, size_t P, si
   CLC_HIP(bfail.alloc(1));
   std::vector<unsigned int> ppl(P);
   int lanes = 0;
-  const int first_try = 512;
+  const int first_try = (h->launch_flags & clc::FLAG_RESIDENT_WG512) != 0 ? 512 : 256;
   for (int nl = first_try; nl <= 512 && lanes == 0; nl *= 2) {
     unsigned int failed = 0;
     CLC_HIP(hipMemsetAsync(bfail.p, 0, sizeof(unsigned int), h->stream));
     hipLaunchKernelGGL(clc::res_plan_kernel, dim3((unsigned)((P + threads - 1) / threads)), dim3(threads), 0, h->stream, d_rec_off,
-                       d_gid, d_starts, (long long)P, n, (long long)G, nl, kResMaxPpl, bppl.p, bfail.p);
+                       d_gid, d_starts, (long long)P, n, (long long)G, nl, nl == 256 ? kResPR256 + kResPL256 : kResPR512 + kResPL512, bppl.p, bfail.p);
     CLC_HIP(hipGetLastError());
     CLC_HIP(hipMemcpyAsync(&failed, bfail.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     CLC_HIP(hipMemcpyAsync(ppl.data(), bppl.p, sizeof(unsigned int) * P, hipMemcpyDeviceToHost, h->stream));
@@ -1550,7 +1552,8 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
     else { if (bl.res_nt) CLC_LAUNCH_RES(false, true, NW, PR, PL); else CLC_LAUNCH_RES(false, false, NW, PR, PL); }            \
   } while (0)
-    CLC_LAUNCH_RES_V(8, kResPR, kResPL);
+    if (h->bres_lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
+    else CLC_LAUNCH_RES_V(8, kResPR512, kResPL512);
 #undef CLC_LAUNCH_RES_V
 #undef CLC_LAUNCH_RES
     CLC_HIP(hipGetLastError());

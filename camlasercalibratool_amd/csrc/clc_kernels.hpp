@@ -1398,7 +1398,14 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
 // pass instead of the last accepted one — nothing reads them any more.
 // Called by all 64 lanes of one wave; `tot` (LDS): the 28 totals of this pass (H 0..20, g 21..26, cost sum 27), written
 // by this same wave (LDS operations of one wave execute in program order; the caller fences).
-template <bool FIRST>
+// LEAN (the resident batched kernel, clc_resident.hpp): the same arithmetic with a small register footprint.  The calling
+// wave keeps ~100 VGPRs of scan points alive across the controller there, and this function, written for a short critical
+// path, holds ~180 VGPRs (x, x_eval, the column scales, the scaled matrix and the bookkeeping all stay in registers from
+// the first batch of LDS reads to the write-back).  LEAN stores what is final as soon as it is known — the state's home
+// is LDS anyway —, parks the scaled system in `park` and reads x, the scales, the gradient and the scaled system back
+// right before the model cost change and the two Plus that need them: three more LDS round trips (~300 cycles of a
+// controller that overlaps the co-resident problem's streaming there), ~60 VGPRs less.  No trace in this mode.
+template <bool FIRST, bool LEAN = false>
 __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o, clc_iteration* __restrict__ trace,
                                                 const int trace_cap, const double* tot, double* park, const int lane,
                                                 unsigned long long* stamp_row = nullptr /* debug builds */) {
@@ -1536,6 +1543,22 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
     for (int b = 0; b < NP; ++b)
       if (b >= lane) s.H[hidx[b]] = Hrow[b];
   }
+  if (LEAN) {
+    // the part of write_back() that is known by now (outputs of the solve: only if the pass did not terminate it)
+    if (lane == 0 && early == CLC_RUNNING) {
+      s.num_successful = n_succ;
+      s.num_unsuccessful = n_unsucc;
+      s.n_trace = n_trace_in + 1;
+      s.n_evals = n_evals;
+      s.initial_cost = initial_cost;
+      s.minimum_cost = minimum_cost;
+      s.min_iter_cost = min_iter_cost;
+      if (xout_dirty) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) s.x_out[i] = x[i];
+      }
+    }
+  }
   CLC_CK();
   // ---- lm_compute_step, ahead of the tests that may make it unnecessary (committed after them) ----
   double Hs[NP], A[NP];
@@ -1552,6 +1575,13 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   const double diag_n = reuse ? diag : dcl;
   const double inv_radius = rcp_pos(radius);
   double Ad = Hds + diag_n * inv_radius;  // lane i: the damped diagonal entry, updated in place by the factorisation
+  if (LEAN) {  // row i of the scaled system waits in LDS for the model cost change (park[8 + 8 i ...]: Hs[0..5], gs)
+    if (lane < NP) {
+#pragma unroll
+      for (int b = 0; b < NP; ++b) park[8 + 8 * lane + b] = Hs[b];
+      park[8 + 8 * lane + 6] = gs;
+    }
+  }
   CLC_CK();
   // Cholesky, right-looking: Lc[j] = column j of L (lane i: L[i][j], meaningful for i > j), inv[j] = 1 / L[j][j]
   // (a pivot <= 0 or NaN makes its reciprocal square root, and with it y[j], NaN: the finiteness test of y below is the
@@ -1591,11 +1621,23 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   double step_n[NP], sg = 0.0, shs = 0.0, row = 0.0;
 #pragma unroll
   for (int a = 0; a < NP; ++a) step_n[a] = -y[a];
+  double Hs2[NP], gs2 = gs;
 #pragma unroll
-  for (int b = 0; b < NP; ++b) row += Hs[b] * step_n[b];  // lane a: (Hs step)[a]
+  for (int b = 0; b < NP; ++b) Hs2[b] = Hs[b];
+  if (LEAN) {  // back from LDS (same wave: program order), not hoisted above the factorisation
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int b = 0; b < NP; ++b) Hs2[b] = park[8 + 8 * i6 + b];
+    gs2 = park[8 + 8 * i6 + 6];
+  }
+#pragma unroll
+  for (int b = 0; b < NP; ++b) row += Hs2[b] * step_n[b];  // lane a: (Hs step)[a]
 #pragma unroll
   for (int a = 0; a < NP; ++a) {
-    sg += step_n[a] * readlane_d(gs, a);
+    sg += step_n[a] * readlane_d(gs2, a);
     shs += step_n[a] * readlane_d(row, a);
   }
   const double mcc_n = -(sg + 0.5 * shs);
@@ -1604,17 +1646,30 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
   // ---- Plus: lane 0 the projected gradient (after a change of x / g), lane 1 the candidate ----
   double cand[NA];
   {
+    double g3 = g, sc3[NP], x3[NA];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) sc3[c] = sc[c];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) x3[i] = x[i];
+    if (LEAN) {  // x, g and the column scales as stored above (lane 0 / lanes < NP wrote them; every lane reads)
+      __builtin_amdgcn_sched_barrier(0);
+      g3 = s.g[i6];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) sc3[c] = s.scale[c];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) x3[i] = s.x[i];
+    }
     double dlt[NP];
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
-      const double ng = -readlane_d(g, c);
-      const double dc = step_n[c] * sc[c];  // undo column scaling
+      const double ng = -readlane_d(g3, c);
+      const double dc = step_n[c] * sc3[c];  // undo column scaling
       dlt[c] = lane == 1 ? dc : ng;
     }
-    pose_plus_rcp(x, dlt, cand);
+    pose_plus_rcp(x3, dlt, cand);
     double m = 0.0;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) m = fmax(m, fabs(x[i] - cand[i]));
+    for (int i = 0; i < NA; ++i) m = fmax(m, fabs(x3[i] - cand[i]));
     const double gnew = readlane_d(m, 0);
     gmax = success ? gnew : gmax;
   }
@@ -1654,17 +1709,19 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
       s.iteration = candidate_ready ? it_iteration + 1 : iteration;
       s.n_invalid = candidate_ready ? 0 : n_invalid_in;
       s.reuse_diagonal = cont ? 1 : reuse;
-      s.num_successful = n_succ;
-      s.num_unsuccessful = n_unsucc;
-      s.n_trace = n_trace_in + 1;
-      s.n_evals = n_evals;
-      s.initial_cost = initial_cost;
-      s.minimum_cost = minimum_cost;
-      s.min_iter_cost = min_iter_cost;
       s.gmax = gmax;
-      if (xout_dirty) {
+      if (!LEAN) {  // (LEAN: stored as soon as they were known)
+        s.num_successful = n_succ;
+        s.num_unsuccessful = n_unsucc;
+        s.n_trace = n_trace_in + 1;
+        s.n_evals = n_evals;
+        s.initial_cost = initial_cost;
+        s.minimum_cost = minimum_cost;
+        s.min_iter_cost = min_iter_cost;
+        if (xout_dirty) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) s.x_out[i] = x[i];
+          for (int i = 0; i < NA; ++i) s.x_out[i] = x[i];
+        }
       }
       if (step_dirty) {
 #pragma unroll

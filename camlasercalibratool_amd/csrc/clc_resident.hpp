@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     clc_summary* __restrict__ summaries, double* __restrict__ results) {
   constexpr int NL = NW * 64;
   constexpr int CH = 6;  // LDS points are consumed in chunks of CH (one chunk of reads in flight ahead of the arithmetic)
-  static_assert(PL % CH == 0, "PL is a whole number of chunks");
+  constexpr int NCH = (PL + CH - 1) / CH;
   __shared__ v2d sh_pts[(PL > 0 ? PL : 1) * NL];
   __shared__ double sh_state[LM_STATE_WORDS];
   __shared__ double sh_tot[32];
@@ -166,23 +166,27 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const int j = PR + i;
     sh_pts[i * NL + tid] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
   }
-  // the lane's plane (idle lanes: zeros, scale 0 — their moments are finite and expand to nothing)
-  double nx = 0.0, ny = 0.0, nz = 0.0, pd = 0.0, ps = 0.0;
-  {
-    const double* gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
-    const v2d a = *reinterpret_cast<const v2d*>(gp);
-    const v2d b = *reinterpret_cast<const v2d*>(gp + 2);
-    const double s = gp[4];
-    if (dl.cnt > 0) { nx = a[0]; ny = a[1]; nz = b[0]; pd = b[1]; ps = s; }
-  }
-  const int npad = ppl - dl.cnt;
-  const double np = (double)npad;
+  // The lane's plane is fetched again in every pass (48 bytes per lane out of L2: a problem's group entries are ~1 KB) rather
+  // than held in 10 VGPRs across the controller, which needs every register it can get.
+  const double* __restrict__ gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
+  const int cnt = dl.cnt;
   if (tid == 0) lm_init(st, opt, poses + 7 * (size_t)prob);
   const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
   __syncthreads();
 
   // one evaluation pass at st.x_eval: the wave's 28 totals -> sh_wsum[wave]
   auto pass = [&]() {
+    // plane of the lane's scan (idle lanes: zeros, scale 0 — their moments are finite and expand to nothing)
+    double nx, ny, nz, pd, ps;
+    {
+      const double* g2 = gp;
+      asm volatile("" : "+v"(g2));  // (an address the compiler cannot prove loop-invariant: the loads stay in the pass)
+      const v2d a = *reinterpret_cast<const v2d*>(g2);
+      const v2d b = *reinterpret_cast<const v2d*>(g2 + 2);
+      const double s5 = g2[4];
+      const bool on = cnt > 0;
+      nx = on ? a[0] : 0.0; ny = on ? a[1] : 0.0; nz = on ? b[0] : 0.0; pd = on ? b[1] : 0.0; ps = on ? s5 : 0.0;
+    }
     PoseU P;
     {
       double x[7];
@@ -192,25 +196,29 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     }
     RowPlane q;
     rows_plane_setup(P.R, P.t, nx, ny, nz, pd, ps, q);
+    const int npad = ppl - cnt;
+    const double np = (double)npad;
     RowMoments M;
     rows_moments_reset<WITH_LOSS>(M);
     if (PL > 0) {
       // chunk 0 of the LDS points is read before the register points are consumed
       v2d buf[2][CH];
 #pragma unroll
-      for (int u = 0; u < CH; ++u) buf[0][u] = sh_pts[u * NL + tid];
+      for (int u = 0; u < CH; ++u)
+        if (u < PL) buf[0][u] = sh_pts[u * NL + tid];
 #pragma unroll
       for (int j = 0; j < PR; ++j)
         if (j < ppl) rows_point<WITH_LOSS>(q, inv_lf2, reg[j][0], reg[j][1], M);
 #pragma unroll
-      for (int c = 0; c < PL / CH; ++c) {
-        if (c + 1 < PL / CH) {
+      for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
 #pragma unroll
-          for (int u = 0; u < CH; ++u) buf[(c + 1) & 1][u] = sh_pts[((c + 1) * CH + u) * NL + tid];
+          for (int u = 0; u < CH; ++u)
+            if ((c + 1) * CH + u < PL) buf[(c + 1) & 1][u] = sh_pts[((c + 1) * CH + u) * NL + tid];
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-          if (PR + c * CH + u < ppl) rows_point<WITH_LOSS>(q, inv_lf2, buf[c & 1][u][0], buf[c & 1][u][1], M);
+          if (c * CH + u < PL && PR + c * CH + u < ppl) rows_point<WITH_LOSS>(q, inv_lf2, buf[c & 1][u][0], buf[c & 1][u][1], M);
       }
     } else {
 #pragma unroll
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   __syncthreads();
   if (wave == 0) {
     totals();
-    lm_advance_wave<true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);  // contains the barrier ...
+    lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);  // contains the barrier ...
   } else {
     __syncthreads();  // ... the other waves meet here
   }
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     __syncthreads();
     if (wave == 0) {
       totals();
-      lm_advance_wave<false>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+      lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
     } else {
       __syncthreads();
     }

@@ -15,11 +15,15 @@ if len(sys.argv) > 1:
 for label, P in sizes:
     rec, off, xb, gt = sd.sim_shard_records(65536, 0, P, 20, 500, 0.01)
     t = time.perf_counter(); sv.upload_batched(rec, off); up = time.perf_counter() - t
-    del rec
-    ok, lanes, ppl, rows = sv.debug_resident()
-    r = {"upload_s": up, "resident": ok, "lanes": lanes, "max_ppl": ppl, "rows": rows, "resident_bytes": rows * lanes * 16}
+    r = {"upload_s": up}
     res = {}
-    for name, fl in (("resident", -1), ("round2_default", BASE | 4096), ("resident", -1), ("round2_default", BASE | 4096)):
+    for name, fl, up_fl in (("resident256", -1, -1), ("round2_default", BASE | 4096, None), ("resident512", -1, BASE | 8192),
+                            ("resident256", -1, -1), ("round2_default", BASE | 4096, None), ("resident512", -1, BASE | 8192)):
+        if up_fl is not None:  # the lane layout is chosen at upload
+            sv.set_launch(0, up_fl)
+            sv.upload_batched(rec, off)
+            ok, lanes, ppl, rows = sv.debug_resident()
+            r[name] = {"resident": ok, "lanes": lanes, "max_ppl": ppl, "rows": rows, "resident_bytes": rows * lanes * 16}
         sv.set_launch(0, fl)
         ts = []
         for _ in range(12):
@@ -29,7 +33,7 @@ for label, P in sizes:
         res[name] = (poses, [(s.termination, s.num_iterations, s.num_evaluations, s.final_cost) for s in sms])
         print(f"{label} {name}: solve_batched {ms:.4f} ms (min {min(ts)*1e3:.4f})", flush=True)
     sv.set_launch(0, -1)
-    pa, sa = res["resident"]; pb, sb = res["round2_default"]
+    pa, sa = res["resident256"]; pb, sb = res["round2_default"]
     r["same_decisions"] = int(sum(a[:3] == b[:3] for a, b in zip(sa, sb)))
     r["max_pose_diff"] = float(np.abs(pa - pb).max())
     r["max_cost_diff"] = float(max(abs(a[3] - b[3]) for a, b in zip(sa, sb)))

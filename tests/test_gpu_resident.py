@@ -36,8 +36,11 @@ def _key(s):
 
 
 def _batch(seed, P, n_poses, K, noise=0.01):
-    rec, off, x0, gt = sd.sim_shard_records(seed, 0, P, n_poses, K, noise)
-    return rec, off, x0, gt
+    if n_poses <= 32:
+        return sd.sim_shard_records(seed, 0, P, n_poses, K, noise)
+    sh = sd.sim_shard(seed, 0, P, n_poses, K, noise, candidates=4 * n_poses)  # (more board poses than the default draws)
+    rec, off = sh.records()
+    return rec, off, sh.start_poses(), sh.gt_Tcl
 
 
 def _cut(rec, off, keep):
