@@ -189,6 +189,7 @@ struct clc_handle {
   size_t bres_row_cap = 0;
   int bres_lanes = 0;              // lanes per problem of the built layout (256 / 512)
   int bres_max_ppl = 0;            // largest points-per-lane over the problems
+  int bres_uni_ppl = -1;           // >= 0: every problem has this many points per lane
   long long bres_rows = 0;         // j-rows in all
   bool bres_ok = false;
   long long* d_tile_off = nullptr;
@@ -449,10 +450,12 @@ int build_resident(clc_handle* h, const double* d_aos, long long n, size_t P, si
   std::vector<unsigned int> row(P + 1, 0u);
   unsigned long long total = 0;
   unsigned int max_ppl = 0;
+  bool uniform = true;
   for (size_t k = 0; k < P; ++k) {
     row[k] = (unsigned int)total;
     total += ppl[k];
     max_ppl = std::max(max_ppl, ppl[k]);
+    uniform = uniform && ppl[k] == ppl[0];
   }
   if (total >= 0xFFFFFFF0ull) return CLC_OK;
   row[P] = (unsigned int)total;
@@ -477,6 +480,7 @@ int build_resident(clc_handle* h, const double* d_aos, long long n, size_t P, si
   CLC_HIP(hipStreamSynchronize(h->stream));  // `row` is a host temporary
   h->bres_lanes = lanes;
   h->bres_max_ppl = (int)max_ppl;
+  h->bres_uni_ppl = uniform && P > 0 ? (int)ppl[0] : -1;
   h->bres_rows = (long long)total;
   h->bres_ok = true;
   return CLC_OK;
@@ -1546,7 +1550,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->d_bres_desc);
 #define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream,        \
-                     h->d_bres_xy, d_row, d_desc, h->d_bgroups, opt, h->d_poses, h->d_summaries, h->d_results)
+                     h->d_bres_xy, d_row, d_desc, h->d_bgroups, h->bres_uni_ppl, opt, h->d_poses, h->d_summaries, h->d_results)
 #define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
   do {                                                                                                                        \
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
@@ -2126,6 +2130,14 @@ int clc_time_eval(clc_handle* h, const double pose[7], int with_loss, double lf,
 
 #ifdef CLC_STAMPS
 // Debug build only: copy the step-kernel stamp buffer out and clear it.
+extern "C" int clc_debug_res_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(clc::clc_res_stamp_buf)) bytes = sizeof(clc::clc_res_stamp_buf);
+  if (hipDeviceSynchronize() != hipSuccess) return CLC_ERR_HIP;
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(clc::clc_res_stamp_buf), bytes) != hipSuccess) return CLC_ERR_HIP;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(clc::clc_res_stamp_buf)) != hipSuccess) return CLC_ERR_HIP;
+  return hipMemset(p, 0, sizeof(clc::clc_res_stamp_buf)) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
+}
 extern "C" int clc_debug_stamps(void* dst, size_t bytes) {
   if (bytes > sizeof(clc::clc_stamp_buf)) bytes = sizeof(clc::clc_stamp_buf);
   if (hipDeviceSynchronize() != hipSuccess) return CLC_ERR_HIP;

@@ -129,20 +129,84 @@ __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict_
   }
 }
 
+#ifdef CLC_STAMPS
+// Debug build only (scripts/r03_res_stamps.py): stamps of the first RES_STAMP_WGS problems' waves 0 and 1 —
+// slot 0: wall clock (100 MHz) at kernel entry, 1: wall clock at exit, 2: shader clock at entry, 3: after the loads landed;
+// then per pass p < RES_STAMP_PASSES at 4 + 6 p: shader clock at pass start, after the point loop, after the wave
+// reduction, after barrier 1, (wave 0) after the totals, after the controller / barrier 2.
+constexpr int RES_STAMP_WGS = 1024, RES_STAMP_PASSES = 8, RES_STAMP_SLOTS = 4 + 6 * RES_STAMP_PASSES;
+__device__ long long clc_res_stamp_buf[RES_STAMP_WGS][2][RES_STAMP_SLOTS];
+#ifndef CLC_RES_STAMP_BASE
+#define CLC_RES_STAMP_BASE 0
+#endif
+#define RES_STAMP(slot, val)                                                                              \
+  do {                                                                                                    \
+    if (lane == 0 && (wave == cw || wave == ((cw + 1) & 3)) && blockIdx.x >= CLC_RES_STAMP_BASE &&        \
+        blockIdx.x < CLC_RES_STAMP_BASE + RES_STAMP_WGS && (slot) < RES_STAMP_SLOTS)                      \
+      clc_res_stamp_buf[blockIdx.x - CLC_RES_STAMP_BASE][wave == cw ? 0 : 1][slot] = (val);               \
+  } while (0)
+#else
+#define RES_STAMP(slot, val) do {} while (0)
+#endif
+
 template <bool NT>
 __device__ __forceinline__ v2d res_load(const v2d* p) {
   if (NT) return __builtin_nontemporal_load(p);
   return *p;
 }
 
+// Point arithmetic of the resident kernel: rows_point (clc_rows.hpp) with what only costs issue slots taken out —
+//   * the Cauchy weight 1 / (1 + r0^2/lf^2) from the v_rcp_f64 seed and ONE Newton step (CLC_RES_NEWTON; the seed is good
+//     to ~2^-27, scripts/probes/rcp_probe.hip, so one step leaves < 1 ulp + 2^-54; the row kernels take two);
+//   * the running product of (1 + r0^2/lf^2) is renormalised (mantissa, exponent) every second point instead of every
+//     point: a mantissa in [0.5, 1) times two factors below 2^511 each cannot overflow, so this is exact up to
+//     |r0| ~ 1e76 lf — beyond that the cost is +inf and the solve fails like a non-finite evaluation;
+//   * no max(DBL_MIN, .) on the weight (Ceres' rho' clamp, which only acts when 1 + r0^2/lf^2 > 4.5e307).
+#ifndef CLC_RES_NEWTON
+#define CLC_RES_NEWTON 1
+#endif
+template <bool WITH_LOSS, bool RENORM>
+__device__ __forceinline__ void res_point(const RowPlane& q, const double inv_lf2, const double x, const double y, RowMoments& M) {
+  const double r0 = fma(q.my, y, fma(q.mx, x, q.c0));
+  double w = 1.0;
+  if (WITH_LOSS) {
+    const double sum = fma(r0 * r0, inv_lf2, 1.0);
+    double r = __builtin_amdgcn_rcp(sum);
+#pragma unroll
+    for (int it = 0; it < CLC_RES_NEWTON; ++it) r = fma(r, fma(-sum, r, 1.0), r);
+    w = r;
+    const double pr = M.prod * sum;
+    if (RENORM) {
+      M.expo += __builtin_amdgcn_frexp_exp(pr);
+      M.prod = __builtin_amdgcn_frexp_mant(pr);
+    } else {
+      M.prod = pr;
+    }
+  } else {
+    M.prod = fma(r0, r0, M.prod);
+  }
+  const double wx = w * x, wy = w * y, wr = w * r0;
+  M.S0 += w;
+  M.Sx += wx;
+  M.Sy += wy;
+  M.Sxx = fma(wx, x, M.Sxx);
+  M.Sxy = fma(wx, y, M.Sxy);
+  M.Syy = fma(wy, y, M.Syy);
+  M.T0 += wr;
+  M.Tx = fma(wr, x, M.Tx);
+  M.Ty = fma(wr, y, M.Ty);
+}
+
 // The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
+// uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read).
 template <bool WITH_LOSS, bool NT, int NW, int PR, int PL>
 __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
-    const double* __restrict__ groups, const clc_options opt, double* __restrict__ poses,
+    const double* __restrict__ groups, const int uni_ppl, const clc_options opt, double* __restrict__ poses,
     clc_summary* __restrict__ summaries, double* __restrict__ results) {
   constexpr int NL = NW * 64;
-  constexpr int CH = 6;  // LDS points are consumed in chunks of CH (one chunk of reads in flight ahead of the arithmetic)
+  constexpr int NP = PR + PL;  // points a lane can hold
+  constexpr int CH = 6;        // LDS points are read in chunks of CH, one chunk ahead of the arithmetic
   constexpr int NCH = (PL + CH - 1) / CH;
   __shared__ v2d sh_pts[(PL > 0 ? PL : 1) * NL];
   __shared__ double sh_state[LM_STATE_WORDS];
@@ -150,11 +214,31 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   __shared__ double sh_wsum[NW][NACC];
   __shared__ double sh_park[32 + (sizeof(LmScratch) + 7) / 8];
   const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Controller wave: the two workgroups that share a CU (256-thread form) pick waves on DIFFERENT SIMDs — wave 0 for the
+  // workgroup whose LDS allocation starts at 0, wave 2 for the other — so that two controllers running at the same time
+  // (co-resident problems in phase) do not share one SIMD's issue slots while the other three idle.
+  int cw = 0;
+  if (NW == 4) {
+    const unsigned lds_alloc = __builtin_amdgcn_s_getreg((6 /*HW_REG_LDS_ALLOC*/) | (0 << 6) | ((12 - 1) << 11));  // LDS_BASE field (bits below LDS_SIZE at 12)
+    cw = lds_alloc != 0 ? 2 : 0;
+  }
+  RES_STAMP(0, wall_clock64());
+  RES_STAMP(2, clock64());
   LmState& st = *reinterpret_cast<LmState*>(sh_state);
-  const unsigned int row0 = res_row[prob];
-  const int ppl = __builtin_amdgcn_readfirstlane((int)(res_row[prob + 1] - row0));
+  // start pose: host memory behind PCIe (~2 us) — requested first, consumed after the points have landed
+  const double pose_w = poses[7 * (size_t)prob + (tid < 7 ? tid : 0)];
+  unsigned int row0;
+  int ppl;
+  if (uni_ppl >= 0) {
+    row0 = (unsigned int)prob * (unsigned int)uni_ppl;
+    ppl = uni_ppl;
+  } else {
+    row0 = res_row[prob];
+    ppl = __builtin_amdgcn_readfirstlane((int)(res_row[prob + 1] - row0));
+  }
   // ---- the problem's points: HBM -> registers / LDS, once.  Unconditional loads from clamped row indices (the array
-  // carries one padding row): a load inside `if (j < ppl)` sits in its own branch with its own wait at the join.
+  // carries one padding row): a load inside `if (j < ppl)` sits in its own branch with its own wait at the join.  Slots
+  // beyond ppl become zeros (the pass may run one slot past ppl).
   const v2d* __restrict__ src = reinterpret_cast<const v2d*>(xyl) + (size_t)row0 * NL + tid;
   const int j_last = ppl > 0 ? ppl - 1 : 0;
   v2d reg[PR];
@@ -164,18 +248,35 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     const int j = PR + i;
-    sh_pts[i * NL + tid] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+    v2d v = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+    if (j >= ppl) { v[0] = 0.0; v[1] = 0.0; }
+    sh_pts[i * NL + tid] = v;
   }
-  // The lane's plane is fetched again in every pass (48 bytes per lane out of L2: a problem's group entries are ~1 KB) rather
-  // than held in 10 VGPRs across the controller, which needs every register it can get.
+#pragma unroll
+  for (int j = 0; j < PR; ++j)
+    if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; }
+  // The lane's plane is fetched again in every pass (48 bytes per lane out of L1/L2: a problem's group entries are ~1 KB)
+  // rather than held in 10 VGPRs across the controller, which needs every register it can get.
   const double* __restrict__ gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
   const int cnt = dl.cnt;
-  if (tid == 0) lm_init(st, opt, poses + 7 * (size_t)prob);
+  if (tid < 7) sh_park[tid] = pose_w;
+  if (wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid == 0) lm_init(st, opt, sh_park);
+  }
   const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
+  // points processed per lane and pass: ppl rounded up to whole pairs (two points per basic block: two independent
+  // dependency chains for a wave that has its SIMD to itself while the co-resident problem is in its controller)
+  const int ppl_eff = (ppl & 1) != 0 && ppl < NP ? ppl + 1 : ppl;
   __syncthreads();
+  RES_STAMP(3, clock64());
+  int pass_no = 0;  // (debug stamps)
 
   // one evaluation pass at st.x_eval: the wave's 28 totals -> sh_wsum[wave]
   auto pass = [&]() {
+    RES_STAMP(4 + 6 * pass_no, clock64());
     // plane of the lane's scan (idle lanes: zeros, scale 0 — their moments are finite and expand to nothing)
     double nx, ny, nz, pd, ps;
     {
@@ -187,6 +288,12 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
       const bool on = cnt > 0;
       nx = on ? a[0] : 0.0; ny = on ? a[1] : 0.0; nz = on ? b[0] : 0.0; pd = on ? b[1] : 0.0; ps = on ? s5 : 0.0;
     }
+    v2d buf[2][CH];  // LDS points, chunk c in buf[c & 1]; chunk 0 is read before the register points are consumed
+    if (PL > 0) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (u < PL) buf[0][u] = sh_pts[u * NL + tid];
+    }
     PoseU P;
     {
       double x[7];
@@ -196,42 +303,41 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     }
     RowPlane q;
     rows_plane_setup(P.R, P.t, nx, ny, nz, pd, ps, q);
-    const int npad = ppl - cnt;
+    const int npad = ppl_eff - cnt;
     const double np = (double)npad;
     RowMoments M;
     rows_moments_reset<WITH_LOSS>(M);
-    if (PL > 0) {
-      // chunk 0 of the LDS points is read before the register points are consumed
-      v2d buf[2][CH];
 #pragma unroll
-      for (int u = 0; u < CH; ++u)
-        if (u < PL) buf[0][u] = sh_pts[u * NL + tid];
+    for (int j0 = 0; j0 < NP; j0 += 2) {
+      if (j0 < ppl) {  // wave-uniform; both points of the pair in one basic block
 #pragma unroll
-      for (int j = 0; j < PR; ++j)
-        if (j < ppl) rows_point<WITH_LOSS>(q, inv_lf2, reg[j][0], reg[j][1], M);
+        for (int j = j0; j < j0 + 2 && j < NP; ++j) {
+          if (j >= PR && (j - PR) % CH == 0 && (j - PR) / CH + 1 < NCH) {  // entering an LDS chunk: request the next one
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int c1 = (j - PR) / CH + 1;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (c + 1 < NCH) {
-#pragma unroll
-          for (int u = 0; u < CH; ++u)
-            if ((c + 1) * CH + u < PL) buf[(c + 1) & 1][u] = sh_pts[((c + 1) * CH + u) * NL + tid];
+            for (int u = 0; u < CH; ++u)
+              if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + tid];
+          }
+          const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
+          if (j == j0) res_point<WITH_LOSS, false>(q, inv_lf2, v[0], v[1], M);
+          else res_point<WITH_LOSS, true>(q, inv_lf2, v[0], v[1], M);
         }
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-          if (c * CH + u < PL && PR + c * CH + u < ppl) rows_point<WITH_LOSS>(q, inv_lf2, buf[c & 1][u][0], buf[c & 1][u][1], M);
+        if (j0 + 1 >= NP && WITH_LOSS) {  // a last single point: renormalise here
+          M.expo += __builtin_amdgcn_frexp_exp(M.prod);
+          M.prod = __builtin_amdgcn_frexp_mant(M.prod);
+        }
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < PR; ++j)
-        if (j < ppl) rows_point<WITH_LOSS>(q, inv_lf2, reg[j][0], reg[j][1], M);
     }
+    RES_STAMP(5 + 6 * pass_no, clock64());
     // the zero padding out again: npad points (0, 0) with r0 = c0 each
     double lp = 0.0;
     {
       const double c0 = q.c0;
       if (WITH_LOSS) {
         const double sum_p = fma(c0 * c0, inv_lf2, 1.0);
-        const double w_p = fmax(2.2250738585072014e-308, rcp_ge1(sum_p));
+        const double w_p = rcp_ge1(sum_p);
         const double cs = npad > 0 ? np * w_p : 0.0;
         M.S0 -= cs;
         M.T0 = fma(-cs, c0, M.T0);
@@ -251,6 +357,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     rows_flush<WITH_LOSS>(q, M, acc);
     if (WITH_LOSS) acc[27] = fma(-q.s2, lp, acc[27]);
     wave_reduce_butterfly(acc, sh_wsum[wave], lane);
+    RES_STAMP(6 + 6 * pass_no, clock64());
   };
   // totals of the pass (fixed order) + the controller, on wave 0; the other waves leave from its barrier
   auto totals = [&]() {
@@ -264,26 +371,47 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
+#ifndef CLC_RES_PEEL
+#define CLC_RES_PEEL 1
+#endif
+  const int cap = opt.max_num_iterations + 2;
+#if CLC_RES_PEEL
   pass();
   __syncthreads();
-  if (wave == 0) {
+  RES_STAMP(7, clock64());
+  if (wave == cw) {
     totals();
+    RES_STAMP(8, clock64());
     lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);  // contains the barrier ...
   } else {
     __syncthreads();  // ... the other waves meet here
   }
-  const int cap = opt.max_num_iterations + 2;
+  RES_STAMP(9, clock64());
+  pass_no = 1;
   for (int k = 0; k < cap && st.status == CLC_RUNNING; ++k) {  // (status: published before the barrier)
+#else
+  for (int k = -1; k < cap && (k < 0 || st.status == CLC_RUNNING); ++k) {
+#endif
     pass();
     __syncthreads();
-    if (wave == 0) {
+    RES_STAMP(7 + 6 * pass_no, clock64());
+    if (wave == cw) {
       totals();
+      RES_STAMP(8 + 6 * pass_no, clock64());
+#if CLC_RES_PEEL
       lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+#else
+      if (k < 0) lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+      else lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+#endif
     } else {
       __syncthreads();
     }
+    RES_STAMP(9 + 6 * pass_no, clock64());
+    ++pass_no;
   }
-  if (wave == 0) {
+  RES_STAMP(1, wall_clock64());
+  if (wave == cw) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

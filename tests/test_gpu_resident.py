@@ -83,10 +83,10 @@ def test_resident_layout_is_built_and_is_the_default(sv, oracle_mod):
 
 
 @pytest.mark.parametrize("use_loss", [1, 0])
-@pytest.mark.parametrize("n_poses,K", [(20, 500), (7, 1409), (40, 33), (300, 5), (1, 64), (512, 1)])
+@pytest.mark.parametrize("n_poses,K", [(20, 500), (7, 1409), (40, 33), (300, 5), (1, 64), (500, 4)])
 def test_resident_scan_shapes(sv, oracle_mod, n_poses, K, use_loss):
     """Scan shapes that exercise the lane split: C4's 20 x 500, long scans over many lanes, short scans of one lane each,
-    one point per scan (512 scans = every lane its own plane), a single scan — with and without the Cauchy loss."""
+    500 scans of four points (every lane of the 512-lane form its own plane), a single scan — with and without the Cauchy loss."""
     P = 6
     rec, off, x0, gt = _batch(77 + n_poses, P, n_poses, K)
     sv.set_launch(0, -1)
@@ -120,9 +120,9 @@ def test_resident_falls_back_when_a_problem_does_not_fit(sv, oracle_mod):
     assert not sv.debug_resident()[0]
     p1, s1 = sv.solve_batched(x0)
     sv.set_launch(0, LOCKSTEP_256)
-    p2, s2 = sv.solve_batched(x0)
+    p2, s2 = sv.solve_batched(x0)  # (several workgroups per problem here: another summation order)
     sv.set_launch(0, -1)
-    assert np.array_equal(p1, p2)
+    assert [_key(s) for s in s1] == [_key(s) for s in s2] and np.abs(p1 - p2).max() <= 1e-9
     rec, off, x0, gt = _batch(6, 2, 600, 2)  # 600 scans of two points: more scans than lanes
     sv.upload_batched(rec, off)
     assert not sv.debug_resident()[0]
