@@ -241,20 +241,25 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   // beyond ppl become zeros (the pass may run one slot past ppl).
   const v2d* __restrict__ src = reinterpret_cast<const v2d*>(xyl) + (size_t)row0 * NL + tid;
   const int j_last = ppl > 0 ? ppl - 1 : 0;
+  // Order: the LDS-bound rows first, then the register rows — loads return in order, so the LDS part is written (and the
+  // barrier in front of the first pass passed) while the register rows are still in flight; the first pass then consumes
+  // them as they arrive.  (A lane reads back only its own LDS slots: no barrier is needed for sh_pts.)
+  v2d lds_v[PL > 0 ? PL : 1];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int j = PR + i;
+    lds_v[i] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+  }
   v2d reg[PR];
 #pragma unroll
   for (int j = 0; j < PR; ++j) reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
   const ResLane dl = lane_desc[(size_t)prob * NL + tid];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
-    const int j = PR + i;
-    v2d v = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
-    if (j >= ppl) { v[0] = 0.0; v[1] = 0.0; }
+    v2d v = lds_v[i];
+    if (PR + i >= ppl) { v[0] = 0.0; v[1] = 0.0; }
     sh_pts[i * NL + tid] = v;
   }
-#pragma unroll
-  for (int j = 0; j < PR; ++j)
-    if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; }
   // The lane's plane is fetched again in every pass (48 bytes per lane out of L1/L2: a problem's group entries are ~1 KB)
   // rather than held in 10 VGPRs across the controller, which needs every register it can get.
   const double* __restrict__ gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
@@ -272,6 +277,9 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   const int ppl_eff = (ppl & 1) != 0 && ppl < NP ? ppl + 1 : ppl;
   __syncthreads();
   RES_STAMP(3, clock64());
+#pragma unroll
+  for (int j = 0; j < PR; ++j)
+    if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; }
   int pass_no = 0;  // (debug stamps)
 
   // one evaluation pass at st.x_eval: the wave's 28 totals -> sh_wsum[wave]
@@ -303,6 +311,9 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     }
     RowPlane q;
     rows_plane_setup(P.R, P.t, nx, ny, nz, pd, ps, q);
+#ifdef CLC_STAMPS
+    if (wave != cw) { asm volatile("" :: "v"(q.mx), "v"(q.c0)); RES_STAMP(8 + 6 * pass_no, clock64()); }  // plane + pose have arrived
+#endif
     const int npad = ppl_eff - cnt;
     const double np = (double)npad;
     RowMoments M;
@@ -382,7 +393,11 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   if (wave == cw) {
     totals();
     RES_STAMP(8, clock64());
-    lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);  // contains the barrier ...
+    __builtin_amdgcn_s_setprio(3);  // the serial controller wins the issue arbitration against the co-resident problem's streaming wave
+    int lane_c = lane;
+    asm volatile("" : "+v"(lane_c));  // (opaque: the controller's per-lane LDS addresses are recomputed here, not hoisted out of the pass loop and spilled)
+    lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane_c);  // contains the barrier ...
+    __builtin_amdgcn_s_setprio(0);
   } else {
     __syncthreads();  // ... the other waves meet here
   }
@@ -399,7 +414,11 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
       totals();
       RES_STAMP(8 + 6 * pass_no, clock64());
 #if CLC_RES_PEEL
-      lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+      __builtin_amdgcn_s_setprio(3);
+      int lane_c = lane;
+      asm volatile("" : "+v"(lane_c));
+      lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane_c);
+      __builtin_amdgcn_s_setprio(0);
 #else
       if (k < 0) lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
       else lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);

@@ -51,7 +51,7 @@ def med(a):
     a = a[np.isfinite(a)]
     return float(np.median(a)) if a.size else float("nan")
 print(f"entry -> loads landed (cycles): wave0 {med((t[:,0,3]-t[:,0,2]).astype(float)):.0f}  wave1 {med((t[:,1,3]-t[:,1,2]).astype(float)):.0f}")
-names = ["point loop", "flush+corr+butterfly", "barrier 1 wait", "totals (w0)", "controller (w0) / barrier 2 wait (w1)"]
+names = ["point loop (incl. plane/pose fetch)", "flush+corr+butterfly", "barrier 1 wait", "totals (w0) / pass start -> plane+pose arrived (w1)", "controller (w0) / barrier 2 wait (w1)"]
 for p in range(min(NPASS, int(passes.max()))):
     sel = passes > p
     if sel.sum() == 0:
@@ -60,8 +60,8 @@ for p in range(min(NPASS, int(passes.max()))):
     row = []
     for w in (0, 1):
         d = [med((t[sel, w, b + i + 1] - t[sel, w, b + i]).astype(float)) for i in range(5)]
-        if w == 1:
-            d = d[:3] + [float("nan"), med((t[sel, w, b + 5] - t[sel, w, b + 3]).astype(float))]
+        if w == 1:  # slot b + 4 of the non-controller wave: plane + pose arrived (start of the point arithmetic)
+            d = d[:3] + [med((t[sel, w, b + 4] - t[sel, w, b]).astype(float)), med((t[sel, w, b + 5] - t[sel, w, b + 3]).astype(float))]
         row.append(d)
     nxt = med((t[sel & (passes > p + 1), 0, b + 6] - t[sel & (passes > p + 1), 0, b + 5]).astype(float)) if p + 1 < NPASS else float("nan")
     tot = med((t[sel, 1, b + 5] - t[sel, 1, b]).astype(float))

@@ -136,7 +136,8 @@ def test_resident_falls_back_when_a_problem_does_not_fit(sv, oracle_mod):
 
 
 def test_resident_flag_4096_is_the_previous_default(sv):
-    """Flag 4096 at solve time: the whole-solve-per-launch kernel on the row layout, bit-identical to the lockstep form."""
+    """Flag 4096 at solve time: the round-2 kernels on the row layout (same decisions as the lockstep form, results to
+    rounding — the workgroups per problem differ); at upload time: no lane layout."""
     rec, off, x0, gt = _batch(9, 64, 8, 200)
     sv.set_launch(0, -1)
     sv.upload_batched(rec, off)
@@ -145,9 +146,11 @@ def test_resident_flag_4096_is_the_previous_default(sv):
     pa, sa = sv.solve_batched(x0)
     sv.set_launch(0, LOCKSTEP_256)
     pb, sb = sv.solve_batched(x0)
+    sv.set_launch(0, NO_RESIDENT)
+    assert [_key(s) for s in sa] == [_key(s) for s in sb] and np.abs(pa - pb).max() <= 1e-9
+    sv.upload_batched(rec, off)  # flag 4096 at upload: the lane layout is not built at all
+    assert not sv.debug_resident()[0]
     sv.set_launch(0, -1)
-    assert np.array_equal(pa, pb)
-    assert [_key(s) for s in sa] == [_key(s) for s in sb]
 
 
 def test_resident_wide_ragged_batch(sv, oracle_mod):
