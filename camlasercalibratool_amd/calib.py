@@ -58,11 +58,22 @@ class Session:
     def __init__(self, obs: ObsLike, solver: Optional[Solver] = None):
         self.S = _as_set(obs)
         self.sv = solver or _shared_solver()
+        self._store()
+
+    def _store(self):
         self.sv.store_observations(self.S)
+        self._generation = self.sv.store_generation
+
+    def _ensure_stored(self):
+        """The stored scans belong to the (possibly shared) solver handle: if somebody else — another Session, one of the
+        module-level calls below — stored theirs since, put ours back before selecting from them."""
+        if self.sv.store_generation != self._generation:
+            self._store()
 
     def CamLaserCalClosedSolution(self, Tlc: np.ndarray, verbose: bool = True):
         """Closed-form initialiser; overwrites Tlc (camera->laser) like LaseCamCalCeres.cpp:198-200."""
         sv = self.sv
+        self._ensure_stored()
         sv.select_observations(True, False)  # points_on_line only, :143
         T, unobservable, sv9 = sv.closed_form()
         if unobservable and verbose:  # :173-178
@@ -78,6 +89,7 @@ class Session:
                             options: Optional[Options] = None, verbose: bool = True) -> CalibrationReport:
         """Nonlinear refinement; Tcl (laser->camera) is in/out like LaseCamCalCeres.cpp:215,:311-314."""
         sv = self.sv
+        self._ensure_stored()
         n_rec = sv.select_observations(use_linefitting_data, use_boundary_constraint)
         pose0 = simdata.pose7_from_T(np.asarray(Tcl, dtype=np.float64))  # :215-219
         res = sv.solve(pose0, options)

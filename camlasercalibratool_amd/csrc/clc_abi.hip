@@ -147,6 +147,7 @@ struct clc_handle {
   double* d_soff = nullptr; size_t soff_cap = 0; // pts_off [P+1], ptl_off [P+1], rec_off [P+1] as long long
   std::vector<long long> s_pts_off, s_ptl_off;
   int store_poses = -1;                          // -1: nothing stored
+  int64_t store_generation = 0;                  // bumped by every successful clc_store_observations (clc_store_generation)
   // launch geometry
   int grid_override = 0;
   int launch_flags = kDefaultLaunchFlags;
@@ -211,6 +212,7 @@ struct clc_handle {
   double* d_bpartials = nullptr;
   size_t bpartials_cap_blocks = 0;
   long long batch_max_tiles = 0;
+  long long batch_max_rows = 0;  // most rows of the row layout any one problem owns (exact, from prob_row)
   size_t batch_total_tiles = 0;
   size_t n_problems = 0;
   size_t problems_cap = 0;
@@ -654,8 +656,7 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
   // wave per problem) or a single problem is so long (> 1 024 rows, ~6.5e4 observations) that four waves are too few.
   {
     const size_t row_bytes = (size_t)h->bn_rows * (clc::ROW_DOUBLES * sizeof(double) + sizeof(clc::RowDesc));
-    const long long est_rows_pp = h->batch_total_tiles > 0 ? (long long)((double)h->batch_max_tiles * (double)h->bn_rows / (double)h->batch_total_tiles) : 0;
-    bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && est_rows_pp <= 1024;
+    bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && h->batch_max_rows <= 1024;
   }
   // Problems that fit a workgroup's registers + LDS are read from HBM once and solved on chip (clc_resident.hpp).
   bl->resident = h->bres_ok && (h->launch_flags & (clc::FLAG_NO_RESIDENT | clc::FLAG_BATCHED_LOCKSTEP)) == 0;
@@ -952,8 +953,11 @@ int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz,
   if (ML > 0) CLC_HIP(hipMemcpyAsync(h->d_sptl, ptl + 3 * ptl_off[0], ML * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CLC_HIP(hipStreamSynchronize(h->stream));  // the caller's arrays may go away
   h->store_poses = n_poses;
+  h->store_generation++;
   return CLC_OK;
 }
+
+int64_t clc_store_generation(const clc_handle* h) { return h ? h->store_generation : -1; }
 
 int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_boundary_constraint, int64_t* n_records) {
   if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_select_observations: NULL handle");
@@ -1508,6 +1512,12 @@ int upload_batched_impl(clc_handle* h, const clc_observation* records, bool on_d
   }
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
   if (crc != CLC_OK) return crc;
+  h->batch_max_rows = 0;
+  if (h->brows_ok) {  // O(P) words back: the whole-solve kernel is chosen on the real longest problem, not an estimate
+    std::vector<long long> pr(P + 1);
+    CLC_HIP(hipMemcpy(pr.data(), h->d_prob_row, sizeof(long long) * (P + 1), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < P; ++k) h->batch_max_rows = std::max(h->batch_max_rows, pr[k + 1] - pr[k]);
+  }
   h->n_problems = P;
   return CLC_OK;
 }
@@ -1556,17 +1566,29 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
     else { if (bl.res_nt) CLC_LAUNCH_RES(false, true, NW, PR, PL); else CLC_LAUNCH_RES(false, false, NW, PR, PL); }            \
   } while (0)
+    const bool timed = opt.profile_events == 1;  // HIP event pair around the one launch -> clc_summary.eval_kernel_ms of every problem
+    if (timed) {
+      const int rc = ensure_events(h, 2);
+      if (rc != CLC_OK) return rc;
+      CLC_HIP(hipEventRecord(h->ev[0], h->stream));
+    }
     if (h->bres_lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
     else CLC_LAUNCH_RES_V(8, kResPR512, kResPL512);
 #undef CLC_LAUNCH_RES_V
 #undef CLC_LAUNCH_RES
     CLC_HIP(hipGetLastError());
+    if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
     CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcomes written over PCIe visible
+    float kernel_ms = 0.0f;
+    if (timed) CLC_HIP(hipEventElapsedTime(&kernel_ms, h->ev[0], h->ev[1]));
     h->results_valid = P;
     std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
     std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    for (size_t k = 0; k < P; ++k) summaries[k].solve_ms = ms;
+    for (size_t k = 0; k < P; ++k) {
+      summaries[k].solve_ms = ms;
+      if (timed) { summaries[k].eval_kernel_ms = (double)kernel_ms; summaries[k].eval_kernel_launches = 1; }
+    }
     return CLC_OK;
   }
   if (bl.whole_solve) {
@@ -1798,6 +1820,8 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;        // optional: what RCCL itself says the communicator spans
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;  // optional
   std::string origin;
   std::string error;
 };
@@ -1840,6 +1864,8 @@ RcclApi& rccl() {
     CLC_BIND(AllGather, "ncclAllGather")
     CLC_BIND(GetErrorString, "ncclGetErrorString")
 #undef CLC_BIND
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
       api.lib = nullptr;
     }
@@ -1897,6 +1923,11 @@ int clc_comm_create(clc_comm** out, clc_handle* h, const char id[CLC_COMM_ID_BYT
   c->comm = comm;
   c->rank = rank;
   c->world = world;
+  // what RCCL itself reports for the communicator (clc_comm_world / clc_comm_rank return these): a SCALE record can then
+  // show that RCCL saw N ranks, not just that N was passed in
+  int n = 0;
+  if (api.CommCount && api.CommCount(comm, &n) == ncclSuccess && n > 0) c->world = n;
+  if (api.CommUserRank && api.CommUserRank(comm, &n) == ncclSuccess) c->rank = n;
   *out = c;
   return CLC_OK;
 }
@@ -1923,9 +1954,15 @@ int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_r
   if (!c || cap_per_rank == 0 || first_global_index < 0)
     return fail(CLC_ERR_INVALID_ARG, "clc_gather_results: bad argument");
   clc_handle* h = c->h;
-  const size_t n_local = h->results_valid;
-  if (n_local > cap_per_rank) return fail(CLC_ERR_INVALID_ARG, "clc_gather_results: cap_per_rank < local problems");
-  if (n_local > 0 && !h->d_results) return fail(CLC_ERR_NO_DATA, "clc_gather_results: no solved batch on the handle");
+  size_t n_local = h->results_valid;
+  // This is a collective: a rank that returned before the all-gather would leave every other rank blocked in it.  A rank
+  // with a LOCAL problem therefore still enters the collective — with an all-padding send buffer — and reports its error
+  // afterwards.  (Arguments every rank passes alike — a NULL communicator, cap_per_rank == 0 — are rejected above on all
+  // ranks together; a failed device allocation below cannot be papered over: the communicator is then unusable.)
+  int local_rc = CLC_OK;
+  const char* local_msg = nullptr;
+  if (n_local > cap_per_rank) { local_rc = CLC_ERR_INVALID_ARG; local_msg = "clc_gather_results: cap_per_rank < local problems (this rank contributed padding only)"; n_local = 0; }
+  else if (n_local > 0 && !h->d_results) { local_rc = CLC_ERR_NO_DATA; local_msg = "clc_gather_results: no solved batch on the handle (this rank contributed padding only)"; n_local = 0; }
   CLC_HIP(hipSetDevice(h->device));
   if (cap_per_rank > c->cap) {
     if (c->d_send) CLC_HIP(hipFree(c->d_send));
@@ -1950,6 +1987,7 @@ int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_r
   CLC_HIP(hipMemcpyAsync(c->h_recv, c->d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
   CLC_HIP(hipStreamSynchronize(h->stream));
   if (all_records) std::memcpy(all_records, c->h_recv, bytes);
+  if (local_rc != CLC_OK) return fail(local_rc, local_msg);
   return CLC_OK;
 }
 

@@ -140,6 +140,13 @@ inline void jacobi_eig_sym(const double* Ain, int n, double* w, double* V) {
 // contributes zero instead of a division by zero), L^-T, P^T.  It therefore returns a finite vector for a semi-definite
 // (unobservable) normal matrix too — which is what the reference goes on to use after printing its notice (:173-181).
 // A plain Cholesky, as round 1 used here, fails on such input.
+// Pivot rule: like Eigen's unblocked kernel (LDLT.h, ldlt_inplace<Lower>::unblocked) the factorisation is LEFT-looking —
+// step k updates only entry (k, k) and the column below it (A21 -= A20 (D A10^T)), never the trailing block — so "the
+// largest remaining diagonal entry" is searched on diagonal entries that have not been updated yet, i.e. on the
+// original diagonal of the remaining rows.  That is what this loop does too (a right-looking factorisation would
+// pivot on the Schur complement's diagonal and pick different pivots on semi-definite input).  Restated from the
+// published source, not run against an Eigen build (none in this image): on unobservable input the returned Tlc is
+// pinned against this restatement only.
 inline void ldlt_solve_n(const double* Ain, const double* b, double* x, int n) {
   double A[81], D[9], y[9];
   int perm[9];

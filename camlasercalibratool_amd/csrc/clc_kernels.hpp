@@ -1487,7 +1487,7 @@ __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o
     const bool fun_tol = fabs(it_cost_change) <= o.function_tolerance * x_cost;
     early = par_tol ? CLC_CONVERGENCE_PARAMETER : (fun_tol ? CLC_CONVERGENCE_FUNCTION : CLC_RUNNING);
     // ---- IsStepSuccessful; HandleSuccessfulStep / HandleUnsuccessfulStep as selects ----
-    it_rel = it_cost_change * rcp_pos(mcc);
+    it_rel = it_cost_change * rcp_pos_safe(mcc);
     success = it_rel > o.min_relative_decrease;
     const double q = 2.0 * it_rel - 1.0;  // StepAccepted
     double den = 1.0 - q * q * q;

@@ -272,7 +272,7 @@ CLC_HD void lm_advance(LmStateT<M>& s, LmScratchT<M>& w, const clc_options& o, c
       return;
     }
     // ---- IsStepSuccessful (monotonic step evaluator) ----
-    it.relative_decrease = it.cost_change * rcp_pos(s.model_cost_change);  // model_cost_change > 0 (lm_compute_step)
+    it.relative_decrease = it.cost_change * rcp_pos_safe(s.model_cost_change);  // model_cost_change > 0 (lm_compute_step), possibly tiny
     if (it.relative_decrease > o.min_relative_decrease) {
       // ---- HandleSuccessfulStep: the fused pass already produced g,H at the candidate ----
       CLC_ROLLED for (int i = 0; i < NA; ++i) s.x[i] = s.x_eval[i];

@@ -50,6 +50,19 @@ CLC_HD double rcp_pos(double x) {
 #endif
 }
 
+// 1/x for x > 0 that may be tiny (the controller's model cost change): rcp_pos, and the IEEE quotient where it breaks
+// down — for a subnormal x the v_rcp_f64 seed overflows to +inf and the Newton steps turn it into NaN, where Ceres'
+// cost_change / model_cost_change is a plain division (+inf for a positive cost change: the step is accepted).
+CLC_HD double rcp_pos_safe(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = rcp_pos(x);
+  if (!(fabs(y) <= 1.7976931348623157e308)) y = 1.0 / x;
+  return y;
+#else
+  return 1.0 / x;
+#endif
+}
+
 // sqrt(x) for x >= 0 as x * rsqrt(x) (<= 2 ulp; 0 for 0): used for norms that only feed tolerance tests and the trace.
 CLC_HD double sqrt_pos(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -14,6 +14,8 @@ Result record (12 doubles per problem, clc_result_record):
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -67,14 +69,15 @@ def _rank_world() -> Tuple[int, int]:
     return 0, 1
 
 
-def gather_result_records(local: np.ndarray, n_problems: int, device: Optional[str] = None) -> np.ndarray:
+def gather_result_records(local: np.ndarray, n_problems: int, device: Optional[str] = None, ordered: bool = True) -> np.ndarray:
     """torch.distributed path (any backend; what the CPU/gloo tests run): all_gather of the per-problem
-    result records -> [n_problems, 12] on every rank, ordered by global problem index."""
+    result records -> [n_problems, 12] on every rank, ordered by global problem index (ordered=False: the raw
+    rank-major [world * cap, 12] buffer with its padding records, global index -1, like clc_gather_results)."""
     import torch
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return order_records(local, n_problems)
+        return order_records(local, n_problems) if ordered else np.asarray(local, dtype=np.float64).reshape(-1, RECORD)
     world = dist.get_world_size()
     cap = shard_capacity(n_problems, world)
     buf = torch.full((cap, RECORD), -1.0, dtype=torch.float64)
@@ -84,7 +87,7 @@ def gather_result_records(local: np.ndarray, n_problems: int, device: Optional[s
         buf = buf.to(device)
     out = torch.empty((world * cap, RECORD), dtype=torch.float64, device=buf.device)
     dist.all_gather_into_tensor(out, buf)
-    return order_records(out.cpu().numpy(), n_problems)
+    return order_records(out.cpu().numpy(), n_problems) if ordered else out.cpu().numpy()
 
 
 def exchange_unique_id(rank: int, world: int) -> bytes:
@@ -116,7 +119,12 @@ class ShardSolver:
         self.n_problems = n_problems
         self.lo, self.hi = shard_problems(n_problems, self.rank, self.world)
         self.cap = shard_capacity(n_problems, self.world)
-        self.solver = Solver(self.rank if device_index is None else device_index)
+        if device_index is None:
+            # the HIP device is the LOCAL rank (torchrun exports LOCAL_RANK); the global rank only names the device on one
+            # node with every GPU visible — the fallback for launchers that set neither
+            device_index = int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ else (0 if self.world == 1 else self.rank)
+        self.device_index = device_index
+        self.solver = Solver(device_index)
         self.comm = Comm(self.solver, exchange_unique_id(self.rank, self.world), self.rank, self.world) if use_rccl else None
 
     def upload(self, records: np.ndarray, offsets: np.ndarray):
@@ -132,7 +140,7 @@ class ShardSolver:
             self.last_poses, self.last_summaries = self.solver.solve_batched(poses0, options)
         if self.comm is None:
             local = pack_records(self.last_poses, self.last_summaries, self.lo) if self.hi > self.lo else np.zeros((0, RECORD))
-            return gather_result_records(local, self.n_problems)
+            return gather_result_records(local, self.n_problems, ordered=ordered)
         out = self.comm.gather_results(self.lo, self.cap, copy=copy)
         return order_records(out, self.n_problems) if ordered else out
 

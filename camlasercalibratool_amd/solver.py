@@ -65,6 +65,11 @@ class Comm:
     def library(self) -> str:
         return self._L.clc_comm_library().decode()
 
+    @property
+    def rccl_ranks(self) -> int:
+        """Size of the communicator as RCCL reports it (ncclCommCount)."""
+        return int(self._L.clc_comm_world(self._c))
+
     def gather_results(self, first_global_index: int, cap_per_rank: int, copy: bool = True) -> np.ndarray:
         """ncclAllGather of the result records of the solver's last solve_batched -> [world*cap_per_rank, 12]
         (rank-major; padding records have global index -1).  copy=False returns a view of the communicator's
@@ -157,6 +162,11 @@ class Solver:
         check(self._L.clc_store_observations(self._h, C.c_int(S.n_poses), dptr(np.ascontiguousarray(S.tag_q, dtype=np.float64)),
                                              dptr(np.ascontiguousarray(S.tag_t, dtype=np.float64)), iptr(S.pts_off), dptr(S.pts),
                                              iptr(S.ptl_off), dptr(S.ptl)), "clc_store_observations")
+
+    @property
+    def store_generation(self) -> int:
+        """Stamp of the scans currently stored on this handle (bumped by every store_observations)."""
+        return int(self._L.clc_store_generation(self._h))
 
     def select_observations(self, use_linefitting_data: bool = True, use_boundary_constraint: bool = False) -> int:
         """Build the residual blocks of the selection on the device (src/LaseCamCalCeres.cpp:222-295) and make them the

@@ -218,7 +218,7 @@ namespace clc_adapter {
 //     run.ClosedSolution(Tlc_initial);  Eigen::Matrix4d Tcl = Tlc_initial.inverse();  run.Calibration(Tcl, false);
 class Session {
  public:
-    explicit Session(const std::vector<Oberserve>& obs) : ok_(false)
+    explicit Session(const std::vector<Oberserve>& obs) : ok_(false), generation_(-1)
     {
         Handle H;  // locked first: flatten gathers into the process-wide pinned buffers
         if (!H.h) return;
@@ -229,6 +229,7 @@ class Session {
             std::cerr << "[clc] " << clc_last_error() << std::endl;
             return;
         }
+        generation_ = clc_store_generation(H.h);
         ok_ = true;
     }
 
@@ -236,7 +237,7 @@ class Session {
     void ClosedSolution(Eigen::Matrix4d &Tlc)
     {
         Handle H;
-        if (!ok_ || !H.h) return;
+        if (!ok_ || !H.h || !mine(H.h)) return;
         if (clc_select_observations(H.h, /*linefit=*/1, /*boundary=*/0, NULL) != CLC_OK) {  // points_on_line only, :143
             std::cerr << "[clc] " << clc_last_error() << std::endl;
             return;
@@ -260,7 +261,7 @@ class Session {
     void Calibration(Eigen::Matrix4d &Tcl, bool use_linefitting_data = true, bool use_boundary_constraint = false)
     {
         Handle H;
-        if (!ok_ || !H.h) return;
+        if (!ok_ || !H.h || !mine(H.h)) return;
         int64_t n_rec = 0;
         if (clc_select_observations(H.h, use_linefitting_data, use_boundary_constraint, &n_rec) != CLC_OK) {
             std::cerr << "[clc] " << clc_last_error() << std::endl;  // incl. the reference's std::out_of_range case, :278
@@ -313,7 +314,18 @@ class Session {
     }
 
  private:
+    // The stored scans belong to the process-wide handle: a later Session (or one of the free functions below, which are
+    // one-call sessions) replaces them.  This Session does not keep a copy of `obs`, so it refuses to go on — loudly —
+    // rather than solve somebody else's observations.
+    bool mine(clc_handle* h) const
+    {
+        if (clc_store_generation(h) == generation_) return true;
+        std::cerr << "[clc] Session: another Session / CamLaserCal* call has replaced the scans stored on the shared context; "
+                     "create a new Session for these observations" << std::endl;
+        return false;
+    }
     bool ok_;
+    int64_t generation_;
 };
 
 }  // namespace clc_adapter

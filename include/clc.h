@@ -146,7 +146,12 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
  * kernel in 256-thread workgroups (default: one wave per workgroup for batches of >= 8 problems per CU),
  * 2048 = batched solver: lockstep [evaluation, controller] launches per LM iteration even where the default
  * is one workgroup per problem running the problem's whole solve in ONE launch (row layout of at most 1 GiB,
- * problems of at most ~6.5e4 observations);
+ * no problem longer than 1 024 rows of 64 points — scans are padded to whole rows),
+ * 4096 = batched solver: not the on-chip resident kernel (one workgroup per problem reads the problem's scan points from
+ * HBM ONCE into registers + LDS and runs the whole solve there; the default whenever every problem of the batch fits a
+ * workgroup: at most ~11 000 points and 512 scans, p.z == 0) — at upload: do not build its layout; at solve: run the
+ * paths above, 8192 = resident layout over 512 lanes (one 512-thread workgroup per CU) even where 256 lanes (two
+ * problems per CU) hold every problem;
  * -1 = library default (2|16|32|128|256|512; non-temporal loads / the deep pipeline chosen per launch when
  * the array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
@@ -182,6 +187,10 @@ int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz,
                            const int64_t* pts_off, const double* pts, const int64_t* ptl_off, const double* ptl);
 int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_boundary_constraint,
                             int64_t* n_records);
+/* Number of successful clc_store_observations calls on this handle so far (-1 for NULL).  The stored scans belong to the
+ * handle, not to whoever stored them: a caller that keeps "its" scans across calls on a shared handle (the Session of
+ * the drop-in header) remembers this stamp and re-stores, or refuses to go on, when it has moved. */
+int64_t clc_store_generation(const clc_handle* h);
 
 /* ---- observation array --------------------------------------------------------------
  * Copies N records to the device and re-tiles them for coalesced 16-byte loads.  Stays
@@ -308,6 +317,7 @@ int clc_comm_unique_id(char id[CLC_COMM_ID_BYTES]);
  * every rank of the job must enter it. */
 int clc_comm_create(clc_comm** out, clc_handle* h, const char id[CLC_COMM_ID_BYTES], int rank, int world);
 void clc_comm_destroy(clc_comm* c);
+/* Rank and size of the communicator as RCCL itself reports them (ncclCommUserRank / ncclCommCount). */
 int clc_comm_rank(const clc_comm* c);
 int clc_comm_world(const clc_comm* c);
 /* ncclAllGather of the result records the LAST clc_solve_batched on the comm's handle left in device

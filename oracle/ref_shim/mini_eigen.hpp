@@ -608,6 +608,9 @@ typename MatrixBase<D>::PlainObject MatrixBase<D>::inverse() const {
 // Eigen documents for LDLT ("robust Cholesky decomposition of a matrix with pivoting"; positive or negative
 // SEMI-definite input allowed): the reference calls it on a normal matrix it has just reported as unobservable
 // (LaseCamCalCeres.cpp:173-181), so the semi-definite case must not divide by zero.
+// Left-looking like Eigen's unblocked kernel (LDLT.h, ldlt_inplace<Lower>::unblocked): the pivot search runs over
+// diagonal entries that have not been updated yet — the original diagonal of the remaining rows — not over the Schur
+// complement's diagonal.  Stand-in written from the published source; not checked against an Eigen build.
 template <typename M>
 class LDLT {
  public:

@@ -59,8 +59,9 @@ def _worker(rank, world, port, P, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("P", [5, 6])
-def test_sharded_solve_and_gather_world2(P):
+@pytest.mark.parametrize("P,world", [(5, 2), (6, 2), (13, 8)])
+def test_sharded_solve_and_gather(P, world):
+    """world 2, and 8 ranks with a problem count 8 does not divide (shards of 2 and 1 problems, padding in the gather)."""
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
@@ -68,17 +69,18 @@ def test_sharded_solve_and_gather_world2(P):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, P, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = [q.get(timeout=240) for _ in range(2)]
+    outs = [q.get(timeout=400) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     full = next(o for o in outs if o.ndim == 2)
-    idx = next(o for o in outs if o.ndim == 1)
-    assert full.shape == (P, 12)
-    assert np.array_equal(full[:, 11], np.arange(P)) and np.array_equal(idx, np.arange(P))
+    assert full.shape == (P, 12) and np.array_equal(full[:, 11], np.arange(P))
+    assert sum(o.ndim == 1 for o in outs) == world - 1
+    for idx in (o for o in outs if o.ndim == 1):  # every other rank holds the same ordered result
+        assert np.array_equal(idx, np.arange(P))
     # every problem solved exactly once, by the right rank, and equal to a single-process solve
     sys.path.insert(0, ROOT)
     import oracle

@@ -818,6 +818,38 @@ def test_bench_two_rank_path_dry_run():
     assert d["roofline"]["frac"] > 0
 
 
+def test_bench_eight_rank_path_uneven_shards_dry_run():
+    """What C4 looks like on 8 ranks, through bench.py's own N>1 path: 8 processes (oversubscribing the one visible GPU, gloo
+    process group), a problem count that 8 does not divide — shards of 13 and 12 problems, padding records in the gather —
+    and the rank-major gathered buffer put back into global order by bench.py (order_records)."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--oversubscribe", "--problems-total", "100", "--problems-per-gpu", "13", "--shard-poses", "6",
+           "--shard-pts", "100"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    c4 = d["batched_c4_shard"]
+    g = c4["gather"]
+    assert c4["problems"] == 100
+    assert g["shard_sizes"] == [13, 13, 13, 13, 12, 12, 12, 12] and g["records_per_rank"] == 13
+    assert g["first_global_index_per_rank"] == [0, 13, 26, 39, 52, 64, 76, 88]
+    assert g["padding_records"] == 8 * 13 - 100
+    assert g["first_record_index_of_each_rank_block"] == [0.0, 13.0, 26.0, 39.0, 52.0, 64.0, 76.0, 88.0]
+    first, last = c4["first_and_last_record"]
+    assert first[11] == 0.0 and last[11] == 99.0
+    assert c4["max_abs_T_err_vs_ground_truth_sampled"] < 0.05 and c4["T_cl_max_abs_err_vs_oracle_sample"] <= T_TOL
+    assert g["rccl_ranks"] is None  # (gloo dry run; with --backend nccl bench.py asserts rccl_ranks == WORLD_SIZE)
+
+
 def test_rccl_world1_sharded_solve_through_the_c_abi(sv, oracle_mod):
     """RCCL for real on the one GPU: clc_comm_create (ncclCommInitRank, world size 1) + clc_gather_results
     (ncclAllGather from the device buffer of clc_solve_batched) through dist.solve_sharded / ShardSolver; the gathered
