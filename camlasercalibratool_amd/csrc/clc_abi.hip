@@ -1252,7 +1252,11 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // Controller in the tail of the evaluation launch (one launch per LM iteration) vs its own launch: fused saves a
   // launch boundary (~1 us per iteration) when the evaluation is short, and loses a little when many workgroups
   // queue for the ticket (scripts/size_sweep.py: 0.178 vs 0.193 ms at 5 500 obs, 0.222 vs 0.213 at 1e5, equal at 1e6).
+#ifdef CLC_LEGACY_PATHS
   const bool fused = !use_rows(h) && ((h->launch_flags & clc::FLAG_FUSED_LM) != 0 || (h->launch_auto && grid < h->num_cus));
+#else
+  const bool fused = false;  // (eval_lm_kernel lives in clc_legacy.hpp; the default build runs the launch pair here)
+#endif
 
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
@@ -1284,6 +1288,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
     const int done = std::min(__atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE), launched);  // see solve_stepped
     if (launched < max_evals && launched - done < lookahead) {
       if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
+#ifdef CLC_LEGACY_PATHS
       if (fused) {
         const bool nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;
         const bool cp = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->compact_ok;
@@ -1305,7 +1310,9 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 #undef CLC_LAUNCH_FUSED_L
 #undef CLC_LAUNCH_FUSED
         if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
-      } else {
+      } else
+#endif
+      {
         // iteration 0 carries the initial pose by value and initialises the LM state in lm_kernel
         const bool first = launched == 0;
         launch_eval<true>(h, grid, opt.use_loss != 0, d_x_eval, d_status, opt.loss_scale_factor, first ? &p0 : nullptr);
@@ -2018,6 +2025,9 @@ int clc_debug_eval_timeline(clc_handle* h, const double pose[7], double lf, long
                             int block_threads) {
   if (!h || !pose || !stamps || (block_threads != 256 && block_threads != 512))
     return fail(CLC_ERR_INVALID_ARG, "clc_debug_eval_timeline: bad argument");
+#ifndef CLC_LEGACY_PATHS
+  return fail(CLC_ERR_INVALID_ARG, "clc_debug_eval_timeline: not in this build (-DCLC_LEGACY_PATHS)");
+#else
   if (!h->compact_ok) return fail(CLC_ERR_NO_DATA, "clc_debug_eval_timeline: needs the compact layout");
   CLC_HIP(hipSetDevice(h->device));
   const int grid = eval_grid(h, h->n_obs);
@@ -2041,6 +2051,20 @@ int clc_debug_eval_timeline(clc_handle* h, const double pose[7], double lf, long
   CLC_HIP(hipStreamSynchronize(h->stream));
   CLC_HIP(hipMemcpy(stamps, bs.p, sizeof(long long) * (size_t)n_waves * 8, hipMemcpyDeviceToHost));
   return n_waves;
+#endif
+}
+
+// What this build of the library contains beyond the default: bit 0 = the legacy paths of clc_legacy.hpp
+// (-DCLC_LEGACY_PATHS: flag 8 of clc_set_launch, clc_debug_eval_timeline), bit 1 = debug stamps (-DCLC_STAMPS).
+int clc_debug_build_features(void) {
+  int f = 0;
+#ifdef CLC_LEGACY_PATHS
+  f |= 1;
+#endif
+#ifdef CLC_STAMPS
+  f |= 2;
+#endif
+  return f;
 }
 
 // Layout report: compact[0/1] + group counts for the single-problem array and the batch.

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of the default evaluation kernel: where do the ~9 us at 1e6 obs go, and how
+"""(needs the -DCLC_LEGACY_PATHS build: CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_legacy.so)
+Per-wave timeline of the default evaluation kernel: where do the ~9 us at 1e6 obs go, and how
 balanced are the waves?  256- vs 512-thread workgroups."""
 import os, sys, ctypes as C
 import numpy as np

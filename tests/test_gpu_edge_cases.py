@@ -292,7 +292,7 @@ def test_abi_argument_validation(sv):
     assert L.clc_create(C.byref(h), 9999) == -1
     assert L.clc_solve(sv._h, None, None, None, None, 0) == -1
     assert L.clc_upload(sv._h, None, C.c_size_t(5)) == -1
-    assert L.clc_set_launch(sv._h, -1, 0) == -1 and L.clc_set_launch(sv._h, 0, 4096) == -1
+    assert L.clc_set_launch(sv._h, -1, 0) == -1 and L.clc_set_launch(sv._h, 0, 16384) == -1
     assert b"clc_set_launch" in L.clc_last_error()
     o = clc.default_options()
     o.max_num_iterations = -1

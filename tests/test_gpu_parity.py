@@ -375,7 +375,10 @@ def test_fused_controller_launch_matches_two_kernel_path(sv, oracle_mod, grid):
     """flags bit 8: the LM controller runs in the tail of the evaluation launch (last-arriving
     workgroup).  Must give the same solve for any grid (more or fewer workgroups than CUs, i.e.
     any arrival order / placement), and be bitwise repeatable — a stale or torn inter-workgroup
-    hand-off would show up as run-to-run differences."""
+    hand-off would show up as run-to-run differences.  The path lives in csrc/clc_legacy.hpp: run with
+    CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_legacy.so (the -DCLC_LEGACY_PATHS build)."""
+    if not (_capi.lib().clc_debug_build_features() & 1):
+        pytest.skip("default build: the ticket-fused launch is compiled only with -DCLC_LEGACY_PATHS (libclc_hip_legacy.so)")
     S = sd.sim_fixed_count(77, 400, 500, noise_sigma=0.01)
     rec = clc.flatten_observations(S, False)
     sv.upload(rec)
