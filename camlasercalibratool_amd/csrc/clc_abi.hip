@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/clc.h"
@@ -316,6 +317,24 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
   hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, NT, BT, WG>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy, \
                      reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl,       \
                      h->d_partials, pose_arg, use_pose_arg)
+#ifdef CLC_EVAL_VARIANTS
+    // Occupancy experiment of profiles/r03_occupancy.md (scripts/r03_occupancy.py; -DCLC_EVAL_VARIANTS build only):
+    // CLC_EVAL_VARIANT = 768x4: 768-thread workgroups = 3 waves/SIMD with 4 rows in flight per wave; 512x4: 2 waves/SIMD, 4 rows
+    static const int variant = [] {
+      const char* e = std::getenv("CLC_EVAL_VARIANT");
+      return !e ? 0 : (std::strcmp(e, "768x4") == 0 ? 1 : (std::strcmp(e, "512x4") == 0 ? 2 : 0));
+    }();
+    if (variant == 1) {
+      if (rnt) hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, true, 768, true, 4>), dim3(grid), dim3(768), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
+      else hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, false, 768, true, 4>), dim3(grid), dim3(768), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
+      return;
+    }
+    if (variant == 2) {
+      if (rnt) hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, true, 512, true, 4>), dim3(grid), dim3(512), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
+      else hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, false, 512, true, 4>), dim3(grid), dim3(512), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
+      return;
+    }
+#endif
     if (big) {
       if (eq) ensure_wave_split(h, grid);
       if (eq) { if (rnt) CLC_LAUNCH_R(true, 512, false); else CLC_LAUNCH_R(false, 512, false); }

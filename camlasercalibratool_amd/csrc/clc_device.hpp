@@ -343,13 +343,19 @@ __device__ __forceinline__ WaveRun wave_run(const RowDesc* __restrict__ desc, lo
   r.end = sp[1];
   return r;
 }
+// (A smaller share for wave 0 — which in the step kernel reaches its rows 0.5-0.8 us late, behind the controller's write-back —
+// was measured and rejected: with scans of a whole number of rows the boundaries snap to scan starts, so unequal nominal
+// shares turn into one wave with two scans next to waves with one: 8.7 -> 9.7-10.0 us per step launch at C2 for any share
+// between 5:6 and 0:6, no change at 2.5e5 observations or with 32-row scans; scripts/r03_wave0_share.py, profiles/r03_wave0_share.md.)
 __global__ void wave_split_kernel(const RowDesc* __restrict__ desc, const int n_rows, const int n_blocks, int* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, total = n_blocks * 8 + 1;
   if (t >= total) return;
   if (t == total - 1) { out[t] = n_rows; return; }
   const WaveMap m = make_wave_map<512, false>(t >> 3, n_blocks, t & 7);
   const int nominal = (int)m.begin(n_rows);
-  const int window = ((n_rows / n_blocks) / 8 + 1) / 2;  // <= the smallest share: nearest-start maps of ordered points stay ordered
+  // Boundaries move to the nearest scan start within half a share.  "Nearest start within a fixed window, else stay" is a
+  // monotone map of the ordered nominal boundaries, so the table stays a partition (a share may come out empty).
+  const int window = ((n_rows / n_blocks) / 8 + 1) / 2;
   int best = nominal;
   if (nominal > 0 && nominal < n_rows) {
     for (int j = 0; j <= window; ++j) {

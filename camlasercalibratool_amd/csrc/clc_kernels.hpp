@@ -20,7 +20,7 @@
 namespace clc {
 
 // K1 on the row layout: same contract as eval_kernel (one 28-double partial per workgroup).
-template <bool WITH_LOSS, bool NT, int BT, bool WEIGHTED>
+template <bool WITH_LOSS, bool NT, int BT, bool WEIGHTED, int DEPTH = ROWS_DEPTH>
 __global__ __launch_bounds__(BT) void eval_rows_kernel(const double* __restrict__ xy, const RowDesc* __restrict__ desc,
                                                        const long long n_rows, const double* __restrict__ pose,
                                                        const int32_t* __restrict__ status, const double lf,
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(BT) void eval_rows_kernel(const double* __restrict_
     r0 = wm.begin(n_rows);
     r1 = wm.end(n_rows);
   }
-  if (!stream_rows<WITH_LOSS, NT>(xy, desc, r0, r1, lane, get_pose, inv_lf2, acc)) return;
+  if (!stream_rows<WITH_LOSS, NT, DEPTH>(xy, desc, r0, r1, lane, get_pose, inv_lf2, acc)) return;
   block_reduce_store<BT / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 

@@ -155,48 +155,6 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
   return *p;
 }
 
-// Point arithmetic of the resident kernel: rows_point (clc_rows.hpp) with what only costs issue slots taken out —
-//   * the Cauchy weight 1 / (1 + r0^2/lf^2) from the v_rcp_f64 seed and ONE Newton step (CLC_RES_NEWTON; the seed is good
-//     to ~2^-27, scripts/probes/rcp_probe.hip, so one step leaves < 1 ulp + 2^-54; the row kernels take two);
-//   * the running product of (1 + r0^2/lf^2) is renormalised (mantissa, exponent) every second point instead of every
-//     point: a mantissa in [0.5, 1) times two factors below 2^511 each cannot overflow, so this is exact up to
-//     |r0| ~ 1e76 lf — beyond that the cost is +inf and the solve fails like a non-finite evaluation;
-//   * no max(DBL_MIN, .) on the weight (Ceres' rho' clamp, which only acts when 1 + r0^2/lf^2 > 4.5e307).
-#ifndef CLC_RES_NEWTON
-#define CLC_RES_NEWTON 1
-#endif
-template <bool WITH_LOSS, bool RENORM>
-__device__ __forceinline__ void res_point(const RowPlane& q, const double inv_lf2, const double x, const double y, RowMoments& M) {
-  const double r0 = fma(q.my, y, fma(q.mx, x, q.c0));
-  double w = 1.0;
-  if (WITH_LOSS) {
-    const double sum = fma(r0 * r0, inv_lf2, 1.0);
-    double r = __builtin_amdgcn_rcp(sum);
-#pragma unroll
-    for (int it = 0; it < CLC_RES_NEWTON; ++it) r = fma(r, fma(-sum, r, 1.0), r);
-    w = r;
-    const double pr = M.prod * sum;
-    if (RENORM) {
-      M.expo += __builtin_amdgcn_frexp_exp(pr);
-      M.prod = __builtin_amdgcn_frexp_mant(pr);
-    } else {
-      M.prod = pr;
-    }
-  } else {
-    M.prod = fma(r0, r0, M.prod);
-  }
-  const double wx = w * x, wy = w * y, wr = w * r0;
-  M.S0 += w;
-  M.Sx += wx;
-  M.Sy += wy;
-  M.Sxx = fma(wx, x, M.Sxx);
-  M.Sxy = fma(wx, y, M.Sxy);
-  M.Syy = fma(wy, y, M.Syy);
-  M.T0 += wr;
-  M.Tx = fma(wr, x, M.Tx);
-  M.Ty = fma(wr, y, M.Ty);
-}
-
 // The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
 // uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read).
 template <bool WITH_LOSS, bool NT, int NW, int PR, int PL>
@@ -332,12 +290,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
               if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + tid];
           }
           const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
-          if (j == j0) res_point<WITH_LOSS, false>(q, inv_lf2, v[0], v[1], M);
-          else res_point<WITH_LOSS, true>(q, inv_lf2, v[0], v[1], M);
-        }
-        if (j0 + 1 >= NP && WITH_LOSS) {  // a last single point: renormalise here
-          M.expo += __builtin_amdgcn_frexp_exp(M.prod);
-          M.prod = __builtin_amdgcn_frexp_mant(M.prod);
+          rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M, /*renorm=*/j != j0);  // (rows_flush normalises a last single point)
         }
       }
     }

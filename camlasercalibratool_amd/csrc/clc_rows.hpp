@@ -15,7 +15,7 @@
 // The robust cost 1/2 sum rho = lf^2/2 sum s^2 log(1 + r0^2/lf^2) needs no logarithm per point either: the lane keeps
 // the running PRODUCT of (1 + r0^2/lf^2) as (mantissa, exponent) — one multiply and a frexp per point — and takes one
 // logarithm per segment.
-// Per point: ~26 FP64 instructions instead of ~100; per streamed byte: 16 B (x, y) instead of 28 (x, y, z, group id).
+// Per point: ~21 FP64 instructions instead of ~100; per streamed byte: 16 B (x, y) instead of 28 (x, y, z, group id).
 //
 // Written for device code and for the host-side unit shim (tests/shim/rows_shim.cpp, g++): same source, the device-only
 // intrinsics have plain-C fall-backs.
@@ -54,6 +54,19 @@ CLC_HD double rcp_ge1(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
   r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
+// The Cauchy weight 1/x, x = 1 + r0^2/lf^2 >= 1: v_rcp_f64 seed (relative error <= 2^-25, scripts/probes/rcp_probe.hip) + ONE
+// Newton step: <= 10 ulp (1e-15 relative), two FP64 instructions less per point than rcp_ge1.  The weights only enter the
+// normal equation (H, g: reduction tolerance 1e-11); the cost comes from the exact running product, not from them.
+CLC_HD double rcp_ge1_weight(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
   r = fma(r, fma(-x, r, 1.0), r);
   return r;
 #else
@@ -111,16 +124,27 @@ CLC_HD void rows_moments_reset(RowMoments& M) {
 }
 
 // One scan point (x, y, 0).
+// renorm (WITH_LOSS): bring the running product back to (mantissa in [0.5, 1), exponent) after this point.  Callers do so
+// on every SECOND point of a lane: a mantissa below 1 times two factors cannot overflow while each factor 1 + r0^2/lf^2 is
+// below 2^511 (|r0| < 1e76 lf) — beyond that the cost is +inf and the solve fails like any non-finite evaluation — and
+// rows_flush normalises whatever is left.  One multiply + 1 (instead of 3) instructions per point for the robust cost.
+// The weight is rho'(s) = 1 / (1 + r0^2/lf^2) without Ceres' max(DBL_MIN, .) clamp, which only acts beyond 4.5e307.
 template <bool WITH_LOSS>
-CLC_HD void rows_point(const RowPlane& q, const double inv_lf2, const double x, const double y, RowMoments& M) {
+CLC_HD void rows_point(const RowPlane& q, const double inv_lf2, const double x, const double y, RowMoments& M,
+                       const bool renorm = true) {
   const double r0 = fma(q.my, y, fma(q.mx, x, q.c0));
   double w = 1.0;
   if (WITH_LOSS) {
     const double sum = fma(r0 * r0, inv_lf2, 1.0);
-    w = fmax(2.2250738585072014e-308, rcp_ge1(sum));
-    int e;
-    M.prod = frexp_pos(M.prod * sum, e);  // mantissa in [0.5,1) times a finite sum >= 1: cannot overflow
-    M.expo += e;
+    w = rcp_ge1_weight(sum);
+    const double pr = M.prod * sum;
+    if (renorm) {
+      int e;
+      M.prod = frexp_pos(pr, e);
+      M.expo += e;
+    } else {
+      M.prod = pr;
+    }
   } else {
     M.prod = fma(r0, r0, M.prod);
   }
@@ -183,9 +207,11 @@ CLC_HD void rows_flush(const RowPlane& q, const RowMoments& M, double* acc) {
   acc[25] = fma(-mz, Tx, acc[25]);
   acc[26] = fma(my, Tx, fma(-mx, Ty, acc[26]));
   // cost
-  if (WITH_LOSS)
-    acc[27] = fma(s2, log_mant_exp(M.prod, M.expo), acc[27]);
-  else
+  if (WITH_LOSS) {
+    int e;
+    const double m = frexp_pos(M.prod, e);  // (the last point of the segment may have left the product un-normalised)
+    acc[27] = fma(s2, log_mant_exp(m, M.expo + e), acc[27]);
+  } else
     acc[27] = fma(s2, M.prod, acc[27]);
 }
 

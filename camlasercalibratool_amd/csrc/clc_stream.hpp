@@ -328,7 +328,7 @@ struct LmRows {
     rows_plane_setup(P.R, P.t, nx, ny, nz, d, s, q);
     rows_moments_reset<WITH_LOSS>(M);
   }
-  __device__ __forceinline__ void point(double x, double y) { rows_point<WITH_LOSS>(q, inv_lf2, x, y, M); }
+  __device__ __forceinline__ void point(double x, double y, bool renorm) { rows_point<WITH_LOSS>(q, inv_lf2, x, y, M, renorm); }
   __device__ __forceinline__ void flush(double (&acc)[NACC]) { rows_flush<WITH_LOSS>(q, M, acc); }
 };
 
@@ -346,7 +346,7 @@ struct Normal9Rows {
     nx = nx_; ny = ny_; nz = nz_; md = -d;
     sxx = sxy = sx = syy = sy = s1 = 0.0;
   }
-  __device__ __forceinline__ void point(double x, double y) {
+  __device__ __forceinline__ void point(double x, double y, bool) {
     sxx = fma(x, x, sxx);
     sxy = fma(x, y, sxy);
     syy = fma(y, y, syy);
@@ -413,7 +413,7 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
         if (r != 0) pol.flush(acc);
         pol.begin_scan(P, readlane_d(dv, 0), readlane_d(dv, 1), readlane_d(dv, 2), readlane_d(dv, 3), readlane_d(dv, 4));
       }
-      if (lane < count) pol.point(v[0], v[1]);
+      if (lane < count) pol.point(v[0], v[1], (u & 1) != 0);  // (the running product is renormalised on every second row)
     }
   }
   if (n > 0) pol.flush(acc);
