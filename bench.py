@@ -170,11 +170,12 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        ss.solve(x0, ordered=False, copy=False)
+        ss.solve(x0, ordered=False, copy=False, inplace=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = ss.solve(x0, ordered=False, copy=False)  # solve this shard + all-gather of all ranks' records
+        # start poses into the handle's pinned buffer, solve this shard in place, all-gather of all ranks' records
+        out = ss.solve(x0, ordered=False, copy=False, inplace=True)
     barrier()
     elapsed = time.perf_counter() - t0
     sms = ss.last_summaries

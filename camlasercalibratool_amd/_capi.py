@@ -31,7 +31,7 @@ EXPORTED = [
     "clc_comm_unique_id", "clc_comm_create", "clc_comm_destroy", "clc_comm_rank", "clc_comm_world",
     "clc_gather_results", "clc_comm_records",
     "clc_store_observations", "clc_select_observations", "clc_upload_batched_device", "clc_line_fit_batched_device",
-    "clc_scan_to_points_device", "clc_pinned_alloc", "clc_pinned_free", "clc_store_generation",
+    "clc_scan_to_points_device", "clc_pinned_alloc", "clc_pinned_free", "clc_store_generation", "clc_batched_host_buffers",
 ]
 
 

@@ -115,6 +115,21 @@ constexpr int kSmallDoubles = 512;  // device + pinned scratch for small transfe
 
 }  // namespace
 
+// Lane layout of clc_resident.hpp: j-major point rows, lane descriptors, row offsets per problem.
+struct ResLayout {
+  double* d_xy = nullptr;
+  size_t xy_cap = 0;
+  double* d_desc = nullptr;  // clc::ResLane [P * lanes]
+  size_t desc_cap = 0;
+  double* d_row = nullptr;   // unsigned int [P + 1]
+  size_t row_cap = 0;
+  int lanes = 0;             // lanes per problem of the built layout (256 / 512)
+  int max_ppl = 0;           // largest points-per-lane over the problems
+  int uni_ppl = -1;          // >= 0: every problem has this many points per lane
+  long long rows = 0;        // j-rows in all
+  bool ok = false;
+};
+
 struct clc_handle {
   DevPool pool;  // temporaries of the entry points (DevBuf)
   int device = 0;
@@ -182,18 +197,13 @@ struct clc_handle {
   long long bn_rows = 0;
   bool brows_ok = false;
   long long* d_prob_row = nullptr;  // [P+1] first row of every problem
-  // resident ("lane") layout of the batched problems (clc_resident.hpp): j-major point rows, lane descriptors, row offsets
-  double* d_bres_xy = nullptr;
-  size_t bres_xy_cap = 0;
-  double* d_bres_desc = nullptr;   // clc::ResLane [P * lanes]
-  size_t bres_desc_cap = 0;
-  double* d_bres_row = nullptr;    // unsigned int [P + 1]
-  size_t bres_row_cap = 0;
-  int bres_lanes = 0;              // lanes per problem of the built layout (256 / 512)
-  int bres_max_ppl = 0;            // largest points-per-lane over the problems
-  int bres_uni_ppl = -1;           // >= 0: every problem has this many points per lane
-  long long bres_rows = 0;         // j-rows in all
-  bool bres_ok = false;
+  // resident ("lane") layouts (clc_resident.hpp): of the batched problems, and of a single problem small enough for one workgroup
+  ResLayout bres, sres;
+  // single-problem resident solve: start pose in / result out through page-locked, device-mapped host memory
+  double* h_spose = nullptr;          // [7] host view
+  double* d_spose = nullptr;          // device view of the same allocation
+  clc_summary* h_ssummary = nullptr;
+  clc_summary* d_ssummary = nullptr;
   long long* d_tile_off = nullptr;
   long long* d_nobs = nullptr;
   // batched poses / summaries live in pinned, device-mapped host memory: the init kernel reads the start poses and the
@@ -431,7 +441,7 @@ struct LayoutTargets {
   double** d_ct; size_t* ct_cap; double** d_gr; size_t* gr_cap; long long* n_groups; bool* compact_ok;
   double** d_rxy; size_t* rxy_cap; double** d_rdesc; size_t* rdesc_cap; long long* n_rows; bool* rows_ok;
   long long** d_prob_row;  // nullptr for the single-problem array
-  bool resident = false;   // batched uploads: also build the on-chip resident ("lane") layout (clc_resident.hpp)
+  ResLayout* res = nullptr;  // also build the on-chip resident ("lane") layout (clc_resident.hpp) into this
 };
 
 // Resident layout limits: what the instantiations of resident_solve_kernel hold per lane (registers + LDS).
@@ -441,13 +451,13 @@ constexpr int kResPR256 = 23, kResPL256 = 19, kResPR512 = 4, kResPL512 = 18;
 
 // The lane layout of the batched problems (clc_resident.hpp) from the staged records and their scan structure: plan
 // (points per lane of every problem, on the device), offsets (O(P) on the host), lane descriptors + j-major point rows.
-// Leaves h->bres_ok false — and the other batched layouts in charge — when some problem does not fit a workgroup.
-int build_resident(clc_handle* h, const double* d_aos, long long n, size_t P, size_t G, const long long* d_rec_off,
-                   const unsigned int* d_gid, const long long* d_starts) {
-  h->bres_ok = false;
-  h->bres_lanes = 0;
-  h->bres_max_ppl = 0;
-  h->bres_rows = 0;
+// Leaves L.ok false — and the streaming layouts in charge — when some problem does not fit a workgroup.
+int build_resident(clc_handle* h, ResLayout& L, int first_try, const double* d_aos, long long n, size_t P, size_t G,
+                   const long long* d_rec_off, const unsigned int* d_gid, const long long* d_starts) {
+  L.ok = false;
+  L.lanes = 0;
+  L.max_ppl = 0;
+  L.rows = 0;
   if ((h->launch_flags & clc::FLAG_NO_RESIDENT) != 0) return CLC_OK;
   const int threads = 256;
   DevBuf<unsigned int> bppl(&h->pool), bfail(&h->pool);
@@ -455,7 +465,6 @@ int build_resident(clc_handle* h, const double* d_aos, long long n, size_t P, si
   CLC_HIP(bfail.alloc(1));
   std::vector<unsigned int> ppl(P);
   int lanes = 0;
-  const int first_try = (h->launch_flags & clc::FLAG_RESIDENT_WG512) != 0 ? 512 : 256;
   for (int nl = first_try; nl <= 512 && lanes == 0; nl *= 2) {
     unsigned int failed = 0;
     CLC_HIP(hipMemsetAsync(bfail.p, 0, sizeof(unsigned int), h->stream));
@@ -480,30 +489,30 @@ int build_resident(clc_handle* h, const double* d_aos, long long n, size_t P, si
   }
   if (total >= 0xFFFFFFF0ull) return CLC_OK;
   row[P] = (unsigned int)total;
-  int rc = ensure_bytes(&h->d_bres_row, &h->bres_row_cap, (P + 1) * sizeof(unsigned int));
+  int rc = ensure_bytes(&L.d_row, &L.row_cap, (P + 1) * sizeof(unsigned int));
   if (rc != CLC_OK) return rc;
-  rc = ensure_bytes(&h->d_bres_desc, &h->bres_desc_cap, P * (size_t)lanes * sizeof(clc::ResLane));
+  rc = ensure_bytes(&L.d_desc, &L.desc_cap, P * (size_t)lanes * sizeof(clc::ResLane));
   if (rc != CLC_OK) return rc;
   // one padding row: the kernel's loads run unconditionally from clamped row indices (an empty last problem reads it)
-  rc = ensure_bytes(&h->d_bres_xy, &h->bres_xy_cap, ((size_t)total + 1) * (size_t)lanes * 2 * sizeof(double));
+  rc = ensure_bytes(&L.d_xy, &L.xy_cap, ((size_t)total + 1) * (size_t)lanes * 2 * sizeof(double));
   if (rc != CLC_OK) return rc;
-  CLC_HIP(hipMemcpyAsync(h->d_bres_row, row.data(), (P + 1) * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
-  CLC_HIP(hipMemsetAsync(h->d_bres_xy + (size_t)total * (size_t)lanes * 2, 0, (size_t)lanes * 2 * sizeof(double), h->stream));
-  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->d_bres_row);
-  clc::ResLane* d_desc = reinterpret_cast<clc::ResLane*>(h->d_bres_desc);
+  CLC_HIP(hipMemcpyAsync(L.d_row, row.data(), (P + 1) * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemsetAsync(L.d_xy + (size_t)total * (size_t)lanes * 2, 0, (size_t)lanes * 2 * sizeof(double), h->stream));
+  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(L.d_row);
+  clc::ResLane* d_desc = reinterpret_cast<clc::ResLane*>(L.d_desc);
   if (lanes == 256)
     hipLaunchKernelGGL((clc::res_build_kernel<256>), dim3((unsigned)P), dim3(256), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
-                       (long long)G, d_row, d_desc, h->d_bres_xy);
+                       (long long)G, d_row, d_desc, L.d_xy);
   else
     hipLaunchKernelGGL((clc::res_build_kernel<512>), dim3((unsigned)P), dim3(512), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
-                       (long long)G, d_row, d_desc, h->d_bres_xy);
+                       (long long)G, d_row, d_desc, L.d_xy);
   CLC_HIP(hipGetLastError());
   CLC_HIP(hipStreamSynchronize(h->stream));  // `row` is a host temporary
-  h->bres_lanes = lanes;
-  h->bres_max_ppl = (int)max_ppl;
-  h->bres_uni_ppl = uniform && P > 0 ? (int)ppl[0] : -1;
-  h->bres_rows = (long long)total;
-  h->bres_ok = true;
+  L.lanes = lanes;
+  L.max_ppl = (int)max_ppl;
+  L.uni_ppl = uniform && P > 0 ? (int)ppl[0] : -1;
+  L.rows = (long long)total;
+  L.ok = true;
   return CLC_OK;
 }
 
@@ -603,9 +612,14 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
                          h->stream, broff.p, bgid.p, brbeg.p, (long long)P, n, R, *T.d_prob_row);
     CLC_HIP(hipGetLastError());
   }
-  if (T.resident && !any_z) {
-    rc = build_resident(h, d_aos, n, P, G, broff.p, bgid.p, bstarts.p);
-    if (rc != CLC_OK) return rc;
+  if (T.res != nullptr) {
+    T.res->ok = false;
+    if (!any_z) {
+      // batches: 256 lanes (two problems per CU) unless flag 8192; a single problem: 512 lanes (it has its CU to itself)
+      const int first_try = (T.d_prob_row == nullptr || (h->launch_flags & clc::FLAG_RESIDENT_WG512) != 0) ? 512 : 256;
+      rc = build_resident(h, *T.res, first_try, d_aos, n, P, G, broff.p, bgid.p, bstarts.p);
+      if (rc != CLC_OK) return rc;
+    }
   }
   CLC_HIP(hipStreamSynchronize(h->stream));  // the temporaries above are freed on return
   *T.n_groups = (long long)G;
@@ -678,9 +692,9 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
     bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && h->batch_max_rows <= 1024;
   }
   // Problems that fit a workgroup's registers + LDS are read from HBM once and solved on chip (clc_resident.hpp).
-  bl->resident = h->bres_ok && (h->launch_flags & (clc::FLAG_NO_RESIDENT | clc::FLAG_BATCHED_LOCKSTEP)) == 0;
+  bl->resident = h->bres.ok && (h->launch_flags & (clc::FLAG_NO_RESIDENT | clc::FLAG_BATCHED_LOCKSTEP)) == 0;
   {
-    const size_t res_bytes = (size_t)h->bres_rows * (size_t)h->bres_lanes * 2 * sizeof(double);
+    const size_t res_bytes = (size_t)h->bres.rows * (size_t)h->bres.lanes * 2 * sizeof(double);
     bl->res_nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 || (h->launch_auto && res_bytes > kInfinityCacheBytes + kInfinityCacheBytes / 2);
   }
   return CLC_OK;
@@ -783,6 +797,11 @@ int clc_create(clc_handle** out, int device) {
   CLC_HIP(hipHostMalloc(&h->h_mailbox, sizeof(clc::HostMailbox), hipHostMallocCoherent | hipHostMallocMapped));
   CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mailbox), h->h_mailbox, 0));
   std::memset(h->h_mailbox, 0, sizeof(clc::HostMailbox));
+  // start pose / outcome of the single-workgroup resident solve (one allocation: 8 doubles of pose, then the summary)
+  CLC_HIP(hipHostMalloc(&h->h_spose, 8 * sizeof(double) + sizeof(clc_summary), hipHostMallocCoherent | hipHostMallocMapped));
+  CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_spose), h->h_spose, 0));
+  h->h_ssummary = reinterpret_cast<clc_summary*>(h->h_spose + 8);
+  h->d_ssummary = reinterpret_cast<clc_summary*>(h->d_spose + 8);
   *out = h;
   return CLC_OK;
 }
@@ -795,12 +814,13 @@ void clc_destroy(clc_handle* h) {
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_block, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
                   h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results,
-                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->d_bres_xy, h->d_bres_desc, h->d_bres_row, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
+                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->bres.d_xy, h->bres.d_desc, h->bres.d_row, h->sres.d_xy, h->sres.d_desc, h->sres.d_row, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->pool.clear();
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_mailbox) (void)hipHostFree(h->h_mailbox);
+  if (h->h_spose) (void)hipHostFree(h->h_spose);
   if (h->h_poses) (void)hipHostFree(h->h_poses);
   if (h->h_summaries) (void)hipHostFree(h->h_summaries);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -856,6 +876,7 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
   CLC_HIP(hipSetDevice(h->device));
   h->compact_ok = false;
   h->rows_ok = false;
+  h->sres.ok = false;
   h->split_grid = -1;
   int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
   if (rc != CLC_OK) return rc;
@@ -864,7 +885,10 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
   const std::vector<long long> rec_off = {0, (long long)n};
   const std::vector<long long> tile_off = {0, (long long)((n + clc::TILE - 1) / clc::TILE)};
   const LayoutTargets T = {&h->d_ctiles, &h->ctiles_cap_bytes, &h->d_groups, &h->groups_cap_bytes, &h->n_groups, &h->compact_ok,
-                           &h->d_rxy, &h->rxy_cap_bytes, &h->d_rdesc, &h->rdesc_cap_bytes, &h->n_rows, &h->rows_ok, nullptr};
+                           &h->d_rxy, &h->rxy_cap_bytes, &h->d_rdesc, &h->rdesc_cap_bytes, &h->n_rows, &h->rows_ok, nullptr,
+                           // a problem one workgroup can hold (<= 512 lanes x 22 points) also gets the lane layout: clc_solve then runs
+                           // its whole LM loop in ONE single-workgroup launch from registers + LDS (solve_resident_single)
+                           n <= (size_t)512 * (kResPR512 + kResPL512) ? &h->sres : nullptr};
   return build_layouts(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, T);
 }
 
@@ -1205,6 +1229,46 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
   return CLC_OK;
 }
 
+// A problem that fits ONE workgroup (<= 512 lanes x 22 points; the lane layout was built at upload): the whole LM solve in a
+// single launch of resident_solve_kernel<8 waves> — points read from HBM once into registers + LDS, every pass, reduction and
+// controller step on chip, no kernel boundary and no partial rows between LM iterations.  This is the reference's own problem
+// size (main/calibr_simulation.cpp: 50 poses x ~114 points; main/calibr_offline.cpp: O(10^2) poses): 4.3 us per LM
+// iteration instead of the 7.1 us of the 256-workgroup step chain, which at this size is all launch boundary, row
+// exchange and controller.  One CU works, 255 idle — the problem has 5.7e3 points.
+int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7], clc_summary* summary, clc_iteration* trace,
+                          int trace_cap, std::chrono::steady_clock::time_point t0) {
+  const bool want_trace = trace != nullptr && trace_cap > 0;
+  if (want_trace) {
+    const int rc = ensure_trace(h, opt.max_num_iterations + 8);
+    if (rc != CLC_OK) return rc;
+  }
+  for (int i = 0; i < 7; ++i) h->h_spose[i] = pose[i];
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->sres.d_row);
+  const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->sres.d_desc);
+  clc_iteration* d_trace = want_trace ? h->d_trace : nullptr;
+  const int d_cap = want_trace ? h->trace_cap : 0;
+  if (opt.use_loss)
+    hipLaunchKernelGGL((clc::resident_solve_kernel<true, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
+                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small);
+  else
+    hipLaunchKernelGGL((clc::resident_solve_kernel<false, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
+                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcome written over PCIe visible
+  *summary = *h->h_ssummary;
+  for (int i = 0; i < 7; ++i) pose[i] = h->h_spose[i];
+  if (want_trace) {
+    const int n = std::min(std::min(summary->num_iterations + 1, trace_cap), h->trace_cap);
+    if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  summary->eval_kernel_ms = 0.0;
+  summary->eval_kernel_launches = 0;
+  summary->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve: non-finite result");
+  return CLC_OK;
+}
+
 }  // namespace
 
 // Profiling hook (not part of include/clc.h): one default clc_solve through the step kernel with HIP events on the
@@ -1247,6 +1311,9 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   CLC_HIP(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
 
+  // a problem one workgroup holds: the whole solve in one single-workgroup launch (default flags only: the explicit flag
+  // sets select the step chain / launch pair the bit-identity tests compare; profile_events = 1 asks for per-pass events)
+  if (h->sres.ok && h->launch_auto && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
@@ -1528,12 +1595,12 @@ int upload_batched_impl(clc_handle* h, const clc_observation* records, bool on_d
   int crc = CLC_OK;
   h->bcompact_ok = false;
   h->brows_ok = false;
-  h->bres_ok = false;
+  h->bres.ok = false;
   h->results_valid = 0;
   if (e == hipSuccess && d_aos) {
     const LayoutTargets T = {&h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups, &h->bgroups_cap_bytes, &h->bn_groups,
                              &h->bcompact_ok, &h->d_brxy, &h->brxy_cap_bytes, &h->d_brdesc, &h->brdesc_cap_bytes, &h->bn_rows,
-                             &h->brows_ok, &h->d_prob_row, true};
+                             &h->brows_ok, &h->d_prob_row, &h->bres};
     crc = build_layouts(h, d_aos, n_total, rel, tile_off, T);
   }
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
@@ -1559,9 +1626,21 @@ int clc_upload_batched_device(clc_handle* h, const clc_observation* records_dev,
 
 size_t clc_num_problems(const clc_handle* h) { return h ? h->n_problems : 0; }
 
+int clc_batched_host_buffers(clc_handle* h, double** poses, clc_summary** summaries) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_batched_host_buffers: NULL handle");
+  if (h->n_problems == 0 || !h->h_poses) return fail(CLC_ERR_NO_DATA, "clc_batched_host_buffers: no problems uploaded");
+  if (poses) *poses = h->h_poses;
+  if (summaries) *summaries = h->h_summaries;
+  return CLC_OK;
+}
+
 int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, clc_summary* summaries) {
   if (!h || !poses || !summaries) return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: bad argument");
   if (!h->d_btiles || h->n_problems == 0) return fail(CLC_ERR_NO_DATA, "clc_solve_batched: no problems uploaded");
+  // the handle's own pinned arrays (clc_batched_host_buffers): solved in place, no staging copies
+  const bool in_place = poses == h->h_poses && summaries == h->h_summaries;
+  if ((poses == h->h_poses) != (summaries == h->h_summaries))
+    return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: pass both of the handle's host buffers or neither");
   clc_options opt;
   if (opt_in) opt = *opt_in; else clc_options_default(&opt);
   if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: max_num_iterations < 0");
@@ -1579,14 +1658,14 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   }
   const int bpp = bl.bpp;
   // (the previous batch ended with a stream synchronisation: nothing still reads or writes the staging buffers)
-  std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
+  if (!in_place) std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
   if (bl.resident) {
     // one workgroup per problem, the problem read from HBM once and kept in registers + LDS for its whole solve
-    const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->d_bres_row);
-    const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->d_bres_desc);
+    const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->bres.d_row);
+    const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->bres.d_desc);
 #define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream,        \
-                     h->d_bres_xy, d_row, d_desc, h->d_bgroups, h->bres_uni_ppl, opt, h->d_poses, h->d_summaries, h->d_results)
+                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, h->d_summaries, h->d_results)
 #define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
   do {                                                                                                                        \
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
@@ -1598,7 +1677,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
       if (rc != CLC_OK) return rc;
       CLC_HIP(hipEventRecord(h->ev[0], h->stream));
     }
-    if (h->bres_lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
+    if (h->bres.lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
     else CLC_LAUNCH_RES_V(8, kResPR512, kResPL512);
 #undef CLC_LAUNCH_RES_V
 #undef CLC_LAUNCH_RES
@@ -1608,8 +1687,10 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     float kernel_ms = 0.0f;
     if (timed) CLC_HIP(hipEventElapsedTime(&kernel_ms, h->ev[0], h->ev[1]));
     h->results_valid = P;
-    std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
-    std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+    if (!in_place) {
+      std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
+      std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+    }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (size_t k = 0; k < P; ++k) {
       summaries[k].solve_ms = ms;
@@ -1629,8 +1710,10 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     CLC_HIP(hipGetLastError());
     CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcomes written over PCIe visible
     h->results_valid = P;
-    std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
-    std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+    if (!in_place) {
+      std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
+      std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+    }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (size_t k = 0; k < P; ++k) summaries[k].solve_ms = ms;
     return CLC_OK;
@@ -1678,8 +1761,10 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   }
   CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcomes written over PCIe visible
   h->results_valid = P;
-  std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
-  std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+  if (!in_place) {
+    std::memcpy(poses, h->h_poses, sizeof(double) * 7 * P);
+    std::memcpy(summaries, h->h_summaries, sizeof(clc_summary) * P);
+  }
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (size_t k = 0; k < P; ++k) {
     summaries[k].solve_ms = ms;
@@ -2120,10 +2205,19 @@ int clc_debug_wave_split(clc_handle* h, int grid, int* split, int* first) {
 // Resident-layout report of the batch: built[0/1], lanes per problem, largest points-per-lane, j-rows in all.
 int clc_debug_resident(clc_handle* h, int* ok, int* lanes, int* max_ppl, long long* rows) {
   if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_resident: NULL handle");
-  if (ok) *ok = h->bres_ok ? 1 : 0;
-  if (lanes) *lanes = h->bres_lanes;
-  if (max_ppl) *max_ppl = h->bres_max_ppl;
-  if (rows) *rows = h->bres_rows;
+  if (ok) *ok = h->bres.ok ? 1 : 0;
+  if (lanes) *lanes = h->bres.lanes;
+  if (max_ppl) *max_ppl = h->bres.max_ppl;
+  if (rows) *rows = h->bres.rows;
+  return CLC_OK;
+}
+
+// The same for the single-problem array (built for problems one workgroup can hold; clc_solve then runs in one launch).
+int clc_debug_resident_single(clc_handle* h, int* ok, int* lanes, int* max_ppl) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_resident_single: NULL handle");
+  if (ok) *ok = h->sres.ok ? 1 : 0;
+  if (lanes) *lanes = h->sres.lanes;
+  if (max_ppl) *max_ppl = h->sres.max_ppl;
   return CLC_OK;
 }
 

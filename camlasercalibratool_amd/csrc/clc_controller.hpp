@@ -118,7 +118,7 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
 // the first batch of LDS reads to the write-back).  LEAN stores what is final as soon as it is known — the state's home
 // is LDS anyway —, parks the scaled system in `park` and reads x, the scales, the gradient and the scaled system back
 // right before the model cost change and the two Plus that need them: three more LDS round trips (~300 cycles of a
-// controller that overlaps the co-resident problem's streaming there), ~60 VGPRs less.  No trace in this mode.
+// controller that overlaps the co-resident problem's streaming there), ~60 VGPRs less.
 template <bool FIRST, bool LEAN = false>
 __device__ __forceinline__ void lm_advance_wave(LmState& s, const clc_options& o, clc_iteration* __restrict__ trace,
                                                 const int trace_cap, const double* tot, double* park, const int lane,

@@ -157,11 +157,12 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
 
 // The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
 // uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read).
+// trace (nullable; single-problem launches only): the iteration records of clc_solve.
 template <bool WITH_LOSS, bool NT, int NW, int PR, int PL>
 __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
-    const double* __restrict__ groups, const int uni_ppl, const clc_options opt, double* __restrict__ poses,
-    clc_summary* __restrict__ summaries, double* __restrict__ results) {
+    const double* __restrict__ groups, const int uni_ppl, const clc_options opt, clc_iteration* __restrict__ trace,
+    const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results) {
   constexpr int NL = NW * 64;
   constexpr int NP = PR + PL;  // points a lane can hold
   constexpr int CH = 6;        // LDS points are read in chunks of CH, one chunk ahead of the arithmetic
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     __builtin_amdgcn_s_setprio(3);  // the serial controller wins the issue arbitration against the co-resident problem's streaming wave
     int lane_c = lane;
     asm volatile("" : "+v"(lane_c));  // (opaque: the controller's per-lane LDS addresses are recomputed here, not hoisted out of the pass loop and spilled)
-    lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane_c);  // contains the barrier ...
+    lm_advance_wave<true, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane_c);  // contains the barrier ...
     __builtin_amdgcn_s_setprio(0);
   } else {
     __syncthreads();  // ... the other waves meet here
@@ -370,11 +371,11 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
       __builtin_amdgcn_s_setprio(3);
       int lane_c = lane;
       asm volatile("" : "+v"(lane_c));
-      lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane_c);
+      lm_advance_wave<false, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane_c);
       __builtin_amdgcn_s_setprio(0);
 #else
-      if (k < 0) lm_advance_wave<true, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
-      else lm_advance_wave<false, true>(st, opt, nullptr, 0, sh_tot, sh_park, lane);
+      if (k < 0) lm_advance_wave<true, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane);
+      else lm_advance_wave<false, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane);
 #endif
     } else {
       __syncthreads();

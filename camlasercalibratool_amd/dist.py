@@ -132,12 +132,19 @@ class ShardSolver:
         assert len(offsets) - 1 == self.hi - self.lo, "upload() takes exactly this rank's shard"
         self.solver.upload_batched(records, offsets)
 
-    def solve(self, poses0: np.ndarray, options=None, ordered: bool = True, copy: bool = True) -> np.ndarray:
+    def solve(self, poses0: np.ndarray, options=None, ordered: bool = True, copy: bool = True, inplace: bool = False) -> np.ndarray:
         """clc_solve_batched on the shard + clc_gather_results: [n_problems, 12] on every rank (ordered=False:
-        the raw rank-major [world * cap, 12] buffer, padding records with global index -1 included)."""
+        the raw rank-major [world * cap, 12] buffer, padding records with global index -1 included).
+        inplace=True: the start poses are written into the handle's own pinned buffer and solved there
+        (clc_batched_host_buffers): last_poses / last_summaries are then views that the next solve overwrites."""
         self.last_poses, self.last_summaries = None, None
         if self.hi > self.lo:
-            self.last_poses, self.last_summaries = self.solver.solve_batched(poses0, options)
+            if inplace:
+                pb, _ = self.solver.batched_buffers()
+                pb[:] = np.asarray(poses0, dtype=np.float64).reshape(pb.shape)
+                self.last_poses, self.last_summaries = self.solver.solve_batched_inplace(options)
+            else:
+                self.last_poses, self.last_summaries = self.solver.solve_batched(poses0, options)
         if self.comm is None:
             local = pack_records(self.last_poses, self.last_summaries, self.lo) if self.hi > self.lo else np.zeros((0, RECORD))
             return gather_result_records(local, self.n_problems, ordered=ordered)

@@ -252,6 +252,25 @@ class Solver:
     def num_problems(self) -> int:
         return int(self._L.clc_num_problems(self._h))
 
+    def batched_buffers(self):
+        """The handle's own pinned host arrays of the uploaded batch -> (poses [P,7] float64 view, summaries: ctypes array
+        view of P Summary records).  Fill `poses` with the start poses and call solve_batched_inplace(): no staging copies."""
+        P = self.num_problems
+        pp, ps = C.POINTER(C.c_double)(), C.POINTER(Summary)()
+        check(self._L.clc_batched_host_buffers(self._h, C.byref(pp), C.byref(ps)), "clc_batched_host_buffers")
+        poses = np.ctypeslib.as_array(pp, shape=(P, 7))
+        sms = C.cast(ps, C.POINTER(Summary * P)).contents
+        return poses, sms
+
+    def solve_batched_inplace(self, options: Optional[Options] = None):
+        """clc_solve_batched on the handle's own buffers (batched_buffers()): start poses in, results out, in place."""
+        P = self.num_problems
+        pp, ps = C.POINTER(C.c_double)(), C.POINTER(Summary)()
+        check(self._L.clc_batched_host_buffers(self._h, C.byref(pp), C.byref(ps)), "clc_batched_host_buffers")
+        o = options or default_options()
+        check(self._L.clc_solve_batched(self._h, C.byref(o), pp, ps), "clc_solve_batched")
+        return np.ctypeslib.as_array(pp, shape=(P, 7)), C.cast(ps, C.POINTER(Summary * P)).contents
+
     def solve_batched(self, poses0: np.ndarray, options: Optional[Options] = None):
         """-> (poses[P,7], summaries[P])"""
         P = self.num_problems
@@ -322,6 +341,13 @@ class Solver:
         ok, lanes, ppl, rows = C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
         check(self._L.clc_debug_resident(self._h, C.byref(ok), C.byref(lanes), C.byref(ppl), C.byref(rows)), "clc_debug_resident")
         return bool(ok.value), lanes.value, ppl.value, rows.value
+
+    def debug_resident_single(self):
+        """Lane layout of the single-problem array -> (built, lanes, points per lane); built = clc_solve with the default
+        flags runs the whole LM solve in ONE single-workgroup launch (problems of at most 512 x 22 points)."""
+        ok, lanes, ppl = C.c_int(), C.c_int(), C.c_int()
+        check(self._L.clc_debug_resident_single(self._h, C.byref(ok), C.byref(lanes), C.byref(ppl)), "clc_debug_resident_single")
+        return bool(ok.value), lanes.value, ppl.value
 
     def debug_wave_split(self, grid: int):
         """Wave split table of the row layout for `grid` workgroups -> (split[grid * 8 + 1], first[n_rows])."""

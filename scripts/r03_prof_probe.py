@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Small profiling targets (one per invocation) to run under rocprofv3 with a timeout:
+   resident P      batched solve of P problems x 1e4 observations on the resident kernel (5 solves) and on the round-2 path (5 solves)
+   step N          5 clc_solve of an N-observation problem through the step-kernel chain
+   eval N          20 launches of the row-layout evaluation kernel on N observations + 20 of the 64-byte-tile kernel (PMC calibration)"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import camlasercalibratool_amd as clc
+from camlasercalibratool_amd import simdata as sd
+what, n = sys.argv[1], int(sys.argv[2])
+sv = clc.Solver(0)
+x0 = sd.pose7_from_T(np.eye(4))
+BASE = 2 | 16 | 32 | 128 | 256 | 512
+out = {"what": what, "n": n}
+if what == "resident":
+    rec, off, xb, gt = sd.sim_shard_records(65536, 0, n, 20, 500, 0.01)
+    sv.upload_batched(rec, off)
+    ok, lanes, ppl, rows = sv.debug_resident()
+    _, _, _, bn_rows = sv.debug_rows()
+    out.update(resident=ok, lanes=lanes, ppl=ppl, lane_layout_bytes=rows * lanes * 16 + n * lanes * 8, row_layout_bytes=bn_rows * (64 * 16 + 64))
+    for name, fl in (("resident", -1), ("round2", BASE | 4096)):
+        sv.set_launch(0, fl)
+        sv.pose_plus(x0[None, :], np.zeros((1, 6)))  # marker
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter(); p, s = sv.solve_batched(xb); ts.append(time.perf_counter() - t)
+        out[name + "_ms"] = 1e3 * float(np.median(ts))
+        out["passes_total"] = int(sum(q.num_evaluations for q in s))
+    sv.pose_plus(x0[None, :], np.zeros((1, 6)))
+elif what == "step":
+    rec = clc.flatten_observations(sd.sim_fixed_count(1000, n // 500, 500, noise_sigma=0.01), False)
+    sv.set_launch(0, BASE)
+    sv.upload(rec)
+    for _ in range(5):
+        r = sv.solve(x0, trace_cap=0)
+    out.update(passes=int(r.summary.num_evaluations), solve_ms=r.summary.solve_ms)
+else:
+    rec = clc.flatten_observations(sd.sim_fixed_count(1000, 2000, 500, noise_sigma=0.01), False)
+    reps = max(1, n // rec.shape[0])
+    big = np.ascontiguousarray(np.tile(rec, (reps, 1)))
+    sv.upload(big)
+    _, n_rows, _, _ = sv.debug_rows()
+    out.update(observations=int(big.shape[0]), row_layout_bytes=n_rows * (64 * 16 + 64))
+    sv.pose_plus(x0[None, :], np.zeros((1, 6)))
+    out["rows_us"] = 1e3 * sv.time_eval(x0, reps=20)
+    sv.set_launch(0, 6)
+    sv.pose_plus(x0[None, :], np.zeros((1, 6)))
+    out["tiled64_us"] = 1e3 * sv.time_eval(x0, reps=20)
+    sv.pose_plus(x0[None, :], np.zeros((1, 6)))
+print(json.dumps(out))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import camlasercalibratool_amd as clc
-from camlasercalibratool_amd import simdata as sd
+from camlasercalibratool_amd import _capi, simdata as sd
 
 pytestmark = pytest.mark.gpu
 
@@ -187,3 +187,87 @@ def test_resident_wide_ragged_batch(sv, oracle_mod):
         assert sr[k].termination == ref.summary.termination and sr[k].num_iterations == ref.summary.num_iterations, k
         if keep[k] >= per // 2:
             assert _dT(pr[k], ref.pose) <= T_TOL and abs(sr[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
+
+
+def test_solve_batched_in_place_on_the_handles_buffers(sv):
+    """clc_batched_host_buffers + clc_solve_batched on exactly those pointers: same results as the copying call, no staging."""
+    rec, off, x0, gt = _batch(31, 40, 10, 120)
+    sv.set_launch(0, -1)
+    sv.upload_batched(rec, off)
+    pa, sa = sv.solve_batched(x0)
+    pb, sb = sv.batched_buffers()
+    assert pb.shape == (40, 7)
+    pb[:] = x0
+    pc, sc = sv.solve_batched_inplace()
+    assert np.array_equal(pc, pa) and pc.ctypes.data == pb.ctypes.data
+    assert [_key(s) for s in sc] == [_key(s) for s in sa] and [s.final_cost for s in sc] == [s.final_cost for s in sa]
+    L = _capi.lib()
+    import ctypes as C
+    bad = (clc.Summary * 40)()
+    assert L.clc_solve_batched(sv._h, None, pb.ctypes.data_as(C.POINTER(C.c_double)), bad) == -1  # one of the two pointers only
+
+
+X0 = sd.pose7_from_T(np.eye(4))
+STEP_CHAIN = BASE  # explicit flags: the 256-workgroup step_kernel chain (what clc_solve runs for problems beyond one workgroup)
+
+
+@pytest.mark.parametrize("seed,noise", [(1, 0.01), (7, 0.03), (3, 0.0)])
+def test_single_problem_resident_solve(sv, oracle_mod, seed, noise):
+    """The reference's own problem size (simulation_lasercamcal_node: 50 poses x ~114 points): clc_solve with the default
+    flags runs the whole LM loop in ONE single-workgroup launch from registers + LDS.  Same decisions and iteration trace as
+    the step-kernel chain (to rounding: another summation order) and as the oracle's DENSE_QR solve."""
+    S = sd.GenerateSimData(seed, noise_sigma=noise)
+    rec = clc.flatten_observations(S, False)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    ok, lanes, ppl = sv.debug_resident_single()
+    assert ok and lanes == 512 and 1 <= ppl <= 22
+    r = sv.solve(X0)
+    sv.set_launch(0, STEP_CHAIN)
+    c = sv.solve(X0)
+    sv.set_launch(0, -1)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    assert _key(r.summary) == _key(c.summary) and r.summary.termination == ref.summary.termination
+    assert r.summary.num_iterations == ref.summary.num_iterations and len(r.trace) == len(c.trace) == len(ref.trace)
+    assert np.abs(r.pose - c.pose).max() <= 1e-9 and abs(r.summary.final_cost - c.summary.final_cost) <= 1e-12 * max(1.0, c.summary.final_cost)
+    assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    for a, b in zip(r.trace, c.trace):
+        assert (a.iteration, a.step_is_valid, a.step_is_successful) == (b.iteration, b.step_is_valid, b.step_is_successful)
+        for f in ("cost", "cost_change", "gradient_max_norm", "step_norm", "relative_decrease", "trust_region_radius"):
+            x, y = getattr(a, f), getattr(b, f)
+            assert abs(x - y) <= 1e-7 * max(abs(y), 1e-12) + 1e-15, (f, a.iteration, x, y)
+    # bitwise repeatable
+    r2 = sv.solve(X0)
+    assert np.array_equal(r.pose, r2.pose) and r.summary.final_cost == r2.summary.final_cost
+
+
+def test_single_problem_resident_options_and_limits(sv, oracle_mod):
+    """Solver options reach the in-kernel controller (no loss, iteration cap); a problem beyond 512 x 22 points, or with
+    p.z != 0, keeps the step chain; profile_events = 1 asks for per-pass events and gets the launch pair."""
+    S = sd.sim_fixed_count(5, 20, 500, noise_sigma=0.01)  # 10 000 points: fits
+    rec = clc.flatten_observations(S, False)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    assert sv.debug_resident_single()[0]
+    for kw in (dict(use_loss=0), dict(max_num_iterations=3), dict(function_tolerance=1e-12)):
+        o, oo = clc.default_options(), oracle_mod.default_options()
+        for k, v in kw.items():
+            setattr(o, k, v)
+            setattr(oo, k, v)
+        r = sv.solve(X0, o)
+        ref = oracle_mod.solve(rec, X0, options=oo, linear_solver="qr")
+        assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations, kw
+        assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL, kw
+    o = clc.default_options()
+    o.profile_events = 1
+    r = sv.solve(X0, o)
+    assert r.summary.eval_kernel_launches == r.summary.num_evaluations and r.summary.eval_kernel_ms > 0
+    S2 = sd.sim_fixed_count(5, 24, 500, noise_sigma=0.01)  # 12 000 points: does not fit one workgroup
+    sv.upload(clc.flatten_observations(S2, False))
+    assert not sv.debug_resident_single()[0]
+    rec[7, 6] = 1e-3
+    sv.upload(rec)
+    assert not sv.debug_resident_single()[0]
+    r = sv.solve(X0)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
