@@ -323,27 +323,37 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
     // 1e6 observations, but 15.4 vs 14.7 at 4e6 and 45.1 vs 42.1 at 1.6e7) — the step kernel is not (its wave 0 starts
     // late anyway): it keeps the equal shares at every size.
     const bool eq = (fl & clc::FLAG_EQUAL_WAVES) != 0 && !(h->launch_auto && h->n_rows > 16LL * 8 * grid);
+    // rows in flight per wave: 8 while the array is served by the Infinity Cache, 12 (206 VGPRs, still 2 waves/SIMD) when it
+    // streams from HBM with non-temporal loads — throughput there tracks the bytes in flight per CU (profiles/r03_occupancy.md:
+    // 4 rows 0.40 of peak, 8 rows 0.81, 12 rows 0.82-0.83, 16 rows 0.81; 3 waves/SIMD cannot hold more than 6 rows each: 0.80)
 #define CLC_LAUNCH_R(NT, BT, WG)                                                                              \
-  hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, NT, BT, WG>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy, \
+  hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, NT, BT, WG, (NT) ? 12 : clc::ROWS_DEPTH>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy, \
                      reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl,       \
                      h->d_partials, pose_arg, use_pose_arg)
 #ifdef CLC_EVAL_VARIANTS
     // Occupancy experiment of profiles/r03_occupancy.md (scripts/r03_occupancy.py; -DCLC_EVAL_VARIANTS build only):
-    // CLC_EVAL_VARIANT = 768x4: 768-thread workgroups = 3 waves/SIMD with 4 rows in flight per wave; 512x4: 2 waves/SIMD, 4 rows
+    // CLC_EVAL_VARIANT = <threads>x<rows in flight per wave>: 768x4, 768x6 (3 waves/SIMD), 512x4, 512x12, 512x16 (2 waves/SIMD)
     static const int variant = [] {
       const char* e = std::getenv("CLC_EVAL_VARIANT");
-      return !e ? 0 : (std::strcmp(e, "768x4") == 0 ? 1 : (std::strcmp(e, "512x4") == 0 ? 2 : 0));
+      const char* names[] = {"768x4", "512x4", "512x12", "512x16", "768x6"};
+      for (int i = 0; e && i < 5; ++i)
+        if (std::strcmp(e, names[i]) == 0) return i + 1;
+      return 0;
     }();
-    if (variant == 1) {
-      if (rnt) hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, true, 768, true, 4>), dim3(grid), dim3(768), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
-      else hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, false, 768, true, 4>), dim3(grid), dim3(768), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
-      return;
-    }
-    if (variant == 2) {
-      if (rnt) hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, true, 512, true, 4>), dim3(grid), dim3(512), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
-      else hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, false, 512, true, 4>), dim3(grid), dim3(512), 0, h->stream, h->d_rxy, reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);
-      return;
-    }
+#define CLC_LAUNCH_VAR(BT, DEPTH)                                                                                                  \
+  do {                                                                                                                             \
+    if (rnt) hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, true, BT, true, DEPTH>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy,  \
+                                reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg); \
+    else hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, false, BT, true, DEPTH>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy,     \
+                            reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg);    \
+    return;                                                                                                                        \
+  } while (0)
+    if (variant == 1) CLC_LAUNCH_VAR(768, 4);
+    if (variant == 2) CLC_LAUNCH_VAR(512, 4);
+    if (variant == 3) CLC_LAUNCH_VAR(512, 12);
+    if (variant == 4) CLC_LAUNCH_VAR(512, 16);
+    if (variant == 5) CLC_LAUNCH_VAR(768, 6);
+#undef CLC_LAUNCH_VAR
 #endif
     if (big) {
       if (eq) ensure_wave_split(h, grid);
@@ -1243,6 +1253,9 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
     if (rc != CLC_OK) return rc;
   }
   for (int i = 0; i < 7; ++i) h->h_spose[i] = pose[i];
+  int32_t* h_done = reinterpret_cast<int32_t*>(h->h_spose + 7);  // completion flag behind the pose (same pinned allocation)
+  int32_t* d_done = reinterpret_cast<int32_t*>(h->d_spose + 7);
+  __atomic_store_n(h_done, 0, __ATOMIC_RELAXED);
   std::atomic_thread_fence(std::memory_order_seq_cst);
   const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->sres.d_row);
   const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->sres.d_desc);
@@ -1250,12 +1263,25 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
   const int d_cap = want_trace ? h->trace_cap : 0;
   if (opt.use_loss)
     hipLaunchKernelGGL((clc::resident_solve_kernel<true, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
-                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small);
+                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done);
   else
     hipLaunchKernelGGL((clc::resident_solve_kernel<false, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
-                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small);
+                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done);
   CLC_HIP(hipGetLastError());
-  CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcome written over PCIe visible
+  // The kernel sets the flag (system-scope release) after the outcome is written: polling it avoids the wake-up latency of a
+  // blocking stream synchronisation (~15 us of a ~120 us solve).  Bounded: a wedged queue falls through to the synchronisation,
+  // which reports the error.
+  {
+    long long spins = 0;
+    const auto t_spin = std::chrono::steady_clock::now();
+    while (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == 0) {
+      if ((++spins & 0xFFFF) == 0) {
+        if (hipStreamQuery(h->stream) != hipErrorNotReady) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 30.0) break;
+      }
+    }
+    if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == 0 || want_trace) CLC_HIP(hipStreamSynchronize(h->stream));
+  }
   *summary = *h->h_ssummary;
   for (int i = 0; i < 7; ++i) pose[i] = h->h_spose[i];
   if (want_trace) {
@@ -1665,7 +1691,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->bres.d_desc);
 #define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream,        \
-                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, h->d_summaries, h->d_results)
+                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, h->d_summaries, h->d_results, nullptr)
 #define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
   do {                                                                                                                        \
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \

@@ -158,11 +158,14 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
 // The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
 // uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read).
 // trace (nullable; single-problem launches only): the iteration records of clc_solve.
+// host_done (nullable; single-problem launches only): set to 1 in host memory, system-scope release, once the outcome is written —
+// the host polls it instead of blocking on the stream.
 template <bool WITH_LOSS, bool NT, int NW, int PR, int PL>
 __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, clc_iteration* __restrict__ trace,
-    const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results) {
+    const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results,
+    int32_t* __restrict__ host_done) {
   constexpr int NL = NW * 64;
   constexpr int NP = PR + PL;  // points a lane can hold
   constexpr int CH = 6;        // LDS points are read in chunks of CH, one chunk ahead of the arithmetic
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     if (lane == 0) {
       if (st.status == CLC_RUNNING) st.status = CLC_FAILURE;  // unreachable: the controller stops at the iteration cap
       batched_write_outcome(st, prob, poses, summaries, results);
+      if (host_done != nullptr) __hip_atomic_store(host_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -233,9 +233,13 @@ def test_single_problem_resident_solve(sv, oracle_mod, seed, noise):
     assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
     for a, b in zip(r.trace, c.trace):
         assert (a.iteration, a.step_is_valid, a.step_is_successful) == (b.iteration, b.step_is_valid, b.step_is_successful)
-        for f in ("cost", "cost_change", "gradient_max_norm", "step_norm", "relative_decrease", "trust_region_radius"):
+        # (the two paths sum in different orders: quantities that are differences of nearly equal numbers — the gradient at
+        # the minimum, the last cost changes and what is derived from them — agree to an absolute, not a relative, tolerance)
+        tol = {"cost": (1e-12, 1e-16), "cost_change": (1e-6, 1e-14), "gradient_max_norm": (1e-7, 1e-12), "step_norm": (1e-6, 1e-14),
+               "relative_decrease": (1e-5, 1e-7), "trust_region_radius": (1e-5, 0.0)}
+        for f, (rt, at) in tol.items():
             x, y = getattr(a, f), getattr(b, f)
-            assert abs(x - y) <= 1e-7 * max(abs(y), 1e-12) + 1e-15, (f, a.iteration, x, y)
+            assert abs(x - y) <= rt * abs(y) + at, (f, a.iteration, x, y)
     # bitwise repeatable
     r2 = sv.solve(X0)
     assert np.array_equal(r.pose, r2.pose) and r.summary.final_cost == r2.summary.final_cost
