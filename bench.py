@@ -437,6 +437,7 @@ def main():
                                     "frac": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "achieved_streamed": streamed / (b2b * 1e-3) / 1e9,
                                     "frac_streamed": streamed / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "frac_moved": streamed / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "timing": "hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)"}}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         roof["achieved_streamed"] = streamed / (step_ms * 1e-3) / 1e9
@@ -456,14 +457,15 @@ def main():
         solver.set_launch(0, -1)
         roof["compact28"] = {"avg_kernel_ms": b2bc, "achieved": BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9,
                              "frac": BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "frac_streamed": COMPACT_BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "frac_streamed": COMPACT_BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "frac_moved": COMPACT_BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS}
         roof["tiled64"] = {"avg_kernel_ms": b2b64, "achieved": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9,
                            "frac": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "note": "64-byte records streamed as stored: achieved == actual HBM rate"}
         roof["note"] = (f"{streamed / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state passes are served on-die, and "
-                        "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 2.5, the LM controller 1.7, reductions 0.7: scripts/r02_stamps.py); "
-                        "`frac` prices the launch at the contract's 64 algorithmic bytes per evaluation, `frac_streamed` at the bytes the "
-                        "layout moves; see roofline_large for a working set beyond the cache")
+                        "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 1.7, the LM controller 2.2, reductions 1.4: scripts/r02_stamps.py); "
+                        "`frac_moved` (= `frac_streamed`) is bytes moved / time / 8 TB/s and is bounded by 1; `frac` prices the launch at the contract's 64 algorithmic bytes per "
+                        "evaluation; see roofline_large for a working set beyond the cache")
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
