@@ -176,6 +176,10 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   __shared__ double sh_wsum[NW][NACC];
   __shared__ double sh_park[32 + (sizeof(LmScratch) + 7) / 8];
   const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the iteration trace exists for the single-problem (8-wave) launches only: in the 4-wave form the controller shares the
+  // register file with 92 VGPRs of points, and the trace record's code must not be there at all
+  clc_iteration* const tr = NW == 8 ? trace : nullptr;
+  const int tr_cap = NW == 8 ? trace_cap : 0;
   // Controller wave: the two workgroups that share a CU (256-thread form) pick waves on DIFFERENT SIMDs — wave 0 for the
   // workgroup whose LDS allocation starts at 0, wave 2 for the other — so that two controllers running at the same time
   // (co-resident problems in phase) do not share one SIMD's issue slots while the other three idle.
@@ -234,9 +238,18 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     if (tid == 0) lm_init(st, opt, sh_park);
   }
   const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
-  // points processed per lane and pass: ppl rounded up to whole pairs (two points per basic block: two independent
+  // points processed per lane and pass: ppl rounded up to whole groups (GRP points per basic block: independent
   // dependency chains for a wave that has its SIMD to itself while the co-resident problem is in its controller)
-  const int ppl_eff = (ppl & 1) != 0 && ppl < NP ? ppl + 1 : ppl;
+#ifndef CLC_RES_GROUP
+#define CLC_RES_GROUP 3
+#endif
+  // Points per basic block (the running product is renormalised on the last point of a group: three factors below 2^341 each
+  // cannot overflow).  Three independent dependency chains per block in the 4-wave form — a wave often has its SIMD to itself
+  // there, while the co-resident problem is in its controller: C4 shard 0.95 -> 0.92 ms against pairs, groups of six 0.91
+  // (scripts/r03_resident.py); pairs in the 8-wave form, which never runs alone on a SIMD (and spills with triples).
+  constexpr int GRP = NW == 4 ? CLC_RES_GROUP : 2;
+  const int ppl_up = (ppl + GRP - 1) / GRP * GRP;
+  const int ppl_eff = ppl_up < NP ? ppl_up : NP;
   __syncthreads();
   RES_STAMP(3, clock64());
 #pragma unroll
@@ -281,10 +294,10 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     RowMoments M;
     rows_moments_reset<WITH_LOSS>(M);
 #pragma unroll
-    for (int j0 = 0; j0 < NP; j0 += 2) {
-      if (j0 < ppl) {  // wave-uniform; both points of the pair in one basic block
+    for (int j0 = 0; j0 < NP; j0 += GRP) {
+      if (j0 < ppl) {  // wave-uniform; the points of a group in one basic block
 #pragma unroll
-        for (int j = j0; j < j0 + 2 && j < NP; ++j) {
+        for (int j = j0; j < j0 + GRP && j < NP; ++j) {
           if (j >= PR && (j - PR) % CH == 0 && (j - PR) / CH + 1 < NCH) {  // entering an LDS chunk: request the next one
             constexpr int dummy = 0;
             (void)dummy;
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
               if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + tid];
           }
           const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
-          rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M, /*renorm=*/j != j0);  // (rows_flush normalises a last single point)
+          rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);  // (rows_flush normalises an incomplete last group)
         }
       }
     }
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     __builtin_amdgcn_s_setprio(3);  // the serial controller wins the issue arbitration against the co-resident problem's streaming wave
     int lane_c = lane;
     asm volatile("" : "+v"(lane_c));  // (opaque: the controller's per-lane LDS addresses are recomputed here, not hoisted out of the pass loop and spilled)
-    lm_advance_wave<true, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane_c);  // contains the barrier ...
+    lm_advance_wave<true, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);  // contains the barrier ...
     __builtin_amdgcn_s_setprio(0);
   } else {
     __syncthreads();  // ... the other waves meet here
@@ -374,11 +387,11 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
       __builtin_amdgcn_s_setprio(3);
       int lane_c = lane;
       asm volatile("" : "+v"(lane_c));
-      lm_advance_wave<false, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane_c);
+      lm_advance_wave<false, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
       __builtin_amdgcn_s_setprio(0);
 #else
-      if (k < 0) lm_advance_wave<true, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane);
-      else lm_advance_wave<false, NW == 4>(st, opt, trace, trace_cap, sh_tot, sh_park, lane);
+      if (k < 0) lm_advance_wave<true, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane);
+      else lm_advance_wave<false, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane);
 #endif
     } else {
       __syncthreads();
