@@ -2339,6 +2339,11 @@ extern "C" int clc_debug_res_stamps(void* dst, size_t bytes) {
   if (hipGetSymbolAddress(&p, HIP_SYMBOL(clc::clc_res_stamp_buf)) != hipSuccess) return CLC_ERR_HIP;
   return hipMemset(p, 0, sizeof(clc::clc_res_stamp_buf)) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
 }
+extern "C" int clc_debug_res_ctrl_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(clc::clc_res_stamp_ctrl)) bytes = sizeof(clc::clc_res_stamp_ctrl);
+  if (hipDeviceSynchronize() != hipSuccess) return CLC_ERR_HIP;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(clc::clc_res_stamp_ctrl), bytes) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
+}
 extern "C" int clc_debug_stamps(void* dst, size_t bytes) {
   if (bytes > sizeof(clc::clc_stamp_buf)) bytes = sizeof(clc::clc_stamp_buf);
   if (hipDeviceSynchronize() != hipSuccess) return CLC_ERR_HIP;

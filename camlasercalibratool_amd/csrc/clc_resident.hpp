@@ -136,6 +136,7 @@ __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict_
 // reduction, after barrier 1, (wave 0) after the totals, after the controller / barrier 2.
 constexpr int RES_STAMP_WGS = 1024, RES_STAMP_PASSES = 8, RES_STAMP_SLOTS = 4 + 6 * RES_STAMP_PASSES;
 __device__ long long clc_res_stamp_buf[RES_STAMP_WGS][2][RES_STAMP_SLOTS];
+__device__ unsigned long long clc_res_stamp_ctrl[RES_STAMP_WGS][16];  // lm_advance_wave's packed phase deltas of a workgroup's last pass
 #ifndef CLC_RES_STAMP_BASE
 #define CLC_RES_STAMP_BASE 0
 #endif
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, clc_iteration* __restrict__ trace,
     const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results,
     int32_t* __restrict__ host_done) {
+  constexpr bool RES_LEAN = NW == 4;  // the controller next to 92 VGPRs of points: the small-footprint form (clc_controller.hpp)
   constexpr int NL = NW * 64;
   constexpr int NP = PR + PL;  // points a lane can hold
   constexpr int CH = 6;        // LDS points are read in chunks of CH, one chunk ahead of the arithmetic
@@ -180,14 +182,10 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   // register file with 92 VGPRs of points, and the trace record's code must not be there at all
   clc_iteration* const tr = NW == 8 ? trace : nullptr;
   const int tr_cap = NW == 8 ? trace_cap : 0;
-  // Controller wave: the two workgroups that share a CU (256-thread form) pick waves on DIFFERENT SIMDs — wave 0 for the
-  // workgroup whose LDS allocation starts at 0, wave 2 for the other — so that two controllers running at the same time
-  // (co-resident problems in phase) do not share one SIMD's issue slots while the other three idle.
-  int cw = 0;
-  if (NW == 4) {
-    const unsigned lds_alloc = __builtin_amdgcn_s_getreg((6 /*HW_REG_LDS_ALLOC*/) | (0 << 6) | ((12 - 1) << 11));  // LDS_BASE field (bits below LDS_SIZE at 12)
-    cw = lds_alloc != 0 ? 2 : 0;
-  }
+  // The controller runs on wave 0.  (Picking wave 0 / wave 2 by the workgroup's LDS allocation base — s_getreg HW_REG_LDS_ALLOC — so
+  // that the two workgroups of a CU never run their controllers on the same SIMD was measured: no gain, and the run-time wave
+  // index cost a live SGPR in a kernel that already spills scalars — a -DCLC_STAMPS build of that form computed wrong steps.)
+  constexpr int cw = 0;
   RES_STAMP(0, wall_clock64());
   RES_STAMP(2, clock64());
   LmState& st = *reinterpret_cast<LmState*>(sh_state);
@@ -366,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     __builtin_amdgcn_s_setprio(3);  // the serial controller wins the issue arbitration against the co-resident problem's streaming wave
     int lane_c = lane;
     asm volatile("" : "+v"(lane_c));  // (opaque: the controller's per-lane LDS addresses are recomputed here, not hoisted out of the pass loop and spilled)
-    lm_advance_wave<true, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);  // contains the barrier ...
+    lm_advance_wave<true, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);  // contains the barrier ...
     __builtin_amdgcn_s_setprio(0);
   } else {
     __syncthreads();  // ... the other waves meet here
@@ -387,7 +385,14 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
       __builtin_amdgcn_s_setprio(3);
       int lane_c = lane;
       asm volatile("" : "+v"(lane_c));
-      lm_advance_wave<false, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
+#if defined(CLC_STAMPS) && !defined(CLC_RES_NO_CROW)
+      // the controller's own phase stamps (CLC_CK in lm_advance_wave: packed 16-bit cycle deltas into words 15 and 6 of the row)
+      unsigned long long* crow = (blockIdx.x >= CLC_RES_STAMP_BASE && blockIdx.x < CLC_RES_STAMP_BASE + RES_STAMP_WGS)
+                                     ? reinterpret_cast<unsigned long long*>(&clc_res_stamp_ctrl[blockIdx.x - CLC_RES_STAMP_BASE][0]) : nullptr;
+      lm_advance_wave<false, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c, crow);
+#else
+      lm_advance_wave<false, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
+#endif
       __builtin_amdgcn_s_setprio(0);
 #else
       if (k < 0) lm_advance_wave<true, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane);

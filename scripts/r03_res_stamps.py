@@ -68,4 +68,12 @@ for p in range(min(NPASS, int(passes.max()))):
     print(f"pass {p} ({int(sel.sum())} wgs) cycles  w0: " + " ".join(f"{x:7.0f}" for x in row[0]) + "   w1: " + " ".join(f"{x:7.0f}" for x in row[1]) +
           f"   | pass total (w1) {tot:.0f}  w0 ctrl end -> next pass start {nxt:.0f}")
 print("columns:", names)
+cb = np.zeros((NWG, 16), dtype=np.uint64)
+L.clc_debug_res_ctrl_stamps.argtypes = [C.c_void_p, C.c_size_t]
+if L.clc_debug_res_ctrl_stamps(cb.ctypes.data, cb.nbytes) == 0:
+    w0, w1 = cb[:n, 15], cb[:n, 6]
+    ok = w0 > 0
+    ph = [((w0[ok] >> np.uint64(16 * i)) & np.uint64(0xFFFF)).astype(float) for i in range(4)] + [((w1[ok] >> np.uint64(16 * i)) & np.uint64(0xFFFF)).astype(float) for i in range(4)]
+    lab = ["loads + acceptance + early stores", "scaling / damping", "Cholesky", "triangular solves", "model cost change", "two Plus + gradient norm", "tests + publish", "(slow path) + barrier"]
+    print("controller phases of a workgroup's last pass (cycles, median): " + "; ".join(f"{l} {np.median(p):.0f}" for l, p in zip(lab, ph)) + f"; sum {sum(np.median(p) for p in ph):.0f}")
 # shader clock rate estimate: cycles between entry and exit stamps vs wall clock
