@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Row share of a workgroup's wave 0 (the step kernel's controller wave) against the other seven: C2 / C1 / C5-like solve
-time and step period for CLC_WAVE0_SHARE = a:b (one subprocess per setting: the library reads the variable once)."""
+time and step period for CLC_WAVE0_SHARE = a:b (one subprocess per setting: the library reads the variable once).
+NEGATIVE RESULT (profiles/r03_wave0_share.md): the CLC_WAVE0_SHARE knob of wave_split_kernel was removed again after this
+measurement (git history: commit "Fast per-point math in rows_point ... wave-0 share experiment (negative)"); kept as the record of how it was measured."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
