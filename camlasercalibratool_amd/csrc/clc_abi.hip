@@ -803,6 +803,7 @@ int clc_create(clc_handle** out, int device) {
   CLC_HIP(hipMalloc(&h->d_queue, sizeof(unsigned int)));
   CLC_HIP(hipMalloc(&h->d_ticket, sizeof(unsigned int)));
   CLC_HIP(hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned int), h->own_stream));
+  CLC_HIP(hipMemsetAsync(h->d_queue, 0, sizeof(unsigned int), h->own_stream));  // (counters are zero between launches)
   CLC_HIP(hipStreamSynchronize(h->own_stream));  // the caller may switch streams (clc_set_stream) before the first launch
   CLC_HIP(hipHostMalloc(&h->h_mailbox, sizeof(clc::HostMailbox), hipHostMallocCoherent | hipHostMallocMapped));
   CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mailbox), h->h_mailbox, 0));
@@ -1263,10 +1264,10 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
   const int d_cap = want_trace ? h->trace_cap : 0;
   if (opt.use_loss)
     hipLaunchKernelGGL((clc::resident_solve_kernel<true, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
-                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done);
+                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done, nullptr);
   else
     hipLaunchKernelGGL((clc::resident_solve_kernel<false, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
-                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done);
+                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done, nullptr);
   CLC_HIP(hipGetLastError());
   // The kernel sets the flag (system-scope release) after the outcome is written: polling it avoids the wake-up latency of a
   // blocking stream synchronisation (~15 us of a ~120 us solve).  Bounded: a wedged queue falls through to the synchronisation,
@@ -1339,7 +1340,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 
   // a problem one workgroup holds: the whole solve in one single-workgroup launch (default flags only: the explicit flag
   // sets select the step chain / launch pair the bit-identity tests compare; profile_events = 1 asks for per-pass events)
-  if (h->sres.ok && h->launch_auto && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
+  if (h->sres.ok && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
@@ -1691,12 +1692,15 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->bres.d_desc);
 #define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream,        \
-                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, h->d_summaries, h->d_results, nullptr)
+                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, h->d_summaries, h->d_results, nullptr, nullptr)
 #define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
   do {                                                                                                                        \
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
     else { if (bl.res_nt) CLC_LAUNCH_RES(false, true, NW, PR, PL); else CLC_LAUNCH_RES(false, false, NW, PR, PL); }            \
   } while (0)
+    // (A completion flag raised by the last workgroup to finish, polled by the host instead of this blocking synchronisation, was
+    // measured: every workgroup then needs a system-scope release before it counts itself in, which on this part writes back L2 —
+    // C4 shard 0.93 -> 1.28 ms, C3 0.150 -> 0.166.  The single-workgroup solve keeps its flag: one release per solve.)
     const bool timed = opt.profile_events == 1;  // HIP event pair around the one launch -> clc_summary.eval_kernel_ms of every problem
     if (timed) {
       const int rc = ensure_events(h, 2);

@@ -159,14 +159,15 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
 // The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
 // uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read).
 // trace (nullable; single-problem launches only): the iteration records of clc_solve.
-// host_done (nullable; single-problem launches only): set to 1 in host memory, system-scope release, once the outcome is written —
-// the host polls it instead of blocking on the stream.
+// host_done (nullable): set to 1 in host memory, system-scope release, once the outcome of EVERY problem of the launch is written
+// (done_count: device counter of finished workgroups, zero between launches; nullable for a single-workgroup launch) — the host
+// polls it instead of blocking on the stream.
 template <bool WITH_LOSS, bool NT, int NW, int PR, int PL>
 __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, clc_iteration* __restrict__ trace,
     const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results,
-    int32_t* __restrict__ host_done) {
+    int32_t* __restrict__ host_done, unsigned int* __restrict__ done_count) {
   constexpr bool RES_LEAN = NW == 4;  // the controller next to 92 VGPRs of points: the small-footprint form (clc_controller.hpp)
   constexpr int NL = NW * 64;
   constexpr int NP = PR + PL;  // points a lane can hold
@@ -412,7 +413,18 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     if (lane == 0) {
       if (st.status == CLC_RUNNING) st.status = CLC_FAILURE;  // unreachable: the controller stops at the iteration cap
       batched_write_outcome(st, prob, poses, summaries, results);
-      if (host_done != nullptr) __hip_atomic_store(host_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (host_done != nullptr) {
+        bool last = true;
+        if (done_count != nullptr) {
+          // this workgroup's outcome is complete in host / device memory before it counts itself in (system-scope release);
+          // the last one to arrive has therefore seen everybody's, resets the counter for the next launch and raises the flag
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          const unsigned int n = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          last = n == gridDim.x - 1;
+          if (last) __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(host_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
