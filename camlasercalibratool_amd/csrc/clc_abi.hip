@@ -154,6 +154,7 @@ struct clc_handle {
   size_t rdesc_cap_bytes = 0;
   long long n_rows = 0;
   bool rows_ok = false;
+  bool rows_z = false;  // the rows carry z (some record has p.z != 0): ROW_DOUBLES_Z doubles per row
   int split_grid = -1;  // grid the wave split table behind d_rdesc was built for (-1: none)
   // resident pose-major scans (clc_store_observations): device copies + the host-side CSR offsets
   double* d_sq = nullptr; size_t sq_cap = 0;     // tag_q (w,x,y,z) [P*4]
@@ -196,6 +197,7 @@ struct clc_handle {
   size_t brdesc_cap_bytes = 0;
   long long bn_rows = 0;
   bool brows_ok = false;
+  bool brows_z = false;
   long long* d_prob_row = nullptr;  // [P+1] first row of every problem
   // resident ("lane") layouts (clc_resident.hpp): of the batched problems, and of a single problem small enough for one workgroup
   ResLayout bres, sres;
@@ -288,8 +290,8 @@ bool use_rows(const clc_handle* h) {
 }
 bool use_brows(const clc_handle* h) { return (h->launch_flags & clc::FLAG_ROWS) != 0 && h->brows_ok; }
 // Rows streamed from HBM rather than the Infinity Cache (> 1.5x its size) are loaded non-temporally.
-bool rows_nontemporal(const clc_handle* h, long long n_rows) {
-  const size_t bytes = (size_t)n_rows * (clc::ROW_DOUBLES * sizeof(double) + sizeof(clc::RowDesc));
+bool rows_nontemporal(const clc_handle* h, long long n_rows, bool z = false) {
+  const size_t bytes = (size_t)n_rows * ((z ? clc::ROW_DOUBLES_Z : clc::ROW_DOUBLES) * sizeof(double) + sizeof(clc::RowDesc));
   return (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 || (h->launch_auto && bytes > kInfinityCacheBytes + kInfinityCacheBytes / 2);
 }
 
@@ -317,7 +319,16 @@ void launch_eval_v(clc_handle* h, int grid, const double* d_pose, const int32_t*
   const bool cp = (fl & clc::FLAG_COMPACT) != 0 && h->compact_ok;
   const bool big = (fl & clc::FLAG_WG512) != 0;
   if (use_rows(h)) {  // row layout: the Jacobian comes with the moments, a cost-only pass would save nothing
-    const bool rnt = rows_nontemporal(h, h->n_rows);
+    const bool rnt = rows_nontemporal(h, h->n_rows, h->rows_z);
+    if (h->rows_z) {  // rows that carry z: 3:2 wave shares, 8 rows in flight
+#define CLC_LAUNCH_RZ(NT, BT)                                                                                              \
+  hipLaunchKernelGGL((clc::eval_rows_kernel<WITH_LOSS, NT, BT, true, clc::ROWS_DEPTH, true>), dim3(grid), dim3(BT), 0, h->stream, h->d_rxy, \
+                     reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, d_pose, d_status, lf, fl, h->d_partials, pose_arg, use_pose_arg)
+      if (big) { if (rnt) CLC_LAUNCH_RZ(true, 512); else CLC_LAUNCH_RZ(false, 512); }
+      else { if (rnt) CLC_LAUNCH_RZ(true, 256); else CLC_LAUNCH_RZ(false, 256); }
+#undef CLC_LAUNCH_RZ
+      return;
+    }
     // Equal, scan-aligned shares (flag 512) pay where a wave's share is a scan or two; the evaluation kernel ALONE with
     // tens of rows per wave and more is 3-7 % faster with the 3:2 old/young shares (scripts/r02_ab.py: 6.2 vs 6.8 us at
     // 1e6 observations, but 15.4 vs 14.7 at 4e6 and 45.1 vs 42.1 at 1.6e7) — the step kernel is not (its wave 0 starts
@@ -452,6 +463,7 @@ struct LayoutTargets {
   double** d_rxy; size_t* rxy_cap; double** d_rdesc; size_t* rdesc_cap; long long* n_rows; bool* rows_ok;
   long long** d_prob_row;  // nullptr for the single-problem array
   ResLayout* res = nullptr;  // also build the on-chip resident ("lane") layout (clc_resident.hpp) into this
+  bool* rows_z = nullptr;    // out: the rows carry z
 };
 
 // Resident layout limits: what the instantiations of resident_solve_kernel hold per lane (registers + LDS).
@@ -590,7 +602,9 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   long long R = 0;
   DevBuf<unsigned int> brows(&h->pool), brbeg(&h->pool);
   DevBuf<unsigned long long> btot2(&h->pool);
-  if (!any_z) {
+  const size_t row_doubles = any_z ? clc::ROW_DOUBLES_Z : clc::ROW_DOUBLES;
+  if (T.rows_z) *T.rows_z = any_z != 0;
+  {
     const long long gblocks = ((long long)G + clc::SCAN_CHUNK - 1) / clc::SCAN_CHUNK;
     CLC_HIP(brows.alloc(G));
     CLC_HIP(brbeg.alloc(G + 1));
@@ -608,15 +622,15 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   }
   if (rows_ok) {
     // one padding row each: the streaming loop's prologue loads run unconditionally from clamped row indices
-    rc = ensure_bytes(T.d_rxy, T.rxy_cap, ((size_t)R + 1) * clc::ROW_DOUBLES * sizeof(double));
+    rc = ensure_bytes(T.d_rxy, T.rxy_cap, ((size_t)R + 1) * row_doubles * sizeof(double));
     if (rc != CLC_OK) return rc;
     rc = ensure_bytes(T.d_rdesc, T.rdesc_cap, ((size_t)R + 1) * sizeof(clc::RowDesc) + clc::wave_split_bytes(R));  // + the wave split table
     if (rc != CLC_OK) return rc;
-    CLC_HIP(hipMemsetAsync(*T.d_rxy + (size_t)R * clc::ROW_DOUBLES, 0, clc::ROW_DOUBLES * sizeof(double), h->stream));
+    CLC_HIP(hipMemsetAsync(*T.d_rxy + (size_t)R * row_doubles, 0, row_doubles * sizeof(double), h->stream));
     CLC_HIP(hipMemsetAsync(reinterpret_cast<char*>(*T.d_rdesc) + (size_t)R * sizeof(clc::RowDesc), 0, sizeof(clc::RowDesc), h->stream));
     const long long slots = R * clc::ROW;
     hipLaunchKernelGGL(clc::build_rows_kernel, dim3((unsigned)((slots + threads - 1) / threads)), dim3(threads), 0, h->stream,
-                       d_aos, bstarts.p, brbeg.p, (long long)G, R, *T.d_rxy, reinterpret_cast<clc::RowDesc*>(*T.d_rdesc));
+                       d_aos, bstarts.p, brbeg.p, (long long)G, R, (int)row_doubles, *T.d_rxy, reinterpret_cast<clc::RowDesc*>(*T.d_rdesc));
     if (T.d_prob_row)
       hipLaunchKernelGGL(clc::problem_rows_kernel, dim3((unsigned)((P + 1 + threads - 1) / threads)), dim3(threads), 0,
                          h->stream, broff.p, bgid.p, brbeg.p, (long long)P, n, R, *T.d_prob_row);
@@ -690,7 +704,7 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
            (bl->compact && h->launch_auto &&
             h->batch_total_tiles * clc::CTILE_DOUBLES * sizeof(double) > kInfinityCacheBytes + kInfinityCacheBytes / 2);
   bl->deep = (h->launch_flags & clc::FLAG_DEEP) != 0 || bbeyond;
-  bl->rows_nt = bl->rows && rows_nontemporal(h, h->bn_rows);
+  bl->rows_nt = bl->rows && rows_nontemporal(h, h->bn_rows, h->brows_z);
   // One workgroup per problem running the problem's WHOLE solve in one launch (batched_solve_kernel) beats the lockstep
   // launches wherever a pass over the batch is not bandwidth-bound anyway — per evaluation pass, 10^4-observation
   // problems: 17 vs 69 us at 24 problems, 28 vs 52 at 512, 49 vs 65 at 1 024 (C3), 96 vs 115 at 2 048, a tie at 4 096
@@ -698,8 +712,8 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
   // 91 vs 70 at 24, a tie at 256 (scripts/probes/c3_exp.py).  So: unless the rows exceed 1 GiB (a C4 shard: lockstep, one
   // wave per problem) or a single problem is so long (> 1 024 rows, ~6.5e4 observations) that four waves are too few.
   {
-    const size_t row_bytes = (size_t)h->bn_rows * (clc::ROW_DOUBLES * sizeof(double) + sizeof(clc::RowDesc));
-    bl->whole_solve = bl->rows && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && h->batch_max_rows <= 1024;
+    const size_t row_bytes = (size_t)h->bn_rows * ((h->brows_z ? clc::ROW_DOUBLES_Z : clc::ROW_DOUBLES) * sizeof(double) + sizeof(clc::RowDesc));
+    bl->whole_solve = bl->rows && !h->brows_z && (h->launch_flags & clc::FLAG_BATCHED_LOCKSTEP) == 0 && row_bytes <= (1ull << 30) && h->batch_max_rows <= 1024;
   }
   // Problems that fit a workgroup's registers + LDS are read from HBM once and solved on chip (clc_resident.hpp).
   bl->resident = h->bres.ok && (h->launch_flags & (clc::FLAG_NO_RESIDENT | clc::FLAG_BATCHED_LOCKSTEP)) == 0;
@@ -718,6 +732,21 @@ void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLau
   hipLaunchKernelGGL((clc::batched_rows_eval_kernel<LOSS, NT, BT>), dim3((unsigned)n_blocks), dim3(BT), 0, h->stream,   \
                      h->d_brxy, reinterpret_cast<const clc::RowDesc*>(h->d_brdesc), h->d_prob_row, h->d_states, bpp,     \
                      opt.loss_scale_factor, h->d_bpartials)
+    if (h->brows_z) {
+#define CLC_LAUNCH_BRZ(LOSS, NT, BT)                                                                           \
+  hipLaunchKernelGGL((clc::batched_rows_eval_kernel<LOSS, NT, BT, true>), dim3((unsigned)n_blocks), dim3(BT), 0, h->stream, \
+                     h->d_brxy, reinterpret_cast<const clc::RowDesc*>(h->d_brdesc), h->d_prob_row, h->d_states, bpp,     \
+                     opt.loss_scale_factor, h->d_bpartials)
+      if (bl.rows_wave) {
+        if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_BRZ(true, true, 64); else CLC_LAUNCH_BRZ(true, false, 64); }
+        else { if (bl.rows_nt) CLC_LAUNCH_BRZ(false, true, 64); else CLC_LAUNCH_BRZ(false, false, 64); }
+      } else {
+        if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_BRZ(true, true, 256); else CLC_LAUNCH_BRZ(true, false, 256); }
+        else { if (bl.rows_nt) CLC_LAUNCH_BRZ(false, true, 256); else CLC_LAUNCH_BRZ(false, false, 256); }
+      }
+#undef CLC_LAUNCH_BRZ
+      return;
+    }
     if (bl.rows_wave) {
       if (opt.use_loss) { if (bl.rows_nt) CLC_LAUNCH_BR(true, true, 64); else CLC_LAUNCH_BR(true, false, 64); }
       else { if (bl.rows_nt) CLC_LAUNCH_BR(false, true, 64); else CLC_LAUNCH_BR(false, false, 64); }
@@ -899,7 +928,7 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
                            &h->d_rxy, &h->rxy_cap_bytes, &h->d_rdesc, &h->rdesc_cap_bytes, &h->n_rows, &h->rows_ok, nullptr,
                            // a problem one workgroup can hold (<= 512 lanes x 22 points) also gets the lane layout: clc_solve then runs
                            // its whole LM loop in ONE single-workgroup launch from registers + LDS (solve_resident_single)
-                           n <= (size_t)512 * (kResPR512 + kResPL512) ? &h->sres : nullptr};
+                           n <= (size_t)512 * (kResPR512 + kResPL512) ? &h->sres : nullptr, &h->rows_z};
   return build_layouts(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, T);
 }
 
@@ -1154,8 +1183,9 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
   const bool deep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
                     (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
   const bool rows = use_rows(h);
-  const bool rows_nt = rows && rows_nontemporal(h, h->n_rows);
-  const bool rows_eq = (h->launch_flags & clc::FLAG_EQUAL_WAVES) != 0;
+  const bool rows_z = rows && h->rows_z;
+  const bool rows_nt = rows && rows_nontemporal(h, h->n_rows, rows_z);
+  const bool rows_eq = (h->launch_flags & clc::FLAG_EQUAL_WAVES) != 0 && !rows_z;
   if (rows && rows_eq) ensure_wave_split(h, grid);
   double* rows_buf[2] = {h->d_partials, h->d_partials_b};
   int launched = 0, status = CLC_RUNNING, last_done = 0;
@@ -1185,7 +1215,16 @@ int solve_stepped(clc_handle* h, const clc_options& opt, int grid, double pose[7
 #define CLC_LAUNCH_STEP_RM(LOSS, NT, WG)                                                                      \
   do { if (k == 0) CLC_LAUNCH_STEP_R(LOSS, NT, 0, WG); else if (k == 1) CLC_LAUNCH_STEP_R(LOSS, NT, 1, WG);     \
        else CLC_LAUNCH_STEP_R(LOSS, NT, 2, WG); } while (0)
-      if (rows) {
+      if (rows_z) {  // rows that carry z (LAYOUT 2): 3:2 wave shares
+#define CLC_LAUNCH_STEP_Z(LOSS, NT)                                                                           \
+  do { if (k == 0) hipLaunchKernelGGL((clc::step_kernel<LOSS, NT, 0, 2, true>), dim3(grid), dim3(512), 0, h->stream, r_in, h->d_rxy, h->d_rdesc, (int)h->n_rows, grid | ((k & 1) << 30), k, r_out, h->d_block, prm); \
+       else if (k == 1) hipLaunchKernelGGL((clc::step_kernel<LOSS, NT, 1, 2, true>), dim3(grid), dim3(512), 0, h->stream, r_in, h->d_rxy, h->d_rdesc, (int)h->n_rows, grid | ((k & 1) << 30), k, r_out, h->d_block, prm); \
+       else hipLaunchKernelGGL((clc::step_kernel<LOSS, NT, 2, 2, true>), dim3(grid), dim3(512), 0, h->stream, r_in, h->d_rxy, h->d_rdesc, (int)h->n_rows, grid | ((k & 1) << 30), k, r_out, h->d_block, prm); } while (0)
+        if (opt.use_loss) { if (rows_nt) CLC_LAUNCH_STEP_Z(true, true); else CLC_LAUNCH_STEP_Z(true, false); }
+        else { if (rows_nt) CLC_LAUNCH_STEP_Z(false, true); else CLC_LAUNCH_STEP_Z(false, false); }
+#undef CLC_LAUNCH_STEP_Z
+      }
+      else if (rows) {
         if (opt.use_loss) {
           if (rows_eq) { if (rows_nt) CLC_LAUNCH_STEP_RM(true, true, false); else CLC_LAUNCH_STEP_RM(true, false, false); }
           else { if (rows_nt) CLC_LAUNCH_STEP_RM(true, true, true); else CLC_LAUNCH_STEP_RM(true, false, true); }
@@ -1516,7 +1555,14 @@ int clc_closed_form(clc_handle* h, double Tlc[16], int* unobservable, double sv9
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
   if (use_rows(h)) {
-    if (rows_nontemporal(h, h->n_rows))
+    const clc::RowDesc* rdesc = reinterpret_cast<const clc::RowDesc*>(h->d_rdesc);
+    if (h->rows_z) {  // bar_p = (x, y, 1): z is not read, only the row stride differs
+      if (rows_nontemporal(h, h->n_rows, true))
+        hipLaunchKernelGGL((clc::normal9_rows_kernel<true, clc::ROW_DOUBLES_Z>), dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_rxy, rdesc, h->n_rows, h->d_partials);
+      else
+        hipLaunchKernelGGL((clc::normal9_rows_kernel<false, clc::ROW_DOUBLES_Z>), dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_rxy, rdesc, h->n_rows, h->d_partials);
+    }
+    else if (rows_nontemporal(h, h->n_rows))
       hipLaunchKernelGGL(clc::normal9_rows_kernel<true>, dim3(grid), dim3(clc::BLOCK), 0, h->stream, h->d_rxy,
                          reinterpret_cast<const clc::RowDesc*>(h->d_rdesc), h->n_rows, h->d_partials);
     else
@@ -1627,7 +1673,7 @@ int upload_batched_impl(clc_handle* h, const clc_observation* records, bool on_d
   if (e == hipSuccess && d_aos) {
     const LayoutTargets T = {&h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups, &h->bgroups_cap_bytes, &h->bn_groups,
                              &h->bcompact_ok, &h->d_brxy, &h->brxy_cap_bytes, &h->d_brdesc, &h->brdesc_cap_bytes, &h->bn_rows,
-                             &h->brows_ok, &h->d_prob_row, &h->bres};
+                             &h->brows_ok, &h->d_prob_row, &h->bres, &h->brows_z};
     crc = build_layouts(h, d_aos, n_total, rel, tile_off, T);
   }
   if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
@@ -2205,9 +2251,9 @@ int clc_debug_build_features(void) {
 // Row-layout report: rows[0/1] + row counts for the single-problem array and the batch.
 int clc_debug_rows(clc_handle* h, int* rows, long long* n_rows, int* brows, long long* bn_rows) {
   if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_rows: NULL handle");
-  if (rows) *rows = h->rows_ok ? 1 : 0;
+  if (rows) *rows = h->rows_ok ? (h->rows_z ? 2 : 1) : 0;  // 2: the rows carry z
   if (n_rows) *n_rows = h->n_rows;
-  if (brows) *brows = h->brows_ok ? 1 : 0;
+  if (brows) *brows = h->brows_ok ? (h->brows_z ? 2 : 1) : 0;
   if (bn_rows) *bn_rows = h->bn_rows;
   return CLC_OK;
 }

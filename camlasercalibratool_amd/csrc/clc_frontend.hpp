@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void reduce9_kernel(const double* __restrict
 
 // K5 on the row layout: 16 B/point instead of 48 of the 64-byte tiles, 5 FP64 instructions per point.
 // Wave reduction of the 45 accumulators: 45 -> 23 registers with one permlane32 swap round, then xor-shuffles.
-template <bool NT>
+template <bool NT, int STRIDE = ROW_DOUBLES>
 __global__ __launch_bounds__(BLOCK) void normal9_rows_kernel(const double* __restrict__ xy, const RowDesc* __restrict__ desc,
                                                              const long long n_rows, double* __restrict__ partials) {
   double acc[NACC9];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(BLOCK) void normal9_rows_kernel(const double* __res
   const int lane = threadIdx.x & 63;
   const WaveMap wm = make_wave_map<BLOCK>(blockIdx.x, gridDim.x, threadIdx.x >> 6);
   Normal9Rows pol;
-  stream_rows_policy<Normal9Rows, NT, ROWS_DEPTH>(pol, xy, desc, wm.begin(n_rows), wm.end(n_rows), lane,
+  stream_rows_policy<Normal9Rows, NT, ROWS_DEPTH, STRIDE>(pol, xy, desc, wm.begin(n_rows), wm.end(n_rows), lane,
                                       [](PoseU&) { return true; }, acc);
   __shared__ double wsum[BLOCK / 64][NACC9 + 1];
   // halves: after the swap, lanes 0-31 hold acc[i] of {l, l+32} summed, lanes 32-63 acc[i+23]

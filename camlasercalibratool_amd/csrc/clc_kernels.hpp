@@ -20,7 +20,8 @@
 namespace clc {
 
 // K1 on the row layout: same contract as eval_kernel (one 28-double partial per workgroup).
-template <bool WITH_LOSS, bool NT, int BT, bool WEIGHTED, int DEPTH = ROWS_DEPTH>
+// Z: the rows carry z (ROW_DOUBLES_Z stride, 14 moments per scan).
+template <bool WITH_LOSS, bool NT, int BT, bool WEIGHTED, int DEPTH = ROWS_DEPTH, bool Z = false>
 __global__ __launch_bounds__(BT) void eval_rows_kernel(const double* __restrict__ xy, const RowDesc* __restrict__ desc,
                                                        const long long n_rows, const double* __restrict__ pose,
                                                        const int32_t* __restrict__ status, const double lf,
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(BT) void eval_rows_kernel(const double* __restrict_
     r0 = wm.begin(n_rows);
     r1 = wm.end(n_rows);
   }
-  if (!stream_rows<WITH_LOSS, NT, DEPTH>(xy, desc, r0, r1, lane, get_pose, inv_lf2, acc)) return;
+  if (!stream_rows<WITH_LOSS, NT, DEPTH, Z>(xy, desc, r0, r1, lane, get_pose, inv_lf2, acc)) return;
   block_reduce_store<BT / 64>(acc, reduce_mode, partials + (size_t)blockIdx.x * NACC);
 }
 
@@ -204,7 +205,7 @@ __device__ unsigned long long clc_stamp_buf[STAMP_LAUNCHES][STAMP_WGS][STAMP_SLO
 #endif
 
 // LAYOUT 0: compact tiles (ctiles + group table, n = observations); 1: row layout (ctiles = xy rows, groups = row
-// descriptors, n = rows; DEEP selects non-temporal loads, WEIGHTED the 3:2 old/young wave shares).
+// descriptors, n = rows; DEEP selects non-temporal loads, WEIGHTED the 3:2 old/young wave shares); 2: rows that carry z.
 template <bool WITH_LOSS, bool DEEP, int MODE, int LAYOUT = 0, bool WEIGHTED = true>
 __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ rows_in,
                                                    const double* __restrict__ ctiles,
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
   // has summed its rows does it issue its first rows of points — those have the whole controller to arrive.
   if (MODE != 0) lm_tail_sums<false, 512>(rows_in, grid, red, sh_state, L, nullptr, LM_STATE_WORDS + PRM_WORDS);
   bool active;
-  if (LAYOUT == 1) {
+  if (LAYOUT != 0) {
     const RowDesc* desc = reinterpret_cast<const RowDesc*>(groups);
     long long r0 = wm.begin(n), r1 = wm.end(n);
     if (!WEIGHTED) {  // equal shares, boundaries at scan starts (wave_split_kernel)
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
       r0 = run.begin;
       r1 = run.end;
     }
-    active = stream_rows<WITH_LOSS, DEEP>(ctiles, desc, r0, r1, lane, get_pose, inv_lf2, acc);
+    active = stream_rows<WITH_LOSS, DEEP, LAYOUT == 2 ? ROWS_DEPTH_Z : ROWS_DEPTH, LAYOUT == 2>(ctiles, desc, r0, r1, lane, get_pose, inv_lf2, acc);
   }
   else if (DEEP) active = stream_ctiles_deep<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
   else active = stream_ctiles<WITH_LOSS, true, false>(ctiles, groups, n, wm, lane, get_pose, inv_lf2, acc);
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void batched_eval_kernel(
 // (blocks_per_problem counts waves).  A problem of 10^4 observations is 160 rows: with 256-thread workgroups the dispatcher
 // refills a CU only when the slowest of four waves has finished and every workgroup pays a barrier + LDS pass; with
 // single-wave workgroups every wave slot is refilled the moment it frees (measured on one C4 shard: see DESIGN.md K4).
-template <bool WITH_LOSS, bool NT, int BT>
+template <bool WITH_LOSS, bool NT, int BT, bool Z = false>
 __global__ __launch_bounds__(BT) void batched_rows_eval_kernel(
     const double* __restrict__ xy, const RowDesc* __restrict__ desc, const long long* __restrict__ prob_row,
     const LmState* __restrict__ states, const int blocks_per_problem, const double lf, double* __restrict__ partials) {
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(BT) void batched_rows_eval_kernel(
   const int lane = threadIdx.x & 63;
   const long long r0 = prob_row[prob], r1 = prob_row[prob + 1];
   const WaveMap wm = make_wave_map<BT>(j, blocks_per_problem, threadIdx.x >> 6);
-  if (!stream_rows<WITH_LOSS, NT>(xy, desc, r0 + wm.begin(r1 - r0), r0 + wm.end(r1 - r0), lane, get_pose, inv_lf2, acc)) return;
+  if (!stream_rows<WITH_LOSS, NT, ROWS_DEPTH, Z>(xy, desc, r0 + wm.begin(r1 - r0), r0 + wm.end(r1 - r0), lane, get_pose, inv_lf2, acc)) return;
   if (BT == 64)
     wave_reduce_butterfly(acc, partials + (size_t)blockIdx.x * NACC, lane);
   else

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const TIn* __r
 }
 
 // flag[k] = 1 when record k starts a new scan ((n, d, scale) differ bitwise from record k-1); *any_z is set when some
-// record has p.z != 0 (the row layout then does not apply).
+// record has p.z != 0 (the rows then carry z: ROW_DOUBLES_Z doubles per row; the on-chip resident layout does not apply).
 __global__ void scan_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag,
                                  unsigned int* __restrict__ any_z) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,9 +223,10 @@ __global__ void scan_rows_kernel(const long long* __restrict__ starts, long long
 }
 
 // row_begin[G+1]: exclusive prefix of rows[] (row_begin[0] = 0 written here).  One thread per row SLOT.
+// stride = ROW_DOUBLES, or ROW_DOUBLES_Z: the 64 z of the row are stored after its (x, y) pairs.
 __global__ void build_rows_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
                                   const unsigned int* __restrict__ row_begin, long long n_groups, long long n_rows,
-                                  double* __restrict__ xy, RowDesc* __restrict__ desc) {
+                                  const int stride, double* __restrict__ xy, RowDesc* __restrict__ desc) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long r = t >> 6;
   const int lane = (int)(t & 63);
@@ -240,10 +241,11 @@ __global__ void build_rows_kernel(const double* __restrict__ aos, const long lon
   const long long first = starts[g] + (r - (long long)row_begin[g]) * ROW;
   const long long end = starts[g + 1];
   const long long k = first + lane;
-  double x = 0.0, y = 0.0;
-  if (k < end) { x = aos[8 * k + 4]; y = aos[8 * k + 5]; }
+  double x = 0.0, y = 0.0, z = 0.0;
+  if (k < end) { x = aos[8 * k + 4]; y = aos[8 * k + 5]; z = aos[8 * k + 6]; }
   v2d v; v[0] = x; v[1] = y;
-  reinterpret_cast<v2d*>(xy + r * ROW_DOUBLES)[lane] = v;
+  reinterpret_cast<v2d*>(xy + r * stride)[lane] = v;
+  if (stride == ROW_DOUBLES_Z) xy[r * stride + ROW_DOUBLES + lane] = z;
   if (lane == 0) {
     const double* a = aos + 8 * starts[g];
     RowDesc d;

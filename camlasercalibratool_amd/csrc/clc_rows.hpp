@@ -26,6 +26,7 @@ namespace clc {
 
 constexpr int ROW = 64;          // points per row = lanes per wavefront: one point per lane per row
 constexpr int ROW_DOUBLES = 128; // (x, y) interleaved: lane l reads doubles 2l, 2l+1 with one 16-byte load
+constexpr int ROW_DOUBLES_Z = 192;  // rows that carry z: the 64 z of the row follow its 64 (x, y) pairs
 constexpr int NACC_ROWS = 28;    // same accumulator layout as the per-point path: H(21) g(6) cost(1)
 
 // One descriptor per row (64 B, read with scalar loads — it is wave-uniform): the plane and scale of the row's scan
@@ -210,6 +211,120 @@ CLC_HD void rows_flush(const RowPlane& q, const RowMoments& M, double* acc) {
   if (WITH_LOSS) {
     int e;
     const double m = frexp_pos(M.prod, e);  // (the last point of the segment may have left the product un-normalised)
+    acc[27] = fma(s2, log_mant_exp(m, M.expo + e), acc[27]);
+  } else
+    acc[27] = fma(s2, M.prod, acc[27]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Scan points OFF the lidar plane (p.z != 0): Oberserve::points is std::vector<Eigen::Vector3d> (include/LaseCamCalCeres.h:22),
+// and although the reference's own producers always write z = 0 (src/utilities.cpp:198-215), a caller of the Vector3d
+// interface need not.  Same idea, one dimension more: r0 = m.p + c0 and u = [n, p x m] are linear in (1, x, y, z), so a
+// lane accumulates the 14 weighted moments S0, S_a, S_ab (a <= b in {x, y, z}), T0, T_a and expands them once per scan
+// segment: 28.5 FP64 instructions and 24 B per point (x, y as for z = 0 plus one more 8-byte row of z), against 21.5 / 16.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RowMoments3 {
+  double S0, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz, T0, Tx, Ty, Tz;
+  double prod;  // as RowMoments
+  int expo;
+};
+
+template <bool WITH_LOSS>
+CLC_HD void rows3_moments_reset(RowMoments3& M) {
+  M.S0 = M.Sx = M.Sy = M.Sz = M.Sxx = M.Sxy = M.Sxz = M.Syy = M.Syz = M.Szz = M.T0 = M.Tx = M.Ty = M.Tz = 0.0;
+  M.prod = WITH_LOSS ? 0.5 : 0.0;
+  M.expo = WITH_LOSS ? 1 : 0;
+}
+
+// One scan point (x, y, z); renorm as for rows_point.
+template <bool WITH_LOSS>
+CLC_HD void rows3_point(const RowPlane& q, const double inv_lf2, const double x, const double y, const double z, RowMoments3& M,
+                        const bool renorm = true) {
+  const double r0 = fma(q.mz, z, fma(q.my, y, fma(q.mx, x, q.c0)));
+  double w = 1.0;
+  if (WITH_LOSS) {
+    const double sum = fma(r0 * r0, inv_lf2, 1.0);
+    w = rcp_ge1_weight(sum);
+    const double pr = M.prod * sum;
+    if (renorm) {
+      int e;
+      M.prod = frexp_pos(pr, e);
+      M.expo += e;
+    } else {
+      M.prod = pr;
+    }
+  } else {
+    M.prod = fma(r0, r0, M.prod);
+  }
+  const double wx = w * x, wy = w * y, wz = w * z, wr = w * r0;
+  M.S0 += w;
+  M.Sx += wx;
+  M.Sy += wy;
+  M.Sz += wz;
+  M.Sxx = fma(wx, x, M.Sxx);
+  M.Sxy = fma(wx, y, M.Sxy);
+  M.Sxz = fma(wx, z, M.Sxz);
+  M.Syy = fma(wy, y, M.Syy);
+  M.Syz = fma(wy, z, M.Syz);
+  M.Szz = fma(wz, z, M.Szz);
+  M.T0 += wr;
+  M.Tx = fma(wr, x, M.Tx);
+  M.Ty = fma(wr, y, M.Ty);
+  M.Tz = fma(wr, z, M.Tz);
+}
+
+// Expansion into the 28 accumulators (layout as rows_flush).  With u_theta = p x m = (y mz - z my, z mx - x mz, x my - y mx):
+//   sum w u_theta            = (mz Sy - my Sz,  mx Sz - mz Sx,  my Sx - mx Sy)
+//   sum w u_theta u_theta^T  = quadratic forms of the second moments (below), sum w r0 u_theta likewise from T_a.
+template <bool WITH_LOSS>
+CLC_HD void rows3_flush(const RowPlane& q, const RowMoments3& M, double* acc) {
+  const double s2 = q.s2;
+  const double S0 = s2 * M.S0, Sx = s2 * M.Sx, Sy = s2 * M.Sy, Sz = s2 * M.Sz;
+  const double Sxx = s2 * M.Sxx, Sxy = s2 * M.Sxy, Sxz = s2 * M.Sxz, Syy = s2 * M.Syy, Syz = s2 * M.Syz, Szz = s2 * M.Szz;
+  const double T0 = s2 * M.T0, Tx = s2 * M.Tx, Ty = s2 * M.Ty, Tz = s2 * M.Tz;
+  const double nx = q.nx, ny = q.ny, nz = q.nz, mx = q.mx, my = q.my, mz = q.mz;
+  // translation block: n n^T S0
+  const double ax = nx * S0, ay = ny * S0, az = nz * S0;
+  acc[0] = fma(ax, nx, acc[0]);
+  acc[1] = fma(ax, ny, acc[1]);
+  acc[2] = fma(ax, nz, acc[2]);
+  acc[6] = fma(ay, ny, acc[6]);
+  acc[7] = fma(ay, nz, acc[7]);
+  acc[11] = fma(az, nz, acc[11]);
+  // cross block: n (sum w u_theta)^T
+  const double v3 = fma(mz, Sy, -(my * Sz)), v4 = fma(mx, Sz, -(mz * Sx)), v5 = fma(my, Sx, -(mx * Sy));
+  acc[3] = fma(nx, v3, acc[3]);
+  acc[4] = fma(nx, v4, acc[4]);
+  acc[5] = fma(nx, v5, acc[5]);
+  acc[8] = fma(ny, v3, acc[8]);
+  acc[9] = fma(ny, v4, acc[9]);
+  acc[10] = fma(ny, v5, acc[10]);
+  acc[12] = fma(nz, v3, acc[12]);
+  acc[13] = fma(nz, v4, acc[13]);
+  acc[14] = fma(nz, v5, acc[14]);
+  // rotation block: sum w u_theta u_theta^T via the vectors  P_a = sum w a (p x m)  for a in {x, y, z}:
+  //   P_x = (mz Sxy - my Sxz, mx Sxz - mz Sxx, my Sxx - mx Sxy), P_y, P_z alike;  then
+  //   sum w (p x m)(p x m)^T = row a of the cross-product matrix [.]x m applied to P:  (33) = mz P_y[0] - my P_z[0], ...
+  const double Px0 = fma(mz, Sxy, -(my * Sxz)), Px1 = fma(mx, Sxz, -(mz * Sxx)), Px2 = fma(my, Sxx, -(mx * Sxy));
+  const double Py0 = fma(mz, Syy, -(my * Syz)), Py1 = fma(mx, Syz, -(mz * Sxy)), Py2 = fma(my, Sxy, -(mx * Syy));
+  const double Pz0 = fma(mz, Syz, -(my * Szz)), Pz1 = fma(mx, Szz, -(mz * Sxz)), Pz2 = fma(my, Sxz, -(mx * Syz));
+  acc[15] = fma(mz, Py0, fma(-my, Pz0, acc[15]));  // (a a)
+  acc[16] = fma(mz, Py1, fma(-my, Pz1, acc[16]));  // (a b)
+  acc[17] = fma(mz, Py2, fma(-my, Pz2, acc[17]));  // (a c)
+  acc[18] = fma(mx, Pz1, fma(-mz, Px1, acc[18]));  // (b b)
+  acc[19] = fma(mx, Pz2, fma(-mz, Px2, acc[19]));  // (b c)
+  acc[20] = fma(my, Px2, fma(-mx, Py2, acc[20]));  // (c c)
+  // gradient: sum w r0 u
+  acc[21] = fma(nx, T0, acc[21]);
+  acc[22] = fma(ny, T0, acc[22]);
+  acc[23] = fma(nz, T0, acc[23]);
+  acc[24] = fma(mz, Ty, fma(-my, Tz, acc[24]));
+  acc[25] = fma(mx, Tz, fma(-mz, Tx, acc[25]));
+  acc[26] = fma(my, Tx, fma(-mx, Ty, acc[26]));
+  // cost
+  if (WITH_LOSS) {
+    int e;
+    const double m = frexp_pos(M.prod, e);
     acc[27] = fma(s2, log_mant_exp(m, M.expo + e), acc[27]);
   } else
     acc[27] = fma(s2, M.prod, acc[27]);

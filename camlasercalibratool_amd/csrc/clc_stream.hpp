@@ -289,8 +289,9 @@ __device__ __forceinline__ bool stream_ctiles_deep(const double* __restrict__ ct
 //   * desc[row] (64 B, wave-uniform: scalar loads): the scan's plane and scale, the valid count of the row, and
 //     whether the row starts a scan,
 // i.e. 17 B of traffic per observation for scans that fill their rows (28 B in the compact layout, 64 B algorithmic).
-// Needs p.z == 0 for every record (always true for the reference's scan points); otherwise the upload keeps the
-// compact / 64-byte layouts only.  A wave owns a contiguous run of rows, keeps DEPTH row loads in flight, accumulates
+// Arrays with some p.z != 0 (never produced by the reference's own scan conversion, but Oberserve::points is Vector3d) keep a
+// third 8-byte value per point: rows of ROW_DOUBLES_Z = 192 doubles, 64 z after the 64 (x, y) pairs, 25.4 B per observation.
+// A wave owns a contiguous run of rows, keeps DEPTH row loads in flight, accumulates
 // per-scan moments (one point per lane per row, ~26 FP64 instructions) and expands them into the 28 accumulators
 // when the scan changes (rows_flush).  Same lane->row map for every launch: bitwise reproducible.
 // ---------------------------------------------------------------------------------------
@@ -298,10 +299,20 @@ __device__ __forceinline__ bool stream_ctiles_deep(const double* __restrict__ ct
 #define CLC_ROWS_DEPTH 8
 #endif
 constexpr int ROWS_DEPTH = CLC_ROWS_DEPTH;
+// rows that carry z, in the kernels that also hold the LM controller (24 B per point in flight instead of 16, 14 moments instead
+// of 9: with 8 rows in flight hipcc parks 52-68 bytes per lane in scratch there)
+constexpr int ROWS_DEPTH_Z = 6;
 
-template <bool NT>
+template <bool NT, int STRIDE = ROW_DOUBLES>
 __device__ __forceinline__ v2d load_row(const double* __restrict__ xy, long long row, int lane) {
-  const v2d* p = reinterpret_cast<const v2d*>(xy + row * ROW_DOUBLES) + lane;
+  const v2d* p = reinterpret_cast<const v2d*>(xy + row * STRIDE) + lane;
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+// Rows of scans with points off the lidar plane (ROW_DOUBLES_Z per row): 64 z follow the 64 (x, y) pairs.
+template <bool NT>
+__device__ __forceinline__ double load_row_z(const double* __restrict__ xy, long long row, int lane) {
+  const double* p = xy + row * ROW_DOUBLES_Z + ROW_DOUBLES + lane;
   if (NT) return __builtin_nontemporal_load(p);
   return *p;
 }
@@ -320,6 +331,7 @@ __device__ __forceinline__ double load_desc_lane(const RowDesc* __restrict__ des
 template <bool WITH_LOSS>
 struct LmRows {
   static constexpr int NA = NACC;
+  static constexpr bool Z = false;
   const double& inv_lf2;  // set by get_pose (it may depend on options that arrive late)
   RowPlane q;
   RowMoments M;
@@ -332,6 +344,23 @@ struct LmRows {
   __device__ __forceinline__ void flush(double (&acc)[NACC]) { rows_flush<WITH_LOSS>(q, M, acc); }
 };
 
+// The same for rows that carry z (p.z != 0 somewhere in the array): 14 moments per scan (clc_rows.hpp, rows3_*).
+template <bool WITH_LOSS>
+struct LmRows3 {
+  static constexpr int NA = NACC;
+  static constexpr bool Z = true;
+  const double& inv_lf2;
+  RowPlane q;
+  RowMoments3 M;
+  __device__ __forceinline__ explicit LmRows3(const double& inv) : inv_lf2(inv) {}
+  __device__ __forceinline__ void begin_scan(const PoseU& P, double nx, double ny, double nz, double d, double s) {
+    rows_plane_setup(P.R, P.t, nx, ny, nz, d, s, q);
+    rows3_moments_reset<WITH_LOSS>(M);
+  }
+  __device__ __forceinline__ void point(double x, double y, double z, bool renorm) { rows3_point<WITH_LOSS>(q, inv_lf2, x, y, z, M, renorm); }
+  __device__ __forceinline__ void flush(double (&acc)[NACC]) { rows3_flush<WITH_LOSS>(q, M, acc); }
+};
+
 constexpr int NACC9 = 45;
 
 // Row A_k = kron([x, y, 1], n), b_k = -d (src/LaseCamCalCeres.cpp:144-158): A^T A = sum kron(b b^T, n n^T) and
@@ -340,6 +369,7 @@ constexpr int NACC9 = 45;
 // acc layout (as normal9_kernel): [bb(6: xx xy x yy y 1)] x [nn(6: 00 01 02 11 12 22)] then A^T b (9: b-major).
 struct Normal9Rows {
   static constexpr int NA = NACC9;
+  static constexpr bool Z = false;  // bar_p = (x, y, 1): the closed form never reads p.z (src/LaseCamCalCeres.cpp:147)
   double nx, ny, nz, md;
   double sxx, sxy, sx, syy, sy, s1;
   __device__ __forceinline__ void begin_scan(const PoseU&, double nx_, double ny_, double nz_, double d, double) {
@@ -370,7 +400,7 @@ struct Normal9Rows {
   }
 };
 
-template <class Policy, bool NT, int DEPTH = ROWS_DEPTH, class PoseFn>
+template <class Policy, bool NT, int DEPTH = ROWS_DEPTH, int STRIDE = ROW_DOUBLES, class PoseFn>
 __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __restrict__ xy_all,
                                                    const RowDesc* __restrict__ desc_all, long long r_begin_in,
                                                    long long r_end_in, const int lane, PoseFn get_pose,
@@ -379,10 +409,12 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
   // row — 64-bit compares would go through the vector unit)
   const long long r_begin = uniform_ll(r_begin_in);
   const int n = __builtin_amdgcn_readfirstlane((int)(r_end_in - r_begin_in));
-  const double* __restrict__ xy = xy_all + r_begin * ROW_DOUBLES;
+  static_assert(!Policy::Z || STRIDE == ROW_DOUBLES_Z, "z rows come with the 192-double stride");
+  const double* __restrict__ xy = xy_all + r_begin * STRIDE;
   const RowDesc* __restrict__ desc = desc_all + r_begin;
   v2d buf[DEPTH];
   double dbuf[DEPTH];
+  double zbuf[Policy::Z ? DEPTH : 1];
   // Prologue: DEPTH rows in flight, issued UNCONDITIONALLY from clamped row indices (the row arrays carry one padding
   // row, so even an empty run reads mapped memory).  As `if (u < n) load` each load sat in its own branch, and the
   // waits hipcc places at the joins made a wave stall on its first rows of points before it had issued the last ones —
@@ -392,7 +424,8 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
   for (int u = 0; u < DEPTH; ++u) {
     const int ru = u < n_last ? u : n_last;
     dbuf[u] = load_desc_lane(desc, ru, lane);
-    buf[u] = load_row<NT>(xy, ru, lane);
+    buf[u] = load_row<NT, STRIDE>(xy, ru, lane);
+    if constexpr (Policy::Z) zbuf[u] = load_row_z<NT>(xy, ru, lane);
   }
   PoseU P;
   if (!get_pose(P)) return false;  // after the prologue loads are in flight (see stream_tiles)
@@ -403,9 +436,12 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
       if (r >= n) break;
       const double dv = dbuf[u];
       const v2d v = buf[u];
+      double z = 0.0;
+      if constexpr (Policy::Z) z = zbuf[u];
       if (r + DEPTH < n) {
         dbuf[u] = load_desc_lane(desc, r + DEPTH, lane);
-        buf[u] = load_row<NT>(xy, r + DEPTH, lane);
+        buf[u] = load_row<NT, STRIDE>(xy, r + DEPTH, lane);
+        if constexpr (Policy::Z) zbuf[u] = load_row_z<NT>(xy, r + DEPTH, lane);
       }
       const int count = __builtin_amdgcn_readlane(__double2loint(dv), 5);  // RowDesc: double 5 = {count, first}
       const int first = __builtin_amdgcn_readlane(__double2hiint(dv), 5);
@@ -413,19 +449,27 @@ __device__ __forceinline__ bool stream_rows_policy(Policy& pol, const double* __
         if (r != 0) pol.flush(acc);
         pol.begin_scan(P, readlane_d(dv, 0), readlane_d(dv, 1), readlane_d(dv, 2), readlane_d(dv, 3), readlane_d(dv, 4));
       }
-      if (lane < count) pol.point(v[0], v[1], (u & 1) != 0);  // (the running product is renormalised on every second row)
+      if (lane < count) {  // (the running product is renormalised on every second row)
+        if constexpr (Policy::Z) pol.point(v[0], v[1], z, (u & 1) != 0);
+        else pol.point(v[0], v[1], (u & 1) != 0);
+      }
     }
   }
   if (n > 0) pol.flush(acc);
   return true;
 }
 
-template <bool WITH_LOSS, bool NT, int DEPTH = ROWS_DEPTH, class PoseFn>
+template <bool WITH_LOSS, bool NT, int DEPTH = ROWS_DEPTH, bool Z = false, class PoseFn>
 __device__ __forceinline__ bool stream_rows(const double* __restrict__ xy_all, const RowDesc* __restrict__ desc_all,
                                             long long r_begin_in, long long r_end_in, const int lane, PoseFn get_pose,
                                             const double& inv_lf2, double (&acc)[NACC]) {
-  LmRows<WITH_LOSS> pol(inv_lf2);
-  return stream_rows_policy<LmRows<WITH_LOSS>, NT, DEPTH>(pol, xy_all, desc_all, r_begin_in, r_end_in, lane, get_pose, acc);
+  if constexpr (Z) {
+    LmRows3<WITH_LOSS> pol(inv_lf2);
+    return stream_rows_policy<LmRows3<WITH_LOSS>, NT, DEPTH, ROW_DOUBLES_Z>(pol, xy_all, desc_all, r_begin_in, r_end_in, lane, get_pose, acc);
+  } else {
+    LmRows<WITH_LOSS> pol(inv_lf2);
+    return stream_rows_policy<LmRows<WITH_LOSS>, NT, DEPTH>(pol, xy_all, desc_all, r_begin_in, r_end_in, lane, get_pose, acc);
+  }
 }
 
 }  // namespace clc

@@ -335,6 +335,13 @@ class Solver:
         check(self._L.clc_debug_rows(self._h, C.byref(r), C.byref(n), C.byref(br), C.byref(bn)), "clc_debug_rows")
         return bool(r.value), n.value, bool(br.value), bn.value
 
+    def rows_carry_z(self):
+        """(single-problem rows, batched rows) carry z: some uploaded record has p.z != 0, so the rows are the 24-byte form
+        (64 z after the 64 (x, y) pairs of every row, 14 moments per scan) instead of the 16-byte one."""
+        r, n, br, bn = C.c_int(), C.c_longlong(), C.c_int(), C.c_longlong()
+        check(self._L.clc_debug_rows(self._h, C.byref(r), C.byref(n), C.byref(br), C.byref(bn)), "clc_debug_rows")
+        return r.value == 2, br.value == 2
+
     def debug_resident(self):
         """Resident ("lane") layout report of the uploaded batch -> (built, lanes per problem, largest points per lane,
         j-rows in all); built = the batched solver keeps every problem on chip for its whole solve (clc_resident.hpp)."""

@@ -140,8 +140,8 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
  * two tiles in flight per wave, 128 = clc_solve issues ONE launch per LM iteration (every workgroup
  * runs the controller on the previous launch's partial rows before it streams; needs 32 and 16 or 256),
  * 256 = row layout (every scan padded to rows of 64 points, 16-byte (x, y) stream + one 64-byte
- * descriptor per row, per-scan moment accumulation; used when every record has p.z == 0, else the
- * flags without it apply), 512 = row layout with equal row shares per wave whose boundaries are moved to
+ * descriptor per row, per-scan moment accumulation; arrays with some p.z != 0 keep 64 z per row as well,
+ * 24-byte stream, and run the lockstep batched solver), 512 = row layout with equal row shares per wave whose boundaries are moved to
  * the nearest scan start (instead of 3:2 old/young shares cut anywhere), 1024 = batched row
  * kernel in 256-thread workgroups (default: one wave per workgroup for batches of >= 8 problems per CU),
  * 2048 = batched solver: lockstep [evaluation, controller] launches per LM iteration even where the default

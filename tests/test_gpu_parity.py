@@ -205,8 +205,8 @@ def test_compact_layout_is_lossless_and_optional(sv, oracle_mod):
 def test_row_layout_matches_oracle_and_the_per_point_paths(sv, oracle_mod):
     """The row layout (every scan padded to rows of 64 points, per-scan moments expanded once per scan segment) against
     the oracle and the per-point layouts: ragged C1 scans (0..180 points: partial rows, empty poses), C5 board-edge terms
-    (single-record scans with un-normalised planes), a truncated array, loss on and off.  Records with p.z != 0 do not
-    qualify and silently keep the per-point layouts."""
+    (single-record scans with un-normalised planes), a truncated array, loss on and off.  (Records with p.z != 0 get rows
+    that carry z: tests/test_gpu_rows_z.py.)"""
     rng = np.random.default_rng(5)
     gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
     cases = []
@@ -233,11 +233,11 @@ def test_row_layout_matches_oracle_and_the_per_point_paths(sv, oracle_mod):
                         assert np.abs(a - b).max() <= 1e-11 * np.abs(H0).max() if a is H else np.abs(a - b).max() <= 1e-10 * np.abs(g0).max() + 1e-16
                     assert sv.eval(pose, with_loss=with_loss)[0] == c  # fixed lane -> row map: bitwise repeatable
         sv.set_launch(0, -1)
-    # z != 0: no row layout, same answers through the compact layout
+    # z != 0: the rows carry z (tests/test_gpu_rows_z.py); a small array still runs on the compact layout by default
     rec = cases[0].copy()
     rec[::7, 6] = 0.01
     sv.upload(rec)
-    assert not sv.debug_rows()[0] and _layout(sv)[0] == 1
+    assert sv.debug_rows()[0] and sv.rows_carry_z()[0] and _layout(sv)[0] == 1
     c0, g0, H0 = oracle_mod.evaluate_ne(rec, X0)
     c, g, H = sv.eval(X0)
     assert abs(c - c0) <= 1e-11 * abs(c0) and np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()

@@ -1,0 +1,171 @@
+"""GPU tests of the row layout for scan points OFF the lidar plane (p.z != 0).
+
+Oberserve::points is std::vector<Eigen::Vector3d> (include/LaseCamCalCeres.h:22); the reference's own scan conversion writes
+z = 0 (src/utilities.cpp:198-215), a caller of the Vector3d interface need not.  Such arrays keep the row layout with a
+third 8-byte value per point (rows of 192 doubles, 14 moments per scan: csrc/clc_rows.hpp rows3_*): evaluation, the step
+chain, the lockstep batched solver and the closed-form normal equations (which never read z, src/LaseCamCalCeres.cpp:147)
+all run on it.  Compared with the oracle's per-residual evaluation / DENSE_QR solve and with the per-point layouts."""
+import numpy as np
+import pytest
+
+import camlasercalibratool_amd as clc
+from camlasercalibratool_amd import simdata as sd
+
+pytestmark = pytest.mark.gpu
+
+X0 = sd.pose7_from_T(np.eye(4))
+T_TOL = 1e-6
+COST_TOL = 1e-8
+ROWS = 256 | 32           # row layout forced (below 2e5 observations the default keeps the per-point layout)
+BASE = 2 | 16 | 32 | 128 | 256 | 512
+
+
+@pytest.fixture(scope="module")
+def sv():
+    s = clc.Solver(0)
+    yield s
+    s.close()
+
+
+def _dT(a, b):
+    return np.abs(sd.T_from_pose7(a) - sd.T_from_pose7(b)).max()
+
+
+def _off_plane(rec, seed, sigma=0.05, every=1):
+    """The same scans with the points lifted off the lidar plane (a tilted / warped scan plane)."""
+    rng = np.random.default_rng(seed)
+    out = rec.copy()
+    out[::every, 6] = rng.normal(size=out[::every].shape[0]) * sigma
+    return out
+
+
+def test_rows_with_z_match_oracle_and_the_per_point_paths(sv, oracle_mod):
+    """Ragged C1 scans, C5 board-edge terms, a truncated array; every launch shape of the row kernel, loss on and off."""
+    rng = np.random.default_rng(5)
+    gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    cases = [
+        _off_plane(clc.flatten_observations(sd.GenerateSimData(3, n_poses=50, noise_sigma=0.02), False), 1),
+        _off_plane(clc.flatten_observations(sd.sim_board_edges(5, n_poses=300, pts_per_pose=137, noise_sigma=0.002), True, True), 2, every=7),
+        _off_plane(clc.flatten_observations(sd.sim_fixed_count(8, 120, 500, 0.01), False)[:57311], 3, sigma=0.3),
+    ]
+    for rec in cases:
+        sv.set_launch(0, -1)
+        sv.upload(rec)
+        ok, n_rows, _, _ = sv.debug_rows()
+        assert ok and sv.rows_carry_z()[0] and n_rows >= (rec.shape[0] + 63) // 64
+        assert not sv.debug_resident_single()[0]  # the on-chip lane layout holds (x, y) only
+        for pose in (X0, oracle_mod.pose_plus(gt, rng.normal(size=6) * 0.03)):
+            for with_loss in (True, False):
+                c0, g0, H0 = oracle_mod.evaluate_ne(rec, pose, with_loss=with_loss)
+                sv.set_launch(0, 2 | 16 | 32)  # compact per-point layout
+                c2, g2, H2 = sv.eval(pose, with_loss=with_loss)
+                for grid, flags in ((0, ROWS), (0, ROWS | 512), (5, ROWS), (0, 256), (3, 256 | 4)):
+                    sv.set_launch(grid, flags)
+                    c, g, H = sv.eval(pose, with_loss=with_loss)
+                    for b in (c0, c2):
+                        assert abs(c - b) <= 1e-11 * abs(b)
+                    for b in (H0, H2):
+                        assert np.abs(H - b).max() <= 1e-11 * np.abs(H0).max()
+                    for b in (g0, g2):
+                        assert np.abs(g - b).max() <= 1e-10 * np.abs(g0).max() + 1e-16
+                    assert sv.eval(pose, with_loss=with_loss)[0] == c  # fixed lane -> row map: bitwise repeatable
+    sv.set_launch(0, -1)
+
+
+def test_rows_with_z_differ_from_the_flat_answer(sv, oracle_mod):
+    """Guard against a kernel that silently drops z: the same scans with and without the lift give different sums."""
+    rec0 = clc.flatten_observations(sd.sim_fixed_count(4, 40, 300, 0.01), False)
+    rec = _off_plane(rec0, 9, sigma=0.2)
+    sv.set_launch(0, ROWS)
+    sv.upload(rec0)
+    assert sv.debug_rows()[0] and not sv.rows_carry_z()[0]
+    cf, gf, Hf = sv.eval(X0)
+    sv.upload(rec)
+    assert sv.rows_carry_z()[0]
+    c, g, H = sv.eval(X0)
+    c0, g0, H0 = oracle_mod.evaluate_ne(rec, X0)
+    assert abs(c - c0) <= 1e-11 * abs(c0) and abs(c - cf) > 1e-3 * abs(cf)
+    assert np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max() and np.abs(H - Hf).max() > 1e-3 * np.abs(Hf).max()
+    sv.upload(rec0)  # and back: the flag follows the data
+    assert not sv.rows_carry_z()[0] and sv.eval(X0)[0] == cf
+    sv.set_launch(0, -1)
+
+
+@pytest.mark.parametrize("use_loss", [1, 0])
+def test_solve_on_rows_with_z(sv, oracle_mod, use_loss):
+    """clc_solve as the step chain on rows that carry z (forced below 2e5 observations, the default above)."""
+    S = sd.sim_fixed_count(6, 60, 500, noise_sigma=0.01)
+    rec = _off_plane(clc.flatten_observations(S, False), 4, sigma=0.02)
+    o, oo = clc.default_options(), oracle_mod.default_options()
+    o.use_loss = oo.use_loss = use_loss
+    ref = oracle_mod.solve(rec, X0, options=oo, linear_solver="qr")
+    sv.upload(rec)
+    results = []
+    for flags in (ROWS, ROWS | 4, -1):
+        sv.set_launch(0, flags)
+        r = sv.solve(X0, o)
+        assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations, flags
+        assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL, flags
+        results.append(r)
+    sv.set_launch(0, ROWS)
+    assert np.array_equal(results[0].pose, sv.solve(X0, o).pose)  # repeatable bit for bit
+    sv.set_launch(0, -1)
+
+
+def test_solve_default_path_beyond_2e5_observations_with_z(sv, oracle_mod):
+    """2.5e5 observations with z: the default flags stream the rows (24 B per point) through the step chain."""
+    S = sd.sim_fixed_count(7, 500, 500, noise_sigma=0.01)
+    rec = _off_plane(clc.flatten_observations(S, False), 5, sigma=0.01)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    assert sv.debug_rows()[0] and sv.rows_carry_z()[0]
+    r = sv.solve(X0)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations
+    assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    ms, passes = sv.time_steps(X0, 2, 4)
+    assert ms > 0 and passes >= 5
+
+
+def test_closed_form_ignores_z_like_the_reference(sv, oracle_mod):
+    """bar_p = (pt.x, pt.y, 1) (src/LaseCamCalCeres.cpp:147): the 9x9 normal equations on rows that carry z equal those
+    of the flat scans."""
+    S = sd.sim_fixed_count(3, 80, 300, noise_sigma=0.005)
+    rec0 = clc.flatten_observations(S, False)
+    rec = _off_plane(rec0, 6, sigma=0.1)
+    for flags in (ROWS, -1):
+        sv.set_launch(0, flags)
+        sv.upload(rec0)
+        T0, u0, s0 = sv.closed_form()
+        sv.upload(rec)
+        T1, u1, s1 = sv.closed_form()
+        To, uo, so = oracle_mod.closed_form(rec)
+        assert u0 == u1 == uo
+        assert np.abs(T1 - T0).max() <= 1e-12 and np.abs(T1 - To).max() <= 1e-9
+    sv.set_launch(0, -1)
+
+
+def test_batched_problems_with_z(sv, oracle_mod):
+    """A batch with points off the lidar plane: no lane layout, no whole-solve kernel; the lockstep launches run on rows that
+    carry z (one wave per problem and 256-thread workgroups) and agree with the per-point layouts and with the oracle."""
+    P = 12
+    rec, off, x0, gt = sd.sim_shard_records(31, 0, P, 12, 97, 0.01)
+    rec = _off_plane(rec, 8, sigma=0.02)
+    sv.set_launch(0, -1)
+    sv.upload_batched(rec, off)
+    assert sv.debug_rows()[2] and sv.rows_carry_z()[1] and not sv.debug_resident()[0]
+    p1, s1 = sv.solve_batched(x0)
+    sv.set_launch(0, BASE | 2048 | 1024)  # lockstep, 256-thread workgroups, serial controller
+    p2, s2 = sv.solve_batched(x0)
+    sv.set_launch(0, 2 | 16 | 32)         # compact per-point layout
+    p3, s3 = sv.solve_batched(x0)
+    sv.set_launch(0, -1)
+    for k in range(P):
+        ref = oracle_mod.solve(rec[off[k]:off[k + 1]], x0[k], linear_solver="qr")
+        for p, s in ((p1, s1), (p2, s2), (p3, s3)):
+            assert s[k].termination == ref.summary.termination and s[k].num_iterations == ref.summary.num_iterations, k
+            assert _dT(p[k], ref.pose) <= T_TOL and abs(s[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
+    # a later flat batch on the same handle goes back on chip
+    rec0, off0, x00, _ = sd.sim_shard_records(32, 0, P, 12, 97, 0.01)
+    sv.upload_batched(rec0, off0)
+    assert not sv.rows_carry_z()[1] and sv.debug_resident()[0]

@@ -22,15 +22,17 @@ def shim():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", src, "-o", out])
     L = C.CDLL(out)
     L.shim_rows_eval.restype = C.c_long
+    L.shim_rows3_eval.restype = C.c_long
     L.shim_log_mant_exp.restype = C.c_double
     L.shim_log_mant_exp.argtypes = [C.c_double, C.c_int]
     return L
 
 
-def _rows_eval(shim, rec, pose, with_loss=True, lf=0.05, rows_per_wave=0):
+def _rows_eval(shim, rec, pose, with_loss=True, lf=0.05, rows_per_wave=0, with_z=False):
     out = np.empty(28)
     rec = np.ascontiguousarray(rec)
-    n_rows = shim.shim_rows_eval(rec.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(rec.shape[0]),
+    fn = shim.shim_rows3_eval if with_z else shim.shim_rows_eval
+    n_rows = fn(rec.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(rec.shape[0]),
                                  np.ascontiguousarray(pose).ctypes.data_as(C.POINTER(C.c_double)), C.c_int(int(with_loss)),
                                  C.c_double(lf), C.c_long(rows_per_wave), out.ctypes.data_as(C.POINTER(C.c_double)))
     assert n_rows >= 0
@@ -96,3 +98,38 @@ def test_moment_form_far_outliers_do_not_overflow_the_cost_product(shim, oracle_
     c0, g0, H0 = oracle.evaluate_ne(rec, pose)
     assert np.isfinite(c) and abs(c - c0) <= 1e-12 * abs(c0)
     assert np.abs(H - H0).max() <= 1e-10 * np.abs(H0).max()
+
+
+@pytest.mark.parametrize("with_loss", [True, False])
+@pytest.mark.parametrize("rows_per_wave", [0, 1, 3])
+def test_moment_form_with_points_off_the_lidar_plane(shim, oracle_mod, with_loss, rows_per_wave):
+    """p.z != 0 (Oberserve::points is a vector of Vector3d): the 14-moment form against the per-residual evaluation,
+    and on z = 0 data against the 9-moment form."""
+    import oracle
+    rng = np.random.default_rng(11)
+    S = sd.GenerateSimData(7, n_poses=30, noise_sigma=0.02)
+    rec = oracle.flatten(S, False, False).copy()
+    gt = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    flat = rec.copy()
+    rec[:, 6] = rng.normal(size=rec.shape[0]) * 0.3
+    for pose in (gt, sd.pose7_from_T(np.eye(4)), _rand_pose(rng), oracle.pose_plus(gt, rng.normal(size=6) * 0.01)):
+        c, g, H, _ = _rows_eval(shim, rec, pose, with_loss, rows_per_wave=rows_per_wave, with_z=True)
+        c0, g0, H0 = oracle.evaluate_ne(rec, pose, with_loss=with_loss)
+        assert abs(c - c0) <= 1e-12 * abs(c0)
+        assert np.abs(H - H0).max() <= 1e-11 * np.abs(H0).max()
+        assert np.abs(g - g0).max() <= 1e-11 * max(np.abs(g0).max(), 1e-3 * np.sqrt(np.abs(H0).max() * abs(c0)))
+        cz, gz, Hz, _ = _rows_eval(shim, flat, pose, with_loss, rows_per_wave=rows_per_wave, with_z=True)
+        cf, gf, Hf, _ = _rows_eval(shim, flat, pose, with_loss, rows_per_wave=rows_per_wave)
+        assert abs(cz - cf) <= 1e-13 * abs(cf) and np.abs(Hz - Hf).max() <= 1e-13 * np.abs(Hf).max()
+        assert np.abs(gz - gf).max() <= 1e-12 * max(np.abs(gf).max(), 1e-3 * np.sqrt(np.abs(Hf).max() * abs(cf)))
+
+
+def test_shim_rows_eval_refuses_z(shim):
+    rec = np.zeros((3, 8))
+    rec[:, 0] = 1.0
+    rec[:, 7] = 1.0
+    rec[1, 6] = 0.5
+    out = np.empty(28)
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    assert shim.shim_rows_eval(rec.ctypes.data_as(C.POINTER(C.c_double)), C.c_long(3), pose.ctypes.data_as(C.POINTER(C.c_double)),
+                               C.c_int(1), C.c_double(0.05), C.c_long(0), out.ctypes.data_as(C.POINTER(C.c_double))) == -1
