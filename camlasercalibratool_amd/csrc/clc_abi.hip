@@ -22,6 +22,7 @@
 #include "clc_host.hpp"
 #include "clc_kernels.hpp"
 #include "clc_resident.hpp"
+#include "clc_coop.hpp"
 
 namespace {
 
@@ -201,6 +202,15 @@ struct clc_handle {
   long long* d_prob_row = nullptr;  // [P+1] first row of every problem
   // resident ("lane") layouts (clc_resident.hpp): of the batched problems, and of a single problem small enough for one workgroup
   ResLayout bres, sres;
+  // cooperative whole-GPU solve of one problem (clc_coop.hpp): the problem's lane layout in 256 chunks, the exchange boards, the
+  // next free pass tag; disabled on the handle after a launch that timed out (the step chain takes over)
+  ResLayout cres;
+  clc::CoopBoard* d_board = nullptr;
+  unsigned int coop_tag = 1;
+  int coop_checked = 0;  // 0: co-residency not checked yet, 1: 256 workgroups fit the device, -1: they do not
+  bool coop_disabled = false;
+  int coop_aborts = 0;
+  long long coop_solves = 0;
   // single-problem resident solve: start pose in / result out through page-locked, device-mapped host memory
   double* h_spose = nullptr;          // [7] host view
   double* d_spose = nullptr;          // device view of the same allocation
@@ -464,6 +474,7 @@ struct LayoutTargets {
   long long** d_prob_row;  // nullptr for the single-problem array
   ResLayout* res = nullptr;  // also build the on-chip resident ("lane") layout (clc_resident.hpp) into this
   bool* rows_z = nullptr;    // out: the rows carry z
+  ResLayout* coop = nullptr; // single problem only: its lane layout in COOP_WGS chunks (clc_coop.hpp)
 };
 
 // Resident layout limits: what the instantiations of resident_solve_kernel hold per lane (registers + LDS).
@@ -475,7 +486,7 @@ constexpr int kResPR256 = 23, kResPL256 = 19, kResPR512 = 4, kResPL512 = 18;
 // (points per lane of every problem, on the device), offsets (O(P) on the host), lane descriptors + j-major point rows.
 // Leaves L.ok false — and the streaming layouts in charge — when some problem does not fit a workgroup.
 int build_resident(clc_handle* h, ResLayout& L, int first_try, const double* d_aos, long long n, size_t P, size_t G,
-                   const long long* d_rec_off, const unsigned int* d_gid, const long long* d_starts) {
+                   const long long* d_rec_off, const unsigned int* d_gid, const long long* d_starts, int max_ppl_override = 0) {
   L.ok = false;
   L.lanes = 0;
   L.max_ppl = 0;
@@ -487,11 +498,11 @@ int build_resident(clc_handle* h, ResLayout& L, int first_try, const double* d_a
   CLC_HIP(bfail.alloc(1));
   std::vector<unsigned int> ppl(P);
   int lanes = 0;
-  for (int nl = first_try; nl <= 512 && lanes == 0; nl *= 2) {
+  for (int nl = first_try; nl <= (max_ppl_override > 0 ? first_try : 512) && lanes == 0; nl *= 2) {
     unsigned int failed = 0;
     CLC_HIP(hipMemsetAsync(bfail.p, 0, sizeof(unsigned int), h->stream));
     hipLaunchKernelGGL(clc::res_plan_kernel, dim3((unsigned)((P + threads - 1) / threads)), dim3(threads), 0, h->stream, d_rec_off,
-                       d_gid, d_starts, (long long)P, n, (long long)G, nl, nl == 256 ? kResPR256 + kResPL256 : kResPR512 + kResPL512, bppl.p, bfail.p);
+                       d_gid, d_starts, (long long)P, n, (long long)G, nl, max_ppl_override > 0 ? max_ppl_override : (nl == 256 ? kResPR256 + kResPL256 : kResPR512 + kResPL512), bppl.p, bfail.p);
     CLC_HIP(hipGetLastError());
     CLC_HIP(hipMemcpyAsync(&failed, bfail.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     CLC_HIP(hipMemcpyAsync(ppl.data(), bppl.p, sizeof(unsigned int) * P, hipMemcpyDeviceToHost, h->stream));
@@ -642,6 +653,20 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
       // batches: 256 lanes (two problems per CU) unless flag 8192; a single problem: 512 lanes (it has its CU to itself)
       const int first_try = (T.d_prob_row == nullptr || (h->launch_flags & clc::FLAG_RESIDENT_WG512) != 0) ? 512 : 256;
       rc = build_resident(h, *T.res, first_try, d_aos, n, P, G, broff.p, bgid.p, bstarts.p);
+      if (rc != CLC_OK) return rc;
+    }
+  }
+  if (T.coop != nullptr) {
+    T.coop->ok = false;
+    if (!any_z && P == 1 && h->num_cus >= clc::COOP_WGS) {
+      // the one problem in COOP_WGS chunks of equal record counts (a chunk may begin and end inside a scan: res_scan_extent)
+      std::vector<long long> chunk(clc::COOP_WGS + 1);
+      for (int c = 0; c <= clc::COOP_WGS; ++c) chunk[c] = (long long)((__int128)n * c / clc::COOP_WGS);
+      DevBuf<long long> bchunk(&h->pool);
+      CLC_HIP(bchunk.alloc(chunk.size()));
+      CLC_HIP(hipMemcpyAsync(bchunk.p, chunk.data(), chunk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+      CLC_HIP(hipStreamSynchronize(h->stream));
+      rc = build_resident(h, *T.coop, clc::COOP_NL, d_aos, n, (size_t)clc::COOP_WGS, G, bchunk.p, bgid.p, bstarts.p, clc::COOP_PR + clc::COOP_PL);
       if (rc != CLC_OK) return rc;
     }
   }
@@ -854,7 +879,7 @@ void clc_destroy(clc_handle* h) {
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_block, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
                   h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results,
-                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->bres.d_xy, h->bres.d_desc, h->bres.d_row, h->sres.d_xy, h->sres.d_desc, h->sres.d_row, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
+                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->bres.d_xy, h->bres.d_desc, h->bres.d_row, h->sres.d_xy, h->sres.d_desc, h->sres.d_row, h->cres.d_xy, h->cres.d_desc, h->cres.d_row, h->d_board, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->pool.clear();
@@ -917,6 +942,7 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
   h->compact_ok = false;
   h->rows_ok = false;
   h->sres.ok = false;
+  h->cres.ok = false;
   h->split_grid = -1;
   int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
   if (rc != CLC_OK) return rc;
@@ -928,7 +954,9 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
                            &h->d_rxy, &h->rxy_cap_bytes, &h->d_rdesc, &h->rdesc_cap_bytes, &h->n_rows, &h->rows_ok, nullptr,
                            // a problem one workgroup can hold (<= 512 lanes x 22 points) also gets the lane layout: clc_solve then runs
                            // its whole LM loop in ONE single-workgroup launch from registers + LDS (solve_resident_single)
-                           n <= (size_t)512 * (kResPR512 + kResPL512) ? &h->sres : nullptr, &h->rows_z};
+                           n <= (size_t)512 * (kResPR512 + kResPL512) ? &h->sres : nullptr, &h->rows_z,
+                           // larger ones, up to 256 x 512 x 16 points, are dealt to 256 workgroups: the cooperative solve (clc_coop.hpp)
+                           (n > (size_t)512 * (kResPR512 + kResPL512) && n <= (size_t)clc::COOP_WGS * clc::COOP_NL * (clc::COOP_PR + clc::COOP_PL)) ? &h->cres : nullptr};
   return build_layouts(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, T);
 }
 
@@ -1335,6 +1363,97 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
   return CLC_OK;
 }
 
+// clc_solve as ONE launch of 256 co-resident workgroups that keep the problem on chip (clc_coop.hpp).  Returns kCoopFallback when
+// the path cannot be used (device too small, or the launch timed out in its exchange): the caller runs the step chain instead.
+constexpr int kCoopFallback = -1000;
+int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summary* summary, clc_iteration* trace, int trace_cap,
+               std::chrono::steady_clock::time_point t0) {
+  if (h->coop_checked == 0) {
+    int a = 0, b = 0;
+    const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, clc::coop_solve_kernel<true, false>, clc::COOP_NL, 0);
+    const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, clc::coop_solve_kernel<false, false>, clc::COOP_NL, 0);
+    h->coop_checked = (e1 == hipSuccess && e2 == hipSuccess && a >= 1 && b >= 1 && h->num_cus >= clc::COOP_WGS) ? 1 : -1;
+    (void)hipGetLastError();
+  }
+  if (h->coop_checked < 0) return kCoopFallback;
+  if (!h->d_board) {
+    CLC_HIP(hipMalloc(&h->d_board, sizeof(clc::CoopBoard)));
+    CLC_HIP(hipMemsetAsync(h->d_board, 0, sizeof(clc::CoopBoard), h->stream));
+    h->coop_tag = 1;
+  }
+  const unsigned int passes = (unsigned int)opt.max_num_iterations + 4u;
+  if (h->coop_tag > 0xFFFFFFFFu - passes - 8u) {  // the 32-bit pass tags are used up: start over on clean boards
+    CLC_HIP(hipMemsetAsync(h->d_board, 0, sizeof(clc::CoopBoard), h->stream));
+    h->coop_tag = 1;
+  }
+  const bool want_trace = trace != nullptr && trace_cap > 0;
+  if (want_trace) {
+    const int rc = ensure_trace(h, opt.max_num_iterations + 8);
+    if (rc != CLC_OK) return rc;
+  }
+  const bool timed = opt.profile_events == 2;  // HIP event pair around the one launch -> clc_summary.eval_kernel_ms
+  if (timed) {
+    const int rc = ensure_events(h, 2);
+    if (rc != CLC_OK) return rc;
+  }
+  int32_t* h_done = reinterpret_cast<int32_t*>(h->h_spose + 7);  // completion flag behind the pose (same pinned allocation)
+  int32_t* d_done = reinterpret_cast<int32_t*>(h->d_spose + 7);
+  __atomic_store_n(h_done, 0, __ATOMIC_RELAXED);
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  clc::Pose7 p0;
+  for (int i = 0; i < 7; ++i) p0.v[i] = pose[i];
+  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->cres.d_row);
+  const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->cres.d_desc);
+  clc_iteration* d_trace = want_trace ? h->d_trace : nullptr;
+  const int d_cap = want_trace ? h->trace_cap : 0;
+  const unsigned int tag0 = h->coop_tag;
+  h->coop_tag += passes;
+  if (timed) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
+  if (opt.use_loss)
+    hipLaunchKernelGGL((clc::coop_solve_kernel<true, false>), dim3(clc::COOP_WGS), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
+                       h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
+  else
+    hipLaunchKernelGGL((clc::coop_solve_kernel<false, false>), dim3(clc::COOP_WGS), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
+                       h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
+  CLC_HIP(hipGetLastError());
+  if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
+  {  // the kernel raises the flag (system-scope release) after the outcome is written; bounded like solve_resident_single
+    long long spins = 0;
+    const auto t_spin = std::chrono::steady_clock::now();
+    while (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == 0) {
+      if ((++spins & 0xFFFF) == 0) {
+        if (hipStreamQuery(h->stream) != hipErrorNotReady) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 30.0) break;
+      }
+    }
+    if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) != clc::COOP_DONE_OK || want_trace || timed) CLC_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) != clc::COOP_DONE_OK) {
+    // an exchange timed out (a workgroup was not resident in time): nothing was written; never again on this handle
+    h->coop_disabled = true;
+    ++h->coop_aborts;
+    return kCoopFallback;
+  }
+  ++h->coop_solves;
+  *summary = *h->h_ssummary;
+  for (int i = 0; i < 7; ++i) pose[i] = h->h_spose[i];
+  if (want_trace) {
+    const int n = std::min(std::min(summary->num_iterations + 1, trace_cap), h->trace_cap);
+    if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  summary->eval_kernel_ms = 0.0;
+  summary->eval_kernel_launches = 0;
+  if (timed) {
+    float ms = 0.f;
+    CLC_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    summary->eval_kernel_ms = (double)ms;
+    summary->eval_kernel_launches = 1;
+  }
+  summary->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve: non-finite result");
+  return CLC_OK;
+}
+
 }  // namespace
 
 // Profiling hook (not part of include/clc.h): one default clc_solve through the step kernel with HIP events on the
@@ -1380,6 +1499,11 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // a problem one workgroup holds: the whole solve in one single-workgroup launch (default flags only: the explicit flag
   // sets select the step chain / launch pair the bit-identity tests compare; profile_events = 1 asks for per-pass events)
   if (h->sres.ok && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
+  // a problem the 256 CUs hold together: the whole solve in one launch of 256 co-resident workgroups (same conditions)
+  if (h->cres.ok && !h->coop_disabled && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1) {
+    const int rc = solve_coop(h, opt, pose, summary, trace, trace_cap, t0);
+    if (rc != kCoopFallback) return rc;
+  }
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;
@@ -2297,6 +2421,18 @@ int clc_debug_resident_single(clc_handle* h, int* ok, int* lanes, int* max_ppl) 
   return CLC_OK;
 }
 
+// The cooperative whole-GPU solve (clc_coop.hpp): layout built, largest points per lane, solves run on it, launches that timed out,
+// disabled on this handle.
+extern "C" int clc_debug_coop(clc_handle* h, int* ok, int* max_ppl, long long* solves, int* aborts, int* disabled) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_coop: NULL handle");
+  if (ok) *ok = h->cres.ok ? 1 : 0;
+  if (max_ppl) *max_ppl = h->cres.max_ppl;
+  if (solves) *solves = h->coop_solves;
+  if (aborts) *aborts = h->coop_aborts;
+  if (disabled) *disabled = (h->coop_disabled || h->coop_checked < 0) ? 1 : 0;
+  return CLC_OK;
+}
+
 int clc_debug_layout(clc_handle* h, int* compact, long long* n_groups, int* bcompact, long long* bn_groups) {
   if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_layout: NULL handle");
   if (compact) *compact = h->compact_ok ? 1 : 0;
@@ -2388,6 +2524,14 @@ extern "C" int clc_debug_res_stamps(void* dst, size_t bytes) {
   void* p = nullptr;
   if (hipGetSymbolAddress(&p, HIP_SYMBOL(clc::clc_res_stamp_buf)) != hipSuccess) return CLC_ERR_HIP;
   return hipMemset(p, 0, sizeof(clc::clc_res_stamp_buf)) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
+}
+extern "C" int clc_debug_coop_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(clc::clc_coop_stamp_buf)) bytes = sizeof(clc::clc_coop_stamp_buf);
+  if (hipDeviceSynchronize() != hipSuccess) return CLC_ERR_HIP;
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(clc::clc_coop_stamp_buf), bytes) != hipSuccess) return CLC_ERR_HIP;
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(clc::clc_coop_stamp_buf)) != hipSuccess) return CLC_ERR_HIP;
+  return hipMemset(p, 0, sizeof(clc::clc_coop_stamp_buf)) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
 }
 extern "C" int clc_debug_res_ctrl_stamps(void* dst, size_t bytes) {
   if (bytes > sizeof(clc::clc_res_stamp_ctrl)) bytes = sizeof(clc::clc_res_stamp_ctrl);

@@ -36,13 +36,24 @@ struct ResLane {   // per lane of a problem's workgroup
   int32_t cnt;     // valid points of the lane, <= ppl; 0: idle lane
 };
 
-// scans [g0, g1) of problem p (a problem never shares a scan with its neighbours: mark_problem_starts_kernel)
+// scans [g0, g1) that problem p = records [r0, r1) touches.  A batched problem never shares a scan with its neighbours
+// (mark_problem_starts_kernel); the chunks of ONE problem dealt to the workgroups of the cooperative solve (clc_coop.hpp) may
+// begin and end inside a scan: res_scan_extent() clamps a scan to the chunk, and the two parts are simply two lanes' worth of
+// points of the same plane.
 __device__ __forceinline__ void res_problem_scans(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
-                                                  long long p, long long n, long long n_groups, long long& g0, long long& g1) {
-  const long long r0 = rec_off[p], r1 = rec_off[p + 1];
+                                                  long long p, long long& r0, long long& r1, long long& g0, long long& g1) {
+  r0 = rec_off[p];
+  r1 = rec_off[p + 1];
   if (r1 <= r0) { g0 = g1 = 0; return; }
   g0 = gid[r0];
-  g1 = r1 < n ? (long long)gid[r1] : n_groups;
+  g1 = (long long)gid[r1 - 1] + 1;
+}
+__device__ __forceinline__ void res_scan_extent(const long long* __restrict__ starts, long long g, long long r0, long long r1,
+                                                long long& lo, long long& hi) {
+  lo = starts[g];
+  hi = starts[g + 1];
+  lo = lo < r0 ? r0 : lo;
+  hi = hi > r1 ? r1 : hi;
 }
 
 // One thread per problem: ppl[p] = the smallest points-per-lane (<= max_ppl) with sum_s ceil(c_s / ppl) <= n_lanes;
@@ -52,9 +63,9 @@ __global__ void res_plan_kernel(const long long* __restrict__ rec_off, const uns
                                 int n_lanes, int max_ppl, unsigned int* __restrict__ ppl_out, unsigned int* __restrict__ fail) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_problems) return;
-  long long g0, g1;
-  res_problem_scans(rec_off, gid, p, n, n_groups, g0, g1);
-  const long long n_p = rec_off[p + 1] - rec_off[p];
+  long long r0, r1, g0, g1;
+  res_problem_scans(rec_off, gid, p, r0, r1, g0, g1);
+  const long long n_p = r1 - r0;
   unsigned int ppl = 0;
   if (n_p > 0) {
     bool found = false;
@@ -63,7 +74,11 @@ __global__ void res_plan_kernel(const long long* __restrict__ rec_off, const uns
       if (lo < 1) lo = 1;
       for (long long c = lo; c <= max_ppl && !found; ++c) {
         long long lanes = 0;
-        for (long long g = g0; g < g1 && lanes <= n_lanes; ++g) lanes += (starts[g + 1] - starts[g] + c - 1) / c;
+        for (long long g = g0; g < g1 && lanes <= n_lanes; ++g) {
+          long long a, b;
+          res_scan_extent(starts, g, r0, r1, a, b);
+          lanes += (b - a + c - 1) / c;
+        }
         if (lanes <= n_lanes) { ppl = (unsigned int)c; found = true; }
       }
     }
@@ -83,11 +98,15 @@ __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict_
   const int t = threadIdx.x;
   const unsigned int row0 = res_row[p];
   const int ppl = (int)(res_row[p + 1] - row0);
-  long long g0, g1;
-  res_problem_scans(rec_off, gid, p, n, n_groups, g0, g1);
+  long long r0, r1, g0, g1;
+  res_problem_scans(rec_off, gid, p, r0, r1, g0, g1);
   const int ns = ppl > 0 ? (int)(g1 - g0) : 0;  // <= NL (res_plan_kernel)
   int L = 0;
-  if (t < ns) L = (int)((starts[g0 + t + 1] - starts[g0 + t] + ppl - 1) / ppl);
+  if (t < ns) {
+    long long a, b;
+    res_scan_extent(starts, g0 + t, r0, r1, a, b);
+    L = (int)((b - a + ppl - 1) / ppl);
+  }
   lane_first[t + 1] = L;
   if (t == 0) lane_first[0] = 0;
   __syncthreads();
@@ -109,7 +128,9 @@ __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict_
       if (lane_first[mid] <= t) lo = mid; else hi = mid;
     }
     const int i = t - lane_first[lo], Ls = lane_first[lo + 1] - lane_first[lo];
-    const long long s0 = starts[g0 + lo], c = starts[g0 + lo + 1] - s0;
+    long long s0, s1;
+    res_scan_extent(starts, g0 + lo, r0, r1, s0, s1);
+    const long long c = s1 - s0;
     const long long q = c / Ls, r = c % Ls;
     dl.gid = (int32_t)(g0 + lo);
     dl.cnt = (int32_t)(q + (i < r ? 1 : 0));

@@ -356,6 +356,14 @@ class Solver:
         check(self._L.clc_debug_resident_single(self._h, C.byref(ok), C.byref(lanes), C.byref(ppl)), "clc_debug_resident_single")
         return bool(ok.value), lanes.value, ppl.value
 
+    def debug_coop(self):
+        """Cooperative whole-GPU solve of the single-problem array (csrc/clc_coop.hpp) -> (layout built, largest points per
+        lane, solves run on it, launches that timed out, disabled on this handle)."""
+        ok, ppl, solves, aborts, off = C.c_int(), C.c_int(), C.c_longlong(), C.c_int(), C.c_int()
+        self._L.clc_debug_coop.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        check(self._L.clc_debug_coop(self._h, C.byref(ok), C.byref(ppl), C.byref(solves), C.byref(aborts), C.byref(off)), "clc_debug_coop")
+        return bool(ok.value), ppl.value, solves.value, aborts.value, bool(off.value)
+
     def debug_wave_split(self, grid: int):
         """Wave split table of the row layout for `grid` workgroups -> (split[grid * 8 + 1], first[n_rows])."""
         n_rows = self.debug_rows()[1]

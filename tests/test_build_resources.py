@@ -45,7 +45,7 @@ def test_hot_kernels_do_not_spill(usage):
     hot = (_find(usage, "11eval_kernel") + _find(usage, "9lm_kernel") + _find(usage, "19batched_eval_kernel") +
            _find(usage, "17batched_lm_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "15line_fit_kernel") +
            _find(usage, "14normal9_kernel") + _find(usage, "11step_kernel") + _find(usage, "20batched_solve_kernel") +
-           _find(usage, "21resident_solve_kernel"))
+           _find(usage, "21resident_solve_kernel") + _find(usage, "17coop_solve_kernel"))
     for k in hot:
         if "21resident_solve_kernel" in k:
             # The 256-thread form keeps 92 VGPRs of scan points alive across the wavefront controller: hipcc parks a few of
@@ -66,3 +66,11 @@ def test_default_evaluation_kernel_occupancy(usage):
     assert usage[k]["TotalSGPRs"] <= 102
     for k in _find(usage, "19batched_eval_kernel") + _find(usage, "11step_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "20batched_solve_kernel") + _find(usage, "21resident_solve_kernel"):
         assert usage[k]["Occupancy"] >= 2, (k, usage[k])  # the controller inside must not cost the streaming loop its occupancy
+
+
+def test_cooperative_kernel_owns_its_cu(usage):
+    """coop_solve_kernel (csrc/clc_coop.hpp) polls other workgroups' words: all 256 workgroups must be resident at once, one per CU.
+    Its LDS footprint (> 80 KB of the 160 KB) is what keeps a second workgroup off the CU; no scratch next to the controller."""
+    for k in _find(usage, "17coop_solve_kernel"):
+        assert usage[k]["LDS Size"] > 80 * 1024 and usage[k]["LDS Size"] <= 160 * 1024, (k, usage[k])
+        assert usage[k]["ScratchSize"] == 0 and usage[k]["Occupancy"] >= 1, (k, usage[k])

@@ -1,0 +1,147 @@
+"""GPU tests of the cooperative whole-GPU solve (csrc/clc_coop.hpp): one problem of 1e4..2e6 observations dealt once to 256
+co-resident workgroups (registers + LDS), every LM pass run from there, the per-pass totals exchanged through tagged words in
+device memory instead of a kernel boundary.  Replaces ceres::Solve on one problem (src/LaseCamCalCeres.cpp:301-307) for the
+sizes between what one workgroup holds (clc_resident.hpp) and what the chip holds.
+
+The sums are taken in another order than on the streaming layouts: same LM decisions (termination, iteration and evaluation
+counts), pose and cost inside the BASELINE gates against the oracle's DENSE_QR solve, and to rounding against the step chain."""
+import numpy as np
+import pytest
+
+import camlasercalibratool_amd as clc
+from camlasercalibratool_amd import simdata as sd
+
+pytestmark = pytest.mark.gpu
+
+X0 = sd.pose7_from_T(np.eye(4))
+T_TOL = 1e-6
+COST_TOL = 1e-8
+STEP_CHAIN = 2 | 16 | 32 | 128 | 256 | 512   # the explicit default flag set: clc_solve as the step chain
+
+
+@pytest.fixture(scope="module")
+def sv():
+    s = clc.Solver(0)
+    yield s
+    s.close()
+
+
+def _dT(a, b):
+    return np.abs(sd.T_from_pose7(a) - sd.T_from_pose7(b)).max()
+
+
+def _key(s):
+    return (s.termination, s.num_iterations, s.num_evaluations, s.num_successful_steps, s.num_unsuccessful_steps)
+
+
+def _cases():
+    yield "c2 shape, 400 scans x 500", clc.flatten_observations(sd.sim_fixed_count(3, 400, 500, noise_sigma=0.01), False)
+    yield "ragged scans 0..180 (C1 generator)", clc.flatten_observations(sd.GenerateSimData(4, n_poses=400, noise_sigma=0.02), False)
+    yield "24 scans x 5000: chunks cut scans", clc.flatten_observations(sd.sim_fixed_count(5, 24, 5000, noise_sigma=0.01), False)
+    yield "board-edge terms (C5)", clc.flatten_observations(sd.sim_board_edges(6, n_poses=300, pts_per_pose=137, noise_sigma=0.002), True, True)
+    yield "just above one workgroup", clc.flatten_observations(sd.sim_fixed_count(7, 23, 500, noise_sigma=0.01), False)
+
+
+def test_cooperative_solve_is_the_default_and_matches_oracle_and_step_chain(sv, oracle_mod):
+    for name, rec in _cases():
+        sv.set_launch(0, -1)
+        sv.upload(rec)
+        built, ppl, solves0, aborts, off = sv.debug_coop()
+        assert built and 1 <= ppl <= 40 and not off, name
+        assert not sv.debug_resident_single()[0], name
+        r = sv.solve(X0)
+        assert sv.debug_coop()[2] == solves0 + 1 and sv.debug_coop()[3] == aborts, name  # it ran there, and did not time out
+        ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+        assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations, name
+        assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL, name
+        assert abs(r.summary.initial_cost - ref.summary.initial_cost) <= 1e-11 * abs(ref.summary.initial_cost), name
+        sv.set_launch(0, STEP_CHAIN)
+        r2 = sv.solve(X0)
+        assert sv.debug_coop()[2] == solves0 + 1, name  # explicit flags: the step chain
+        assert _key(r.summary) == _key(r2.summary), name
+        assert np.abs(r.pose - r2.pose).max() <= 1e-9 and abs(r.summary.final_cost - r2.summary.final_cost) <= 1e-11 * abs(r2.summary.final_cost), name
+        # the iteration trace, record by record
+        assert len(r.trace) == len(r2.trace) == r.summary.num_iterations + 1, name
+        for a, b in zip(r.trace, r2.trace):
+            assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-10 * abs(b.cost), name
+            assert abs(a.trust_region_radius - b.trust_region_radius) <= 1e-9 * abs(b.trust_region_radius), name
+    sv.set_launch(0, -1)
+
+
+def test_cooperative_solve_is_repeatable_bit_for_bit(sv):
+    """Same lane -> point map, same exchange order every launch; 40 solves in a row advance the pass tags on the same boards."""
+    rec = clc.flatten_observations(sd.sim_fixed_count(9, 300, 400, noise_sigma=0.01), False)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    assert sv.debug_coop()[0]
+    first = sv.solve(X0)
+    n0 = sv.debug_coop()[2]
+    for _ in range(40):
+        r = sv.solve(X0)
+        assert np.array_equal(r.pose, first.pose) and r.summary.final_cost == first.summary.final_cost
+        assert _key(r.summary) == _key(first.summary)
+    built, _, solves, aborts, off = sv.debug_coop()
+    assert solves == n0 + 40 and aborts == 0 and not off
+    # another start pose in between leaves no trace on the boards
+    other = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    sv.solve(other)
+    r = sv.solve(X0)
+    assert np.array_equal(r.pose, first.pose)
+
+
+def test_cooperative_solve_options_and_limits(sv, oracle_mod):
+    """Solver options reach the in-kernel controller; flag 4096 at upload, p.z != 0, or a size outside (11 264, 2 097 152] leave
+    the problem to the other paths; profile_events = 1 asks for per-pass events and gets the launch pair, 2 times the one launch."""
+    rec = clc.flatten_observations(sd.sim_fixed_count(11, 100, 500, noise_sigma=0.01), False)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    assert sv.debug_coop()[0]
+    for kw in (dict(use_loss=0), dict(max_num_iterations=3), dict(function_tolerance=1e-12), dict(max_num_iterations=0)):
+        o, oo = clc.default_options(), oracle_mod.default_options()
+        for k, v in kw.items():
+            setattr(o, k, v)
+            setattr(oo, k, v)
+        n0 = sv.debug_coop()[2]
+        r = sv.solve(X0, o)
+        assert sv.debug_coop()[2] == n0 + 1
+        ref = oracle_mod.solve(rec, X0, options=oo, linear_solver="qr")
+        assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations, kw
+        assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL, kw
+    o = clc.default_options()
+    o.profile_events = 1
+    n0 = sv.debug_coop()[2]
+    r = sv.solve(X0, o)
+    assert sv.debug_coop()[2] == n0 and r.summary.eval_kernel_launches == r.summary.num_evaluations and r.summary.eval_kernel_ms > 0
+    o.profile_events = 2
+    r = sv.solve(X0, o)
+    assert sv.debug_coop()[2] == n0 + 1 and r.summary.eval_kernel_launches == 1 and 0 < r.summary.eval_kernel_ms < r.summary.solve_ms + 1.0
+    recz = rec.copy()
+    recz[7, 6] = 1e-3
+    sv.upload(recz)
+    assert not sv.debug_coop()[0]
+    sv.set_launch(0, STEP_CHAIN | 4096)
+    sv.upload(rec)
+    assert not sv.debug_coop()[0]
+    sv.set_launch(0, -1)
+    sv.upload(rec[:11000])
+    assert not sv.debug_coop()[0] and sv.debug_resident_single()[0]
+    sv.upload(rec)
+    assert sv.debug_coop()[0]
+
+
+def test_cooperative_solve_at_c2_full_size(sv, oracle_mod):
+    """BASELINE configs[1]: 2 000 poses x 500 points = 1e6 observations, 8 points per lane; against the oracle and the step chain."""
+    rec = clc.flatten_observations(sd.sim_fixed_count(1000, 2000, 500, noise_sigma=0.01), False)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    built, ppl, *_ = sv.debug_coop()
+    assert built and ppl in (8, 16)
+    r = sv.solve(X0)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations
+    assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    sv.set_launch(0, STEP_CHAIN)
+    r2 = sv.solve(X0)
+    sv.set_launch(0, -1)
+    assert _key(r.summary) == _key(r2.summary) and np.abs(r.pose - r2.pose).max() <= 1e-9
+    assert sv.debug_coop()[3] == 0
