@@ -140,6 +140,53 @@ def resident_kernel_report(clc, solver, x_start, n_problems, n_obs_total, n_scan
     return rep
 
 
+COOP_WGS, COOP_LANES = 256, 256  # csrc/clc_coop.hpp: workgroups of the cooperative solve, lanes per workgroup
+
+
+def coop_kernel_report(clc, solver, x0, n_obs, n_scans):
+    """Roofline object of clc_solve when it runs as ONE launch of coop_solve_kernel (csrc/clc_coop.hpp): the problem is read from HBM
+    once, dealt to 256 co-resident workgroups and solved on chip; a pass is the serial chain [moments of the lane's points ->
+    exchange of the 28 totals across the chip -> LM controller].  Kernel time: HIP event pair around the launch on the solver's
+    stream (clc_options.profile_events = 2), best of 7."""
+    built, ppl, _, aborts, off = solver.debug_coop()
+    if not built or off:
+        return None
+    o = clc.default_options()
+    o.profile_events = 2
+    best, res = None, None
+    for _ in range(7):
+        r = solver.solve(x0, o, trace_cap=0)
+        if r.summary.eval_kernel_launches != 1:
+            return None  # the launch timed out and the step chain took over
+        if best is None or r.summary.eval_kernel_ms < best:
+            best, res = r.summary.eval_kernel_ms, r
+    passes = int(res.summary.num_evaluations)
+    sec = best * 1e-3
+    evals = float(passes) * n_obs
+    # lane layout (16 B per point slot, zero-padded to ppl per lane) + lane descriptors + plane table, read once; + the exchange words
+    moved = COOP_WGS * ppl * COOP_LANES * 16 + COOP_WGS * COOP_LANES * 8 + n_scans * 48
+    exchange = passes * (COOP_WGS * 448 * 2 + 8 * 448 * (1 + COOP_WGS))  # rows written + read by the 8 leaders, group rows written + read by all
+    rep = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "kernel": f"clc::coop_solve_kernel<loss=1> (the whole LM solve in ONE launch: {COOP_WGS} co-resident workgroups x {COOP_LANES} lanes x {ppl} points "
+                     "per lane in registers + LDS; per pass: lane moments -> two-level exchange of the 28 totals through tagged words -> LM controller in every workgroup)",
+           "launches_per_solve": 1, "avg_kernel_ms": best, "evaluation_passes": passes, "us_per_pass": 1e3 * best / passes,
+           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * evals, "achieved": BYTES_PER_EVAL * evals / sec / 1e9,
+           "frac": BYTES_PER_EVAL * evals / sec / 1e9 / HBM_PEAK_GBS,
+           "moved_bytes_per_launch": int(moved + exchange), "achieved_moved": (moved + exchange) / sec / 1e9,
+           "frac_moved": (moved + exchange) / sec / 1e9 / HBM_PEAK_GBS,
+           "hbm_passes_over_the_data_per_solve": 1, "exchange_bytes_per_launch": int(exchange),
+           "served_from": "infinity_cache" if moved <= INFINITY_CACHE_BYTES else "hbm", "traffic_measured_in_run": False, "traffic": None,
+           "pricings": pricings(evals, n_scans * passes, moved + exchange, sec),
+           "limited_by": "latency, not bandwidth: a pass is the serial chain lane moments + expansion + wave reduction (~2.1 us at 16 points per lane, FP64 issue "
+                         "on one wave per SIMD) -> exchange (2 hops through device memory, ~2.5 us) -> LM controller (~2.4 us on one wave); scripts/r03_coop_stamps.py",
+           "timing": "hipEvent pair around the launch on the solver's stream (profile_events = 2), best of 7",
+           "cooperative_launch_timeouts": aborts,
+           "note": "`frac` prices the launch at the contract's 64 algorithmic bytes per evaluation x all passes and exceeds 1: the observations cross HBM once "
+                   "per SOLVE (then live in registers + LDS), not once per pass; `frac_moved` = bytes actually moved / time / 8 TB/s is the HBM fraction "
+                   "(bounded by 1) and is small because the launch is latency-bound — see `limited_by`, and `roofline_step_chain` / `roofline_large` for the streaming kernels"}
+    return rep
+
+
 def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_rccl=True):
     """BASELINE.json configs[3] on this rank: generate problems [lo, hi) of the 8 192 x world batch, keep them resident,
     then time `steps` x (clc_solve_batched + RCCL all-gather of every rank's result records).
@@ -474,7 +521,25 @@ def main():
                 roof["traffic_source"] = tj.get("source")
             except Exception:
                 pass
-        out["roofline"] = roof
+        # The default clc_solve at this size is ONE launch of the cooperative kernel (csrc/clc_coop.hpp): that is the dominant kernel of
+        # the timed region; the step chain (what runs beyond 2.6e6 observations, with p.z != 0, or with explicit launch flags) keeps
+        # its own object.
+        coop = coop_kernel_report(clc, solver, x0, n_obs, args.poses)
+        if coop is not None:
+            cfile = os.path.join(ROOT, "profiles", "r03_coop_traffic.json")
+            if os.path.exists(cfile):
+                try:
+                    cj = json.load(open(cfile))
+                    coop["traffic"] = cj.get("hbm_bytes_per_launch")
+                    coop["traffic_source"] = cj.get("source")
+                except Exception:
+                    pass
+            coop["timed_region_wall_ms_per_solve"] = 1e3 * elapsed_max / args.steps
+            out["roofline"] = coop
+            roof["note"] = "clc_solve as the step chain (clc_set_launch with explicit flags; the default beyond what the chip holds). " + roof["note"]
+            out["roofline_step_chain"] = roof
+        else:
+            out["roofline"] = roof
 
     # ---- working set beyond the 256 MiB Infinity Cache IN THE LAYOUT STREAMED: evaluation kernel only (rank 0, N=1) ----
     if rank == 0 and world == 1 and args.large_obs > 0:

@@ -3,13 +3,13 @@
 // The reference's ceres::Solve (src/LaseCamCalCeres.cpp:301-307) reads the observations into the ceres::Problem once and
 // iterates on them in place.  The step chain (clc_kernels.hpp K3) re-streams the problem once per LM iteration — 17.4 MB
 // per pass at C2, out of the Infinity Cache — and pays a kernel boundary per iteration.  Here the problem (up to
-// 256 x 512 x 16 = 2.1e6 points; C2 has 1e6) is dealt ONCE to 256 co-resident workgroups, one per CU — chunk c = records
+// 256 x 256 x 40 = 2.6e6 points; C2 has 1e6) is dealt ONCE to 256 co-resident workgroups, one per CU — chunk c = records
 // [c n / 256, (c + 1) n / 256) in the lane layout of clc_resident.hpp: a lane holds points of one scan, PR of them in
 // registers and PL in LDS — and every LM pass runs from there:
 //
-//   pass        every lane: moments of its <= 16 points, expansion (rows_flush), wave butterfly      -> 8 x 28 per workgroup
-//   exchange    workgroup row (28) -> board A;  the first workgroup of each group of 32 (blockIdx % 8: the workgroups the
-//               dispatcher places on one XCD) sums its group's rows -> board B;  everybody reads the 8 rows of board B
+//   pass        every lane: moments of its points, expansion (rows_flush), wave butterfly                -> 4 x 28 per workgroup
+//   exchange    (wave 0) workgroup row (28) -> board A;  the first workgroup of each group of 32 (blockIdx % 8: the workgroups
+//               the dispatcher places on one XCD) sums its group's rows -> board B;  everybody reads the 8 rows of board B
 //   controller  wave 0 of EVERY workgroup runs lm_advance_wave on the same 28 totals — the same arithmetic in the same
 //               order everywhere, so all 256 copies of the LM state stay bit-identical (what the step chain already relies on)
 //
@@ -20,12 +20,14 @@
 // one level (everybody reads 256 rows) 4.9 us per round, counter + fences 12 us, two levels 2.85 us, three levels 3.4 us,
 // levels inside an XCD through the L2 with buffer_inv sc0 no better (3.6-4.5 us), workgroup scope (sc0) never sees the
 // rows.  So the exchange costs what the launch boundary + the next launch's read of 256 rows cost (1.2 + 1.7 us); what the
-// launch saves is the streaming of the points (2.4 us per pass at C2) and the per-launch prologue.
+// launch saves is the streaming of the points (2.4 us per pass at C2) and the per-launch prologue: 7.0-7.2 us per pass at C2
+// against 8.7-9.1 (DESIGN.md K3c has the phase table).
 //
 // Summation order differs from the other layouts: results agree to rounding (1e-11 on sums), the LM decisions are the
-// same.  Co-residency is what makes the polling safe: 256 workgroups of 512 threads on 256 CUs (checked by the host against
-// the occupancy API); every poll is bounded by a wall-clock timeout, after which the workgroup raises the abort flag and
-// leaves, the host falls back to the step chain and stops using this path on the handle.
+// same.  Co-residency is what makes the polling safe: 256 workgroups on 256 CUs, one each (98 KB of LDS per workgroup; the
+// host checks the device against the occupancy API); every poll is bounded by a wall-clock timeout, after which the
+// workgroup raises its abort flag and leaves without publishing, the host falls back to the step chain and stops using
+// this path on the handle.
 #pragma once
 #include "clc_resident.hpp"
 

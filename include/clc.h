@@ -85,7 +85,9 @@ typedef struct clc_options {
   int32_t profile_events; /* 1: bracket every evaluation-kernel launch with HIP events on the
                              handle's stream and report them in clc_summary (the solve then
                              uses the [evaluation, controller] launch pair, not the one-launch
-                             step kernel); 2: controller cycle stamps only (debug)            */
+                             step kernel); 2: when the solve is ONE launch (see clc_solve), an
+                             event pair around it -> eval_kernel_ms, eval_kernel_launches = 1;
+                             otherwise controller cycle stamps only (debug)                    */
 } clc_options;
 
 /* ceres::IterationSummary subset, one per recorded iteration (iteration 0 = initial
@@ -226,7 +228,12 @@ int clc_eval(clc_handle* h, const double pose[7], int with_loss, double loss_sca
  * (src/LaseCamCalCeres.cpp:299-307): Levenberg-Marquardt trust region with Jacobi scaling
  * on the uploaded observations, SE(3) local parameterisation, Cauchy loss; runs entirely
  * on the device.  pose is in/out = [tx,ty,tz,qx,qy,qz,qw] (:219, :311-314).
- * trace (nullable) receives up to trace_cap iteration records. */
+ * trace (nullable) receives up to trace_cap iteration records.
+ * With the library's default launch flags the whole solve is ONE launch when the problem fits on chip
+ * (p.z == 0): up to 11 264 observations in one workgroup, up to ~2.6e6 across 256 co-resident workgroups
+ * (csrc/clc_coop.hpp; needs a 256-CU device, falls back by itself otherwise or when its exchange times
+ * out); beyond that — or with explicit clc_set_launch flags — one launch per LM iteration.  Same LM
+ * decisions on every path; sums are taken in different orders (results agree to rounding). */
 int clc_solve(clc_handle* h, const clc_options* opt, double pose[7], clc_summary* summary,
               clc_iteration* trace, int trace_cap);
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# GPU box: rocprofv3 evidence for the cooperative solve (csrc/clc_coop.hpp) — kernel trace + stats, PMC passes (separate runs) of
+# `scripts/r03_prof_probe.py coop 1000000`, and the kernel stats of the default bench command.  Every run under its own timeout.
+# Outputs: gpurun_out/prof_r03c/ (scripts/summarize_r03c.py turns them into profiles/r03_coop.md, r03_coop_traffic.json, r03_bench_kernel_stats.csv).
+R=$(pwd); O=$R/gpurun_out/prof_r03c; mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+run() {  # name, timeout, rocprof args..., -- target args
+  local name=$1 to=$2; shift 2
+  local s=$(date +%s)
+  timeout $to rocprofv3 "$@" > $O/$name.log 2>&1
+  echo "$name rc=$? $(( $(date +%s) - s ))s"
+}
+P="python $R/scripts/r03_prof_probe.py"
+VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU SQ_INSTS_LDS"
+run coop_trace 120 --kernel-trace --stats --output-format csv -d $O/coop_trace -o w -- $P coop 1000000
+run coop_fetch 120 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/coop_fetch -o w -- $P coop 1000000
+run coop_write 120 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/coop_write -o w -- $P coop 1000000
+run coop_valu 120 --pmc $VALU --kernel-trace --output-format csv -d $O/coop_valu -o w -- $P coop 1000000
+run bench_trace 400 --kernel-trace --stats --output-format csv -d $O/bench_trace -o b -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-cold-start
+cd $R
+find $O -name "*.db" -delete 2>/dev/null
+du -sh $O
