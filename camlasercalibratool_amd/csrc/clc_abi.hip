@@ -211,6 +211,7 @@ struct clc_handle {
   bool coop_disabled = false;
   int coop_aborts = 0;
   long long coop_solves = 0;
+  int coop_test_drop = 0;  // test hook: launch the next cooperative solve this many workgroups short (its exchange must time out)
   // single-problem resident solve: start pose in / result out through page-locked, device-mapped host memory
   double* h_spose = nullptr;          // [7] host view
   double* d_spose = nullptr;          // device view of the same allocation
@@ -1408,12 +1409,14 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
   const int d_cap = want_trace ? h->trace_cap : 0;
   const unsigned int tag0 = h->coop_tag;
   h->coop_tag += passes;
+  const unsigned int wgs = (unsigned int)(clc::COOP_WGS - h->coop_test_drop);
+  h->coop_test_drop = 0;
   if (timed) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
   if (opt.use_loss)
-    hipLaunchKernelGGL((clc::coop_solve_kernel<true, false>), dim3(clc::COOP_WGS), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
+    hipLaunchKernelGGL((clc::coop_solve_kernel<true, false>), dim3(wgs), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
                        h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
   else
-    hipLaunchKernelGGL((clc::coop_solve_kernel<false, false>), dim3(clc::COOP_WGS), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
+    hipLaunchKernelGGL((clc::coop_solve_kernel<false, false>), dim3(wgs), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
                        h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
   CLC_HIP(hipGetLastError());
   if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
@@ -2430,6 +2433,16 @@ extern "C" int clc_debug_coop(clc_handle* h, int* ok, int* max_ppl, long long* s
   if (solves) *solves = h->coop_solves;
   if (aborts) *aborts = h->coop_aborts;
   if (disabled) *disabled = (h->coop_disabled || h->coop_checked < 0) ? 1 : 0;
+  return CLC_OK;
+}
+
+// Test hook for the safety net of the cooperative solve: drop_next > 0 launches the NEXT cooperative solve that many workgroups short
+// (the exchange of the others must time out, nothing is written, clc_solve falls back to the step chain and disables the path);
+// reenable != 0 clears the disabled state again.
+extern "C" int clc_debug_coop_control(clc_handle* h, int drop_next, int reenable) {
+  if (!h || drop_next < 0 || drop_next >= clc::COOP_WGS) return fail(CLC_ERR_INVALID_ARG, "clc_debug_coop_control: bad argument");
+  h->coop_test_drop = drop_next;
+  if (reenable) h->coop_disabled = false;
   return CLC_OK;
 }
 

@@ -364,6 +364,11 @@ class Solver:
         check(self._L.clc_debug_coop(self._h, C.byref(ok), C.byref(ppl), C.byref(solves), C.byref(aborts), C.byref(off)), "clc_debug_coop")
         return bool(ok.value), ppl.value, solves.value, aborts.value, bool(off.value)
 
+    def debug_coop_control(self, drop_next: int = 0, reenable: bool = False):
+        """Test hook: launch the next cooperative solve `drop_next` workgroups short (it must time out and fall back); clear the
+        disabled state."""
+        check(self._L.clc_debug_coop_control(self._h, C.c_int(drop_next), C.c_int(int(reenable))), "clc_debug_coop_control")
+
     def debug_wave_split(self, grid: int):
         """Wave split table of the row layout for `grid` workgroups -> (split[grid * 8 + 1], first[n_rows])."""
         n_rows = self.debug_rows()[1]

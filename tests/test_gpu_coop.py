@@ -145,3 +145,64 @@ def test_cooperative_solve_at_c2_full_size(sv, oracle_mod):
     sv.set_launch(0, -1)
     assert _key(r.summary) == _key(r2.summary) and np.abs(r.pose - r2.pose).max() <= 1e-9
     assert sv.debug_coop()[3] == 0
+
+
+def test_cooperative_solve_that_cannot_complete_falls_back_and_is_disabled(sv, oracle_mod):
+    """The safety net on hardware: a launch that is one workgroup short (test hook) cannot complete its exchange — every poll times out
+    (20 ms), nothing is written, clc_solve answers through the step chain and the handle stops using the path; re-enabled, it works again
+    on the same boards (the aborted launch's tags are behind the next solve's)."""
+    import time
+    rec = clc.flatten_observations(sd.sim_fixed_count(13, 120, 400, noise_sigma=0.01), False)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    assert sv.debug_coop()[0]
+    good = sv.solve(X0)
+    _, _, solves0, aborts0, off0 = sv.debug_coop()
+    assert not off0
+    for drop in (1, 200):
+        sv.debug_coop_control(drop_next=drop)
+        t0 = time.perf_counter()
+        r = sv.solve(X0)
+        dt = time.perf_counter() - t0
+        _, _, solves, aborts, off = sv.debug_coop()
+        assert aborts == aborts0 + 1 and off and solves == solves0, drop
+        assert 0.015 < dt < 2.0, dt  # the timeouts, not a hang
+        assert r.summary.termination == good.summary.termination and r.summary.num_iterations == good.summary.num_iterations
+        assert np.abs(r.pose - good.pose).max() <= 1e-9  # the step chain's answer
+        r = sv.solve(X0)  # disabled: the step chain again, at once
+        assert sv.debug_coop()[2] == solves0
+        sv.debug_coop_control(reenable=True)
+        r = sv.solve(X0)
+        _, _, solves0, aborts0, off0 = sv.debug_coop()
+        assert solves0 == solves + 1 and not off0
+        assert np.array_equal(r.pose, good.pose) and r.summary.final_cost == good.summary.final_cost
+
+
+def test_two_handles_solving_at_once(oracle_mod):
+    """Two handles (two streams) on the one GPU, driven from two threads: their cooperative launches compete for the same 256 CUs.
+    Whatever the dispatcher does — one launch after the other, or interleaved workgroups that time out and fall back — both
+    answers are right and nothing hangs."""
+    import threading
+    rec = clc.flatten_observations(sd.sim_fixed_count(17, 100, 500, noise_sigma=0.01), False)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    out = {}
+
+    def work(name):
+        s = clc.Solver(0)
+        try:
+            s.upload(rec)
+            out[name] = [s.solve(X0) for _ in range(30)] + [s.debug_coop()]
+        finally:
+            s.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in ("a", "b")]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert all(not t.is_alive() for t in th)
+    for k in ("a", "b"):
+        *res, dbg = out[k]
+        for r in res:
+            assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations
+            assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
