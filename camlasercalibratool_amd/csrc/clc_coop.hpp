@@ -146,7 +146,13 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
     sh_abort = 0;
   }
   const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
-  constexpr int GRP = NW == 4 ? 4 : 2;  // points per basic block = independent dependency chains (a wave alone on its SIMD needs them)
+#ifndef CLC_COOP_GRP
+#define CLC_COOP_GRP 8
+#endif
+  // Points per basic block = independent dependency chains: a wave alone on its SIMD needs them (C2 kernel: pairs 0.0986 ms, fours
+  // 0.0942, eights 0.0909).  The running cost product is renormalised once per block: eight factors 1 + r0^2/lf^2 below 2^128 each
+  // (|r0| / lf < 1.8e19) cannot overflow.
+  constexpr int GRP = NW == 4 ? CLC_COOP_GRP : 2;
   const int ppl_up = (ppl + GRP - 1) / GRP * GRP;
   const int ppl_eff = ppl_up < NP ? ppl_up : NP;
   __syncthreads();

@@ -206,3 +206,26 @@ def test_two_handles_solving_at_once(oracle_mod):
         for r in res:
             assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations
             assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+
+
+def test_cooperative_solve_from_a_far_start(sv, oracle_mod):
+    """Start 1e4 m off: every factor 1 + r0^2/lf^2 of the cost product is ~1e13-1e15 and the product is renormalised once per eight
+    points; the solve must take the step chain's decisions record by record (and the oracle's)."""
+    rec = clc.flatten_observations(sd.sim_fixed_count(19, 150, 400, noise_sigma=0.01), False)
+    far = X0.copy()
+    far[:3] = (1e4, -2e4, 5e3)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    n0 = sv.debug_coop()[2]
+    r = sv.solve(far)
+    assert sv.debug_coop()[2] == n0 + 1
+    sv.set_launch(0, STEP_CHAIN)
+    r2 = sv.solve(far)
+    sv.set_launch(0, -1)
+    ref = oracle_mod.solve(rec, far, linear_solver="qr")
+    assert np.isfinite(r.summary.initial_cost) and abs(r.summary.initial_cost - ref.summary.initial_cost) <= 1e-11 * abs(ref.summary.initial_cost)
+    assert _key(r.summary) == _key(r2.summary)
+    assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations
+    for a, b in zip(r.trace, r2.trace):
+        assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-9 * abs(b.cost)
+    assert _dT(r.pose, ref.pose) <= 1e-5 * max(1.0, np.abs(sd.T_from_pose7(ref.pose)).max())
