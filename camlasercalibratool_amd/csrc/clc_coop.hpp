@@ -44,6 +44,10 @@ constexpr int COOP_NW = CLC_COOP_NW, COOP_NL = 64 * COOP_NW;
 constexpr int COOP_PR = COOP_NW == 4 ? 16 : 0, COOP_PL = COOP_NW == 4 ? 24 : 16;
 constexpr unsigned long long COOP_TIMEOUT_TICKS = 2000000ull;      // 20 ms of the 100 MHz wall clock per poll
 constexpr int COOP_DONE_OK = 1, COOP_DONE_ABORT = 2;
+#ifndef CLC_COOP_LEAN
+#define CLC_COOP_LEAN 0
+#endif
+constexpr bool COOP_LEAN = CLC_COOP_LEAN != 0;  // the controller's small-footprint form (clc_controller.hpp): measured, 1.5 % slower here (registers are not short)
 
 struct CoopBoard {
   unsigned long long a[2][COOP_WGS][COOP_ROW_WORDS];     // [pass parity][workgroup][2 x 28 words, padded]
@@ -64,9 +68,10 @@ __device__ __forceinline__ double coop_join(unsigned long long w0, unsigned long
 
 #ifdef CLC_STAMPS
 // Debug build only (scripts/r03_coop_stamps.py): shader-clock stamps of wave 0 (and wave 7 in row 1) of workgroups 0, 7 (leaders), 8 and
-// 255, per pass p < COOP_STAMP_PASSES at 8 p: pass start, pass done (wave totals in LDS), row published, (leaders) group rows gathered,
-// group row published, the 8 group rows arrived, totals in LDS, controller done.  Slot 8 * COOP_STAMP_PASSES: kernel entry, + 1: points in.
-constexpr int COOP_STAMP_PASSES = 16, COOP_STAMP_SLOTS = 8 * COOP_STAMP_PASSES + 2;
+// 255, per pass p < COOP_STAMP_PASSES at 12 p: pass start, pass done (wave totals in LDS), row published, (leaders) group rows gathered,
+// group row published, the 8 group rows arrived, totals in LDS, controller done; inside the pass: 8 pose + plane set up, 9 points done,
+// 10 padding correction + expansion done.  Slot 12 * COOP_STAMP_PASSES: kernel entry, + 1: points in.
+constexpr int COOP_STAMP_PASSES = 16, COOP_STAMP_PER_PASS = 12, COOP_STAMP_SLOTS = COOP_STAMP_PER_PASS * COOP_STAMP_PASSES + 2;
 __device__ long long clc_coop_stamp_buf[4][2][COOP_STAMP_SLOTS];
 #define COOP_STAMP(slot)                                                                                                     \
   do {                                                                                                                       \
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
   LmState& st = *reinterpret_cast<LmState*>(sh_state);
 #ifdef CLC_STAMPS
   int stamp_pass = 0;
-  COOP_STAMP(8 * COOP_STAMP_PASSES);
+  COOP_STAMP(COOP_STAMP_PER_PASS * COOP_STAMP_PASSES);
 #endif
   // uni_ppl >= 0: every chunk has this many points per lane (the usual case: chunks of equal record counts) — no offset read in
   // front of the point loads
@@ -156,14 +161,14 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
   const int ppl_up = (ppl + GRP - 1) / GRP * GRP;
   const int ppl_eff = ppl_up < NP ? ppl_up : NP;
   __syncthreads();
-  COOP_STAMP(8 * COOP_STAMP_PASSES + 1);
+  COOP_STAMP(COOP_STAMP_PER_PASS * COOP_STAMP_PASSES + 1);
 #pragma unroll
   for (int j = 0; j < PR; ++j)
     if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; }
 
   // one evaluation pass at st.x_eval: the wave's 28 totals -> sh_wsum[wave]   (the pass of resident_solve_kernel)
   auto pass = [&]() {
-    COOP_STAMP(8 * stamp_pass);
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass);
     int t = tid;
     asm volatile("" : "+v"(t));  // (opaque: the pass's LDS addresses are recomputed here, not hoisted out of the loop and held — or spilled — across the controller)
     double nx = pl_nx, ny = pl_ny, nz = pl_nz, pd = pl_d, ps = pl_s;
@@ -189,6 +194,10 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
     }
     RowPlane q;
     rows_plane_setup(P.R, P.t, nx, ny, nz, pd, ps, q);
+#ifdef CLC_STAMPS
+    asm volatile("" :: "v"(q.mx), "v"(q.c0));
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 8);
+#endif
     const int npad = ppl_eff - cnt;
     const double np = (double)npad;
     RowMoments M;
@@ -209,6 +218,10 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
         }
       }
     }
+#ifdef CLC_STAMPS
+    asm volatile("" :: "v"(M.S0), "v"(M.Tx), "v"(M.prod));
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 9);
+#endif
     // the zero padding out again: npad points (0, 0) with r0 = c0 each
     double lp = 0.0;
     {
@@ -234,8 +247,12 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
     rows_flush<WITH_LOSS>(q, M, acc);
     if (WITH_LOSS) acc[27] = fma(-q.s2, lp, acc[27]);
+#ifdef CLC_STAMPS
+    asm volatile("" :: "v"(acc[0]), "v"(acc[20]), "v"(acc[27]));
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 10);
+#endif
     wave_reduce_butterfly(acc, sh_wsum[wave], lane);
-    COOP_STAMP(8 * stamp_pass + 1);
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 1);
   };
 
   // The 28 totals of pass `k` over all workgroups -> sh_tot, on wave 0 alone (the wave that runs the controller next: no barrier and
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
       for (int w = 1; w < NW; ++w) s += sh_wsum[w][lane];
       coop_put(board->a[par][wg], lane, s, tag);
     }
-    COOP_STAMP(8 * stamp_pass + 2);
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 2);
     bool fine = true;
     if (leader) {
       // rows of this group: workgroups grp + 8 m, m = 16 h .. 16 h + 15
@@ -274,13 +291,13 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
         if (__all(ok)) break;
         if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS) { fine = false; break; }
       }
-      COOP_STAMP(8 * stamp_pass + 3);
+      COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 3);
       double s = coop_join(w0[0], w1[0]);
 #pragma unroll
       for (int i = 1; i < 16; ++i) s += coop_join(w0[i], w1[i]);
       const double o = __shfl_xor(s, 32, 64);
       if (mine && fine) coop_put(board->b[par][grp], lane, s + o, tag);  // (lanes < 28 are half 0: members 0-15 first)
-      COOP_STAMP(8 * stamp_pass + 4);
+      COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 4);
     }
     if (fine) {
       // the 8 group rows: groups 4 h .. 4 h + 3
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
         __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > COOP_TIMEOUT_TICKS) { fine = false; break; }
       }
-      COOP_STAMP(8 * stamp_pass + 5);
+      COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 5);
       double s = coop_join(w0[0], w1[0]);
 #pragma unroll
       for (int i = 1; i < 4; ++i) s += coop_join(w0[i], w1[i]);
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    COOP_STAMP(8 * stamp_pass + 6);
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 6);
     return fine;
   };
 
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
   if (wave == 0) {
     int lane_c = lane;
     asm volatile("" : "+v"(lane_c));
-    if (exchange(0)) lm_advance_wave<true, false>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
+    if (exchange(0)) lm_advance_wave<true, COOP_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
     else { sh_abort = 1; __syncthreads(); }
   } else {
     exchange(0);
@@ -336,14 +353,14 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
     if (wave == 0) {
       int lane_c = lane;
       asm volatile("" : "+v"(lane_c));
-      if (exchange(k + 1)) lm_advance_wave<false, false>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
+      if (exchange(k + 1)) lm_advance_wave<false, COOP_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
       else { sh_abort = 1; __syncthreads(); }
     } else {
       exchange(k + 1);
       __syncthreads();
     }
 #ifdef CLC_STAMPS
-    COOP_STAMP(8 * stamp_pass + 7);
+    COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 7);
     ++stamp_pass;
 #endif
   }

@@ -28,7 +28,8 @@ print("coop:", sv.debug_coop())
 for _ in range(3):
     sv.solve(x0)
 NP = 16
-buf = np.zeros((4, 2, 8 * NP + 2), dtype=np.int64)
+PP = 12
+buf = np.zeros((4, 2, PP * NP + 2), dtype=np.int64)
 L.clc_debug_coop_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.clc_debug_coop_stamps(buf.ctypes.data, buf.nbytes) == 0  # clears
 o = clc.default_options(); o.profile_events = 2
@@ -41,10 +42,10 @@ names = ["pass (plane, pose, points, flush, butterfly)", "barrier + row publishe
 wgs = ["wg 0 (leader)", "wg 7 (leader)", "wg 8", "wg 255"]
 for w in range(4):
     t = buf[w, 0]
-    print(f"--- {wgs[w]}: entry -> points in {t[8*NP+1]-t[8*NP]} cycles; first pass start {t[0]-t[8*NP]} cycles after entry")
+    print(f"--- {wgs[w]}: entry -> points in {t[PP*NP+1]-t[PP*NP]} cycles; first pass start {t[0]-t[PP*NP]} cycles after entry")
     per = []
     for p in range(min(ne, NP)):
-        s = t[8 * p: 8 * p + 8]
+        s = t[PP * p: PP * p + PP]
         d = [s[1] - s[0], s[2] - s[1], (s[3] - s[2]) if s[3] else 0, (s[4] - s[3]) if s[3] else 0, s[5] - (s[4] if s[3] else s[2]), s[6] - s[5], s[7] - s[6]]
         per.append(d)
     per = np.array(per, dtype=float)
@@ -52,7 +53,9 @@ for w in range(4):
     for i, nm in enumerate(names):
         print(f"    {nm:48s} median {np.median(steady[:, i]):8.0f} cycles   (passes 0,1: {per[0, i]:.0f}, {per[1, i]:.0f})")
     tot = np.median(steady.sum(axis=1))
-    full = np.median(np.diff(t[0:8 * min(ne, NP):8]))
+    full = np.median(np.diff(t[0:PP * min(ne, NP):PP]))
+    inner = np.array([[t[PP*p+8]-t[PP*p], t[PP*p+9]-t[PP*p+8], t[PP*p+10]-t[PP*p+9], t[PP*p+1]-t[PP*p+10]] for p in range(2, min(ne, NP))], dtype=float)
+    print('    inside the pass (median cycles): pose+plane %.0f, points %.0f, padding+expansion %.0f, butterfly %.0f' % tuple(np.median(inner, axis=0)))
     print(f"    sum {tot:.0f} cycles; pass start -> next pass start median {full:.0f} cycles")
-span = buf[:, 0, 8 * (min(ne, NP) - 1) + 7] - buf[:, 0, 8 * NP]
+span = buf[:, 0, PP * (min(ne, NP) - 1) + 7] - buf[:, 0, PP * NP]
 print("entry -> last controller done (cycles):", span.tolist(), " => shader clock MHz if the kernel took all of it:", (span.max() / (1e3 * r.summary.eval_kernel_ms)))
