@@ -120,21 +120,28 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
   // ---- this workgroup's chunk of the problem: HBM -> registers / LDS, once (as resident_solve_kernel) ----
   const v2d* __restrict__ src = reinterpret_cast<const v2d*>(xyl) + (size_t)row0 * NL + tid;
   const int j_last = ppl > 0 ? ppl - 1 : 0;
+  // (the LDS-bound rows only when the chunk has more points per lane than the registers hold — one wave-uniform branch around the
+  // whole block, unconditional loads from clamped row indices inside it: at C2, 16 points per lane, there is nothing to load)
   v2d lds_v[PL];
+  const bool use_lds = ppl > PR;
+  if (use_lds) {
 #pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    const int j = PR + i;
-    lds_v[i] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+    for (int i = 0; i < PL; ++i) {
+      const int j = PR + i;
+      lds_v[i] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+    }
   }
   v2d reg[PR > 0 ? PR : 1];
 #pragma unroll
   for (int j = 0; j < PR; ++j) reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
   const ResLane dl = lane_desc[(size_t)wg * NL + tid];
+  if (use_lds) {
 #pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    v2d v = lds_v[i];
-    if (PR + i >= ppl) { v[0] = 0.0; v[1] = 0.0; }
-    sh_pts[i * NL + tid] = v;
+    for (int i = 0; i < PL; ++i) {
+      v2d v = lds_v[i];
+      if (PR + i >= ppl) { v[0] = 0.0; v[1] = 0.0; }
+      sh_pts[i * NL + tid] = v;
+    }
   }
   const double* __restrict__ gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
   const int cnt = dl.cnt;
@@ -182,9 +189,11 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
       nx = on ? a[0] : 0.0; ny = on ? a[1] : 0.0; nz = on ? b[0] : 0.0; pd = on ? b[1] : 0.0; ps = on ? s5 : 0.0;
     }
     v2d buf[2][CH];
+    if (ppl > PR) {
 #pragma unroll
-    for (int u = 0; u < CH; ++u)
-      if (u < PL) buf[0][u] = sh_pts[u * NL + t];
+      for (int u = 0; u < CH; ++u)
+        if (u < PL) buf[0][u] = sh_pts[u * NL + t];
+    }
     PoseU P;
     {
       double x[7];

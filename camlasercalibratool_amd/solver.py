@@ -11,6 +11,9 @@ from . import _capi
 from ._capi import Iteration, Options, Summary, TERMINATION, check, default_line_options, default_options, dptr, iptr
 
 
+_Pose7 = C.c_double * 7
+
+
 @dataclass
 class SolveResult:
     pose: np.ndarray  # [tx,ty,tz,qx,qy,qz,qw]
@@ -214,11 +217,13 @@ class Solver:
         return cost.value, g, H
 
     def solve(self, pose0: np.ndarray, options: Optional[Options] = None, trace_cap: int = 256) -> SolveResult:
-        pose = np.array(pose0, dtype=np.float64).copy()
+        pose = np.array(pose0, dtype=np.float64)  # (a copy: in/out)
+        assert pose.shape == (7,)
         s = Summary()
         tr = (Iteration * trace_cap)() if trace_cap > 0 else None
         o = options or default_options()
-        check(self._L.clc_solve(self._h, C.byref(o), dptr(pose), C.byref(s), tr, C.c_int(trace_cap)), "clc_solve")
+        # (a ctypes view of the array's buffer: numpy's .ctypes.data_as() costs 2.7 us per call, 3 % of a C2 solve)
+        check(self._L.clc_solve(self._h, C.byref(o), _Pose7.from_buffer(pose), C.byref(s), tr, trace_cap), "clc_solve")
         n = max(0, min(trace_cap, s.num_iterations + 1))
         return SolveResult(pose, s, [tr[i] for i in range(n)])
 
