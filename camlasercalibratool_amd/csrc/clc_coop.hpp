@@ -20,8 +20,10 @@
 // one level (everybody reads 256 rows) 4.9 us per round, counter + fences 12 us, two levels 2.85 us, three levels 3.4 us,
 // levels inside an XCD through the L2 with buffer_inv sc0 no better (3.6-4.5 us), workgroup scope (sc0) never sees the
 // rows.  So the exchange costs what the launch boundary + the next launch's read of 256 rows cost (1.2 + 1.7 us); what the
-// launch saves is the streaming of the points (2.4 us per pass at C2) and the per-launch prologue: 7.0-7.2 us per pass at C2
-// against 8.7-9.1 (DESIGN.md K3c has the phase table).
+// launch saves is the streaming of the points (2.4 us per pass at C2) and the per-launch prologue: 6.9-7.2 us per pass at C2
+// against 8.7-9.1 (DESIGN.md K3c has the phase table).  Also measured, negative: several polls in flight, issued a fraction of a
+// round trip apart, to sample the boards more often than once per round trip — C2 kernel 0.092 ms with one poll at a time, 0.106
+// with two, 0.114 with four (the younger polls still own their registers when the controller starts, and they load the fabric).
 //
 // Summation order differs from the other layouts: results agree to rounding (1e-11 on sums), the LM decisions are the
 // same.  Co-residency is what makes the polling safe: 256 workgroups on 256 CUs, one each (98 KB of LDS per workgroup; the
