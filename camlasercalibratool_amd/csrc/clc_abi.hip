@@ -1379,12 +1379,15 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
   if (h->coop_checked < 0) return kCoopFallback;
   if (!h->d_board) {
     CLC_HIP(hipMalloc(&h->d_board, sizeof(clc::CoopBoard)));
+    // (ordered on the handle's stream AND waited for: the caller may switch streams, clc_set_stream, before the next solve)
     CLC_HIP(hipMemsetAsync(h->d_board, 0, sizeof(clc::CoopBoard), h->stream));
+    CLC_HIP(hipStreamSynchronize(h->stream));
     h->coop_tag = 1;
   }
   const unsigned int passes = (unsigned int)opt.max_num_iterations + 4u;
   if (h->coop_tag > 0xFFFFFFFFu - passes - 8u) {  // the 32-bit pass tags are used up: start over on clean boards
     CLC_HIP(hipMemsetAsync(h->d_board, 0, sizeof(clc::CoopBoard), h->stream));
+    CLC_HIP(hipStreamSynchronize(h->stream));
     h->coop_tag = 1;
   }
   const bool want_trace = trace != nullptr && trace_cap > 0;
@@ -2443,6 +2446,13 @@ extern "C" int clc_debug_coop_control(clc_handle* h, int drop_next, int reenable
   if (!h || drop_next < 0 || drop_next >= clc::COOP_WGS) return fail(CLC_ERR_INVALID_ARG, "clc_debug_coop_control: bad argument");
   h->coop_test_drop = drop_next;
   if (reenable) h->coop_disabled = false;
+  return CLC_OK;
+}
+
+// Test hook: the next cooperative solve starts its pass tags here (to exercise the wrap of the 32-bit tags).
+extern "C" int clc_debug_coop_set_tag(clc_handle* h, unsigned int tag) {
+  if (!h || tag == 0) return fail(CLC_ERR_INVALID_ARG, "clc_debug_coop_set_tag: bad argument");
+  h->coop_tag = tag;
   return CLC_OK;
 }
 

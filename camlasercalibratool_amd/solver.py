@@ -374,6 +374,10 @@ class Solver:
         disabled state."""
         check(self._L.clc_debug_coop_control(self._h, C.c_int(drop_next), C.c_int(int(reenable))), "clc_debug_coop_control")
 
+    def debug_coop_set_tag(self, tag: int):
+        """Test hook: first pass tag of the next cooperative solve (32-bit; exercises the wrap)."""
+        check(self._L.clc_debug_coop_set_tag(self._h, C.c_uint(tag)), "clc_debug_coop_set_tag")
+
     def debug_wave_split(self, grid: int):
         """Wave split table of the row layout for `grid` workgroups -> (split[grid * 8 + 1], first[n_rows])."""
         n_rows = self.debug_rows()[1]

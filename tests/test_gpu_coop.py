@@ -229,3 +229,20 @@ def test_cooperative_solve_from_a_far_start(sv, oracle_mod):
     for a, b in zip(r.trace, r2.trace):
         assert a.step_is_successful == b.step_is_successful and abs(a.cost - b.cost) <= 1e-9 * abs(b.cost)
     assert _dT(r.pose, ref.pose) <= 1e-5 * max(1.0, np.abs(sd.T_from_pose7(ref.pose)).max())
+
+
+def test_cooperative_solve_pass_tags_wrap(sv):
+    """The boards carry 32-bit (solve, pass) tags that only grow; when they run out the boards are cleared and the tags start over.
+    Solves right below the limit, across it and after it give the same bits."""
+    rec = clc.flatten_observations(sd.sim_fixed_count(23, 90, 400, noise_sigma=0.01), False)
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    assert sv.debug_coop()[0]
+    first = sv.solve(X0)
+    aborts0 = sv.debug_coop()[3]
+    for tag in (0xFFFFFFFF - 1000, 0xFFFFFFFF - 150, 0xFFFFFFFF - 60, 0xFFFFFFF0):
+        sv.debug_coop_set_tag(tag)
+        for _ in range(4):  # (a solve reserves max_num_iterations + 4 = 104 tags)
+            r = sv.solve(X0)
+            assert np.array_equal(r.pose, first.pose) and r.summary.final_cost == first.summary.final_cost
+    assert sv.debug_coop()[3] == aborts0 and not sv.debug_coop()[4]
