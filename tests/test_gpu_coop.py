@@ -75,13 +75,13 @@ def test_cooperative_solve_is_repeatable_bit_for_bit(sv):
     sv.upload(rec)
     assert sv.debug_coop()[0]
     first = sv.solve(X0)
-    n0 = sv.debug_coop()[2]
+    n0, aborts_before = sv.debug_coop()[2], sv.debug_coop()[3]
     for _ in range(40):
         r = sv.solve(X0)
         assert np.array_equal(r.pose, first.pose) and r.summary.final_cost == first.summary.final_cost
         assert _key(r.summary) == _key(first.summary)
     built, _, solves, aborts, off = sv.debug_coop()
-    assert solves == n0 + 40 and aborts == 0 and not off
+    assert solves == n0 + 40 and aborts == aborts_before and not off
     # another start pose in between leaves no trace on the boards
     other = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
     sv.solve(other)
@@ -134,7 +134,7 @@ def test_cooperative_solve_at_c2_full_size(sv, oracle_mod):
     rec = clc.flatten_observations(sd.sim_fixed_count(1000, 2000, 500, noise_sigma=0.01), False)
     sv.set_launch(0, -1)
     sv.upload(rec)
-    built, ppl, *_ = sv.debug_coop()
+    built, ppl, _, aborts0, _ = sv.debug_coop()
     assert built and ppl in (8, 16)
     r = sv.solve(X0)
     ref = oracle_mod.solve(rec, X0, linear_solver="qr")
@@ -144,7 +144,7 @@ def test_cooperative_solve_at_c2_full_size(sv, oracle_mod):
     r2 = sv.solve(X0)
     sv.set_launch(0, -1)
     assert _key(r.summary) == _key(r2.summary) and np.abs(r.pose - r2.pose).max() <= 1e-9
-    assert sv.debug_coop()[3] == 0
+    assert sv.debug_coop()[3] == aborts0
 
 
 def test_cooperative_solve_that_cannot_complete_falls_back_and_is_disabled(sv, oracle_mod):
