@@ -621,10 +621,6 @@ def main():
             out["batched_c3"]["T_cl_max_abs_err_vs_oracle_sample"] = w
             out["batched_c3"]["oracle_sample"] = f"{len(sample)} of {Pb} problems (tests/test_gpu_parity.py::test_c3_full_size_batch checks 64)"
 
-    # ---- BASELINE.json configs[3] (C4), one GPU's share: the N=1 base of the multi-GPU curve ----
-    if rank == 0 and world == 1 and not args.no_c4_shard:
-        out["batched_c4_shard"] = run_c4_shard(args, torch, None, 0, 1, local_rank, args.shard_steps, 2)
-
     # ---- CPU baseline + parity (rank 0, N=1): the oracle's DENSE_QR Ceres restatement, 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
@@ -721,6 +717,23 @@ def main():
         cs["note"] = ("fresh process per shape: clc_create (HIP runtime + context + stream + buffers) + first closed form + first refinement and "
                       "analysis pass; `second_call_same_process` is the warm figure; cpu_oracle = the CPU port's time for the same calls")
         out["cold_start"] = cs
+
+    # ---- BASELINE.json configs[3] (C4), one GPU's share: the N=1 base of the multi-GPU curve ----
+    # Last, and under a watchdog: it is the one section of the N=1 run that creates an RCCL communicator (world size 1).  Should
+    # that ever not return, the line — complete but for this sub-object — is still written.
+    if rank == 0 and world == 1 and not args.no_c4_shard:
+        import threading
+
+        def _give_up():
+            out["batched_c4_shard"] = {"error": "the C4-shard section did not finish within 300 s; everything else in this line was measured before it"}
+            _emit(out)
+            os._exit(0)
+
+        dog = threading.Timer(300.0, _give_up)
+        dog.daemon = True
+        dog.start()
+        out["batched_c4_shard"] = run_c4_shard(args, torch, None, 0, 1, local_rank, args.shard_steps, 2)
+        dog.cancel()
 
     if rank == 0:
         _emit(out)
