@@ -532,6 +532,13 @@ def main():
                     cj = json.load(open(cfile))
                     coop["traffic"] = cj.get("hbm_bytes_per_launch")
                     coop["traffic_source"] = cj.get("source")
+                    if cj.get("valu_wave_instructions_per_launch"):
+                        lane_instr = 64.0 * cj["valu_wave_instructions_per_launch"]
+                        coop["valu_issue"] = {"lane_instructions_per_launch": lane_instr, "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR,
+                                              "frac": lane_instr / (coop["avg_kernel_ms"] * 1e-3) / VALU_PEAK_LANE_INSTR,
+                                              "note": "PMC SQ_INSTS_VALU of the builder's profile (profiles/r03_coop.md) x 64 lanes over this run's kernel time, against "
+                                                      "256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: a fifth of the issue peak — the launch waits (exchange, controller on "
+                                                      "one wave) more than it computes"}
                 except Exception:
                     pass
             coop["timed_region_wall_ms_per_solve"] = 1e3 * elapsed_max / args.steps

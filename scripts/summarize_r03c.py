@@ -60,6 +60,7 @@ L += ["", "PMC passes serialise kernels and slow the polling kernel down; durati
 open(os.path.join(dst, "r03_coop.md"), "w").write("\n".join(L))
 json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "lane_layout_bytes": inf.get("lane_layout_bytes"), "passes": passes,
            "kernel_us_median": statistics.median(d),
+           "valu_wave_instructions_per_launch": (statistics.median(v["SQ_INSTS_VALU"] for v in valu) if valu and "SQ_INSTS_VALU" in valu[0] else None),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/r03_prof_probe.py coop 1000000, median of 5 launches; read = 2 x FETCH_SIZE x 1024 (gfx950)"},
           open(os.path.join(dst, "r03_coop_traffic.json"), "w"), indent=1)
 for f in os.listdir(os.path.join(src, "bench_trace")):
