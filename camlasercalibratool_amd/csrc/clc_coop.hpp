@@ -23,7 +23,10 @@
 // launch saves is the streaming of the points (2.4 us per pass at C2) and the per-launch prologue: 6.9-7.2 us per pass at C2
 // against 8.7-9.1 (DESIGN.md K3c has the phase table).  Also measured, negative: several polls in flight, issued a fraction of a
 // round trip apart, to sample the boards more often than once per round trip — C2 kernel 0.092 ms with one poll at a time, 0.106
-// with two, 0.114 with four (the younger polls still own their registers when the controller starts, and they load the fabric).
+// with two, 0.114 with four (the younger polls still own their registers when the controller starts, and they load the fabric);
+// the leaders reading their group's rows at the shared L2 through RMWs (`or 0`: an agent-scope RMW executes in the XCD's L2) — 2.60
+// instead of 2.83 us per round in the probe, where eight waves share the polling, but 0.098 ms in the kernel, where wave 0 alone
+// issues the 64 atomics of a poll.
 //
 // Summation order differs from the other layouts: results agree to rounding (1e-11 on sums), the LM decisions are the
 // same.  Co-residency is what makes the polling safe: 256 workgroups on 256 CUs, one each (98 KB of LDS per workgroup; the

@@ -39,6 +39,13 @@ __device__ __forceinline__ unsigned long long get_word_l2(const unsigned long lo
 __device__ __forceinline__ void put_word_plain(unsigned long long* p, unsigned long long w) { *reinterpret_cast<volatile unsigned long long*>(p) = w; }
 __device__ __forceinline__ unsigned long long get_word_plain(const unsigned long long* p) { return *reinterpret_cast<const volatile unsigned long long*>(p); }
 __device__ __forceinline__ void inv_l1() { asm volatile("buffer_inv sc0" ::: "memory"); }
+// read at the L2: an agent-scope RMW executes in the XCD's L2 (the compiler emits it without sc1), so `or 0` returns what the L2 holds —
+// the freshest copy when the writer sits on the same XCD — without a trip to device memory
+__device__ __forceinline__ unsigned long long get_word_rmw(unsigned long long* p) {
+  unsigned long long z = 0;
+  asm volatile("" : "+v"(z));
+  return __hip_atomic_fetch_or(p, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned long long hi_word(double v, unsigned int tag) {
   return ((unsigned long long)__double_as_longlong(v) & 0xFFFFFFFF00000000ull) | tag;
 }
@@ -50,7 +57,7 @@ __device__ __forceinline__ double join_words(unsigned long long w0, unsigned lon
 }
 
 // modes 2 and 3.  boardA[par][wg][64] (L2 of the XCD), boardB[par][8][64] (fabric), boardC[par][8][64] (L2 of the XCD)
-template <int MODE, bool INV, bool ALL1>
+template <int MODE, bool INV, bool ALL1, bool RMW = false>
 __global__ __launch_bounds__(NT) void exchange2_kernel(unsigned long long* boardA, unsigned long long* boardB, unsigned long long* boardC,
                                                        int rounds, unsigned int tag0, double* out, long long* ticks, int* err, int* misplaced) {
   __shared__ double red[16][32];
@@ -78,13 +85,15 @@ __global__ __launch_bounds__(NT) void exchange2_kernel(unsigned long long* board
       // rows of this XCD: wg' = x + 8 s; thread (g, e) takes s = g and g + 16
       double s = 0.0;
       if (e < NACC) {
-        const unsigned long long* r0 = boardA + ((size_t)par * G + x + 8 * g) * ROW_WORDS + 2 * e;
-        const unsigned long long* r1 = boardA + ((size_t)par * G + x + 8 * (g + 16)) * ROW_WORDS + 2 * e;
+        unsigned long long* r0 = boardA + ((size_t)par * G + x + 8 * g) * ROW_WORDS + 2 * e;
+        unsigned long long* r1 = boardA + ((size_t)par * G + x + 8 * (g + 16)) * ROW_WORDS + 2 * e;
+        int tries = 0;
         unsigned long long a0, a1, b0, b1;
         const unsigned long long t0 = wall_clock64();
         bool ok;
         do {
-          if (INV) { inv_l1(); a0 = get_word_plain(r0); a1 = get_word_plain(r0 + 1); b0 = get_word_plain(r1); b1 = get_word_plain(r1 + 1); }
+          if (RMW && tries++ < 64) { a0 = get_word_rmw(r0); a1 = get_word_rmw(r0 + 1); b0 = get_word_rmw(r1); b1 = get_word_rmw(r1 + 1); }
+          else if (INV) { inv_l1(); a0 = get_word_plain(r0); a1 = get_word_plain(r0 + 1); b0 = get_word_plain(r1); b1 = get_word_plain(r1 + 1); }
           else { a0 = get_word_l2(r0); a1 = get_word_l2(r0 + 1); b0 = get_word_l2(r1); b1 = get_word_l2(r1 + 1); }
           ok = (unsigned int)a0 == tag && (unsigned int)a1 == tag && (unsigned int)b0 == tag && (unsigned int)b1 == tag;
           if (!ok && wall_clock64() - t0 > TIMEOUT_TICKS) { *err = 1; break; }
@@ -298,7 +307,7 @@ int main() {
   (void)hipMalloc(&boardC, sizeof(unsigned long long) * 2 * 8 * ROW_WORDS); (void)hipMemset(boardC, 0, sizeof(unsigned long long) * 2 * 8 * ROW_WORDS);
   (void)hipMalloc(&misplaced, 4); (void)hipMemset(misplaced, 0, 4);
   unsigned int tag = 1;
-  for (int mode = 2; mode < 8; ++mode)
+  for (int mode = 2; mode < 9; ++mode)
     for (int rep = 0; rep < 3; ++rep) {
       hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
       (void)hipEventRecord(a, 0);
@@ -310,7 +319,8 @@ int main() {
       else if (mode == 4) LAUNCH2(2, true, false);
       else if (mode == 5) LAUNCH2(3, true, false);
       else if (mode == 6) LAUNCH2(2, true, true);
-      else LAUNCH2(2, false, true);
+      else if (mode == 7) LAUNCH2(2, false, true);
+      else hipLaunchKernelGGL((exchange2_kernel<2, false, false, true>), dim3(G), dim3(NT), 0, 0, boardA, boardB, boardC, rounds, tag, out, ticks, err, misplaced);  // 8: level 1 read with RMWs at the L2
       (void)hipEventRecord(b, 0);
       (void)hipEventSynchronize(b);
       tag += rounds;
