@@ -217,8 +217,7 @@ class Solver:
         return cost.value, g, H
 
     def solve(self, pose0: np.ndarray, options: Optional[Options] = None, trace_cap: int = 256) -> SolveResult:
-        pose = np.array(pose0, dtype=np.float64)  # (a copy: in/out)
-        assert pose.shape == (7,)
+        pose = np.array(pose0, dtype=np.float64).reshape(7)  # (a copy: in/out)
         s = Summary()
         tr = (Iteration * trace_cap)() if trace_cap > 0 else None
         o = options or default_options()
