@@ -208,7 +208,9 @@ struct clc_handle {
   clc::CoopBoard* d_board = nullptr;
   unsigned int coop_tag = 1;
   int coop_checked = 0;  // 0: co-residency not checked yet, 1: 256 workgroups fit the device, -1: they do not
-  bool coop_disabled = false;
+  // after a launch that timed out the path rests for `coop_backoff` eligible solves (1 024, doubling with every further time-out up to
+  // 2^20: a GPU shared with long-running kernels of somebody else settles on the step chain, a one-off collision costs 20-60 ms once)
+  long long coop_eligible = 0, coop_retry_at = 0, coop_backoff = 1024;
   int coop_aborts = 0;
   long long coop_solves = 0;
   int coop_test_drop = 0;  // test hook: launch the next cooperative solve this many workgroups short (its exchange must time out)
@@ -1435,8 +1437,9 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
     if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) != clc::COOP_DONE_OK || want_trace || timed) CLC_HIP(hipStreamSynchronize(h->stream));
   }
   if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) != clc::COOP_DONE_OK) {
-    // an exchange timed out (a workgroup was not resident in time): nothing was written; never again on this handle
-    h->coop_disabled = true;
+    // an exchange timed out (a workgroup was not resident in time): nothing was written; the path rests (see coop_backoff)
+    h->coop_retry_at = h->coop_eligible + h->coop_backoff;
+    h->coop_backoff = std::min<long long>(h->coop_backoff * 2, 1LL << 20);
     ++h->coop_aborts;
     return kCoopFallback;
   }
@@ -1506,7 +1509,7 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // sets select the step chain / launch pair the bit-identity tests compare; profile_events = 1 asks for per-pass events)
   if (h->sres.ok && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
   // a problem the 256 CUs hold together: the whole solve in one launch of 256 co-resident workgroups (same conditions)
-  if (h->cres.ok && !h->coop_disabled && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1) {
+  if (h->cres.ok && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1 && ++h->coop_eligible > h->coop_retry_at) {
     const int rc = solve_coop(h, opt, pose, summary, trace, trace_cap, t0);
     if (rc != kCoopFallback) return rc;
   }
@@ -2435,7 +2438,7 @@ extern "C" int clc_debug_coop(clc_handle* h, int* ok, int* max_ppl, long long* s
   if (max_ppl) *max_ppl = h->cres.max_ppl;
   if (solves) *solves = h->coop_solves;
   if (aborts) *aborts = h->coop_aborts;
-  if (disabled) *disabled = (h->coop_disabled || h->coop_checked < 0) ? 1 : 0;
+  if (disabled) *disabled = (h->coop_eligible < h->coop_retry_at || h->coop_checked < 0) ? 1 : 0;  // resting after a time-out / device too small
   return CLC_OK;
 }
 
@@ -2445,7 +2448,10 @@ extern "C" int clc_debug_coop(clc_handle* h, int* ok, int* max_ppl, long long* s
 extern "C" int clc_debug_coop_control(clc_handle* h, int drop_next, int reenable) {
   if (!h || drop_next < 0 || drop_next >= clc::COOP_WGS) return fail(CLC_ERR_INVALID_ARG, "clc_debug_coop_control: bad argument");
   h->coop_test_drop = drop_next;
-  if (reenable) h->coop_disabled = false;
+  if (reenable) {
+    h->coop_retry_at = 0;
+    h->coop_backoff = 1024;
+  }
   return CLC_OK;
 }
 

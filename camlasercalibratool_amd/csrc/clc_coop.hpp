@@ -31,8 +31,8 @@
 // Summation order differs from the other layouts: results agree to rounding (1e-11 on sums), the LM decisions are the
 // same.  Co-residency is what makes the polling safe: 256 workgroups on 256 CUs, one each (98 KB of LDS per workgroup; the
 // host checks the device against the occupancy API); every poll is bounded by a wall-clock timeout, after which the
-// workgroup raises its abort flag and leaves without publishing, the host falls back to the step chain and stops using
-// this path on the handle.
+// workgroup raises its abort flag and leaves without publishing, the host falls back to the step chain and rests this
+// path on the handle for its next 1 024 solves (doubling with every further time-out).
 #pragma once
 #include "clc_resident.hpp"
 

@@ -149,7 +149,7 @@ def test_cooperative_solve_at_c2_full_size(sv, oracle_mod):
 
 def test_cooperative_solve_that_cannot_complete_falls_back_and_is_disabled(sv, oracle_mod):
     """The safety net on hardware: a launch that is one workgroup short (test hook) cannot complete its exchange — every poll times out
-    (20 ms), nothing is written, clc_solve answers through the step chain and the handle stops using the path; re-enabled, it works again
+    (20 ms), nothing is written, clc_solve answers through the step chain and the handle rests the path (1 024 solves, doubling); re-enabled, it works again
     on the same boards (the aborted launch's tags are behind the next solve's)."""
     import time
     rec = clc.flatten_observations(sd.sim_fixed_count(13, 120, 400, noise_sigma=0.01), False)
