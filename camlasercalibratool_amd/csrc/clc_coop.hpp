@@ -123,6 +123,9 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
     ppl = __builtin_amdgcn_readfirstlane((int)(res_row[wg + 1] - row0));
   }
   // ---- this workgroup's chunk of the problem: HBM -> registers / LDS, once (as resident_solve_kernel) ----
+  // The lane descriptor is requested FIRST: loads return in order, and the plane it points to is a second, dependent round trip —
+  // with the descriptor queued behind the points that trip began only when the last point had arrived.
+  const ResLane dl = lane_desc[(size_t)wg * NL + tid];
   const v2d* __restrict__ src = reinterpret_cast<const v2d*>(xyl) + (size_t)row0 * NL + tid;
   const int j_last = ppl > 0 ? ppl - 1 : 0;
   // (the LDS-bound rows only when the chunk has more points per lane than the registers hold — one wave-uniform branch around the
@@ -139,7 +142,6 @@ __global__ __launch_bounds__(COOP_NL) void coop_solve_kernel(
   v2d reg[PR > 0 ? PR : 1];
 #pragma unroll
   for (int j = 0; j < PR; ++j) reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
-  const ResLane dl = lane_desc[(size_t)wg * NL + tid];
   if (use_lds) {
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
