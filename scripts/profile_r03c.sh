@@ -17,7 +17,9 @@ run coop_trace 120 --kernel-trace --stats --output-format csv -d $O/coop_trace -
 run coop_fetch 120 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/coop_fetch -o w -- $P coop 1000000
 run coop_write 120 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/coop_write -o w -- $P coop 1000000
 run coop_valu 120 --pmc $VALU --kernel-trace --output-format csv -d $O/coop_valu -o w -- $P coop 1000000
-run bench_trace 400 --kernel-trace --stats --output-format csv -d $O/bench_trace -o b -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-cold-start
+run coop_wait 120 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/coop_wait -o w -- $P coop 1000000
+run coop_wait2 120 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/coop_wait2 -o w -- $P coop 1000000
+[ "$1" = "--counters-only" ] || run bench_trace 400 --kernel-trace --stats --output-format csv -d $O/bench_trace -o b -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-cold-start
 cd $R
 find $O -name "*.db" -delete 2>/dev/null
 du -sh $O

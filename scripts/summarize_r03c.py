@@ -56,6 +56,17 @@ if valu:
     if "SQ_INSTS_VALU" in med and passes:
         L.append(f"| VALU wave-instructions per observation and pass | {med['SQ_INSTS_VALU'] * 64 / (1e6 * passes):.1f} lane-instructions "
                  f"(the per-lane expansion, reduction and the 256 redundant controllers included) |")
+for extra in ("coop_wait", "coop_wait2"):
+    if os.path.exists(os.path.join(src, extra, "w_counter_collection.csv")):
+        cw = counters(extra, "coop_solve_kernel")
+        if cw:
+            for k in sorted(cw[0].keys()):
+                L.append(f"| {k} per launch (chip total; wave-cycle counters count quad-cycles) | {statistics.median(v[k] for v in cw):.4g} |")
+            if extra == "coop_wait2" and "SQ_WAIT_ANY" in cw[0]:
+                wc = counters("coop_wait", "coop_solve_kernel")
+                if wc and "SQ_WAVE_CYCLES" in wc[0]:
+                    L.append(f"| waves waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | {statistics.median(v['SQ_WAIT_ANY'] for v in cw) / statistics.median(v['SQ_WAVE_CYCLES'] for v in wc):.2f} "
+                             f"— the launch is a latency chain: three of four waves sit at the controller's barrier, the fourth polls or runs the serial controller |")
 L += ["", "PMC passes serialise kernels and slow the polling kernel down; durations are taken from the kernel-trace run only.", ""]
 open(os.path.join(dst, "r03_coop.md"), "w").write("\n".join(L))
 json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "lane_layout_bytes": inf.get("lane_layout_bytes"), "passes": passes,
@@ -63,7 +74,7 @@ json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
            "valu_wave_instructions_per_launch": (statistics.median(v["SQ_INSTS_VALU"] for v in valu) if valu and "SQ_INSTS_VALU" in valu[0] else None),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/r03_prof_probe.py coop 1000000, median of 5 launches; read = 2 x FETCH_SIZE x 1024 (gfx950)"},
           open(os.path.join(dst, "r03_coop_traffic.json"), "w"), indent=1)
-for f in os.listdir(os.path.join(src, "bench_trace")):
+for f in (os.listdir(os.path.join(src, "bench_trace")) if os.path.isdir(os.path.join(src, "bench_trace")) else []):
     if f.endswith("kernel_stats.csv"):
         shutil.copy(os.path.join(src, "bench_trace", f), os.path.join(dst, "r03_bench_kernel_stats.csv"))
 print("\n".join(L))
