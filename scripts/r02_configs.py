@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The five configurations of BASELINE.json on one MI355X, one line each: solve time (observations resident), passes,
-evals/s, parity against the oracle (T_cl, final cost, iteration count) — profiles/r02_configs.json."""
+evals/s, parity against the oracle (T_cl, final cost, iteration count) — profiles/r02_configs.json (round 3: CLC_CONFIGS_OUT=r03_configs.json ->
+profiles/r03_configs.json)."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,6 +28,7 @@ def single(name, rec, start, oracle_check=True):
     sv.upload(rec)
     dt, r = timed(lambda: sv.solve(start, trace_cap=0))
     line = {"config": name, "observations": int(rec.shape[0]), "layout": "rows" if (sv.debug_rows()[0] and rec.shape[0] >= 200000) else "compact28",
+            "path": ("cooperative one-launch solve" if sv.debug_coop()[0] else ("single-workgroup resident solve" if sv.debug_resident_single()[0] else "step chain")),
             "solve_ms": dt * 1e3, "passes": int(r.summary.num_evaluations), "lm_iterations": int(r.summary.num_iterations),
             "evals_per_s": r.summary.num_evaluations * rec.shape[0] / dt, "final_cost": r.summary.final_cost}
     if oracle_check:
@@ -60,4 +62,4 @@ for name, P in (("C3 batch of 1024 problems x 1e4 observations", 1024), ("C4 sha
     out.append(line)
     print(json.dumps(line), flush=True)
     del rec
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r02_configs.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", os.environ.get("CLC_CONFIGS_OUT", "r02_configs.json")), "w"), indent=1)
