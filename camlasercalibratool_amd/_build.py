@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("CLC_LIBRARY") or os.path.join(CSRC, "libclc_hip.so")  # CLC_LIBRARY: A/B a different build
 SOURCES = ["clc_abi.hip", "clc_kernels.hpp", "clc_device.hpp", "clc_layouts.hpp", "clc_stream.hpp", "clc_controller.hpp", "clc_frontend.hpp",
-           "clc_legacy.hpp", "clc_resident.hpp", "clc_coop.hpp", "clc_rows.hpp", "clc_lm.hpp", "clc_math.hpp", "clc_host.hpp"]
+           "clc_legacy.hpp", "clc_resident.hpp", "clc_coop.hpp", "clc_lmuni.hpp", "clc_rows.hpp", "clc_lm.hpp", "clc_math.hpp", "clc_host.hpp"]
 # -ffp-contract=on: FMA contraction only where the source spells one expression a*b+c (or fma()).  hipcc's default
 # (fast) lets the backend fuse across statements, and it did so differently in different kernels that inline the
 # same device functions — the step kernel and the [eval, lm] launch pair then differed in the last bits on 1 of 60

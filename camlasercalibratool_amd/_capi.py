@@ -24,7 +24,7 @@ TERMINATION = {
 # every symbol include/clc.h declares (checked by tests/test_abi_symbols.py)
 EXPORTED = [
     "clc_version", "clc_last_error", "clc_options_default", "clc_create", "clc_destroy", "clc_set_stream",
-    "clc_set_launch", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
+    "clc_set_launch", "clc_set_auto_paths", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
     "clc_factor_evaluate", "clc_pose_plus", "clc_pose_plus_jacobian", "clc_eval", "clc_solve",
     "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
     "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",

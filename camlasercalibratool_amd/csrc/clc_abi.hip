@@ -131,6 +131,8 @@ struct ResLayout {
   bool ok = false;
 };
 
+constexpr long long kCoopBackoff0 = 16;  // solves the cooperative path rests after its first abort (doubles with every further one)
+
 struct clc_handle {
   DevPool pool;  // temporaries of the entry points (DevBuf)
   int device = 0;
@@ -169,6 +171,7 @@ struct clc_handle {
   // launch geometry
   int grid_override = 0;
   int launch_flags = kDefaultLaunchFlags;
+  int auto_disable = 0;     // clc_set_auto_paths: 1 no cooperative solve, 2 no single-workgroup resident solve, 4 cooperative kernel's controller in the single-workgroup kernel
   bool launch_auto = true;  // default flags: size-dependent choices (deep pipeline) are made per launch
   double* d_partials = nullptr;
   int partials_cap_blocks = 0;
@@ -208,9 +211,10 @@ struct clc_handle {
   clc::CoopBoard* d_board = nullptr;
   unsigned int coop_tag = 1;
   int coop_checked = 0;  // 0: co-residency not checked yet, 1: 256 workgroups fit the device, -1: they do not
-  // after a launch that timed out the path rests for `coop_backoff` eligible solves (1 024, doubling with every further time-out up to
-  // 2^20: a GPU shared with long-running kernels of somebody else settles on the step chain, a one-off collision costs 20-60 ms once)
-  long long coop_eligible = 0, coop_retry_at = 0, coop_backoff = 1024;
+  // after a launch that aborted the path rests for `coop_backoff` eligible solves (16, doubling with every further abort up to 2^20:
+  // a GPU shared with long-running kernels of somebody else settles on the step chain; a one-off collision costs the first-pass
+  // census timeout, 0.2 ms, once)
+  long long coop_eligible = 0, coop_retry_at = 0, coop_backoff = kCoopBackoff0;
   int coop_aborts = 0;
   long long coop_solves = 0;
   int coop_test_drop = 0;  // test hook: launch the next cooperative solve this many workgroups short (its exchange must time out)
@@ -484,6 +488,8 @@ struct LayoutTargets {
 // 256-lane form: 256-thread workgroups, two problems per CU; 512-lane form: one 512-thread workgroup per CU (problems with more
 // than 256 scans, or flag 8192).  Both hold 512 x 22 = 256 x 44 - 512 points at most.
 constexpr int kResPR256 = 23, kResPL256 = 19, kResPR512 = 4, kResPL512 = 18;
+// controller of the batched launches (clc_resident.hpp CTRL): 4-wave form / 8-wave form
+constexpr int kResCtrl4 = 0, kResCtrl8 = 0;
 
 // The lane layout of the batched problems (clc_resident.hpp) from the staged records and their scan structure: plan
 // (points per lane of every problem, on the device), offsets (O(P) on the host), lane descriptors + j-major point rows.
@@ -850,6 +856,10 @@ int clc_create(clc_handle** out, int device) {
   clc_handle* h = new clc_handle();
   h->device = device;
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = std::getenv("CLC_AUTO_PATHS_DISABLE")) {
+    const int m = std::atoi(e);
+    if (m >= 0 && m <= 7) h->auto_disable = m;
+  }
   CLC_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   CLC_HIP(hipMalloc(&h->d_block, sizeof(clc::SolveBlock)));
@@ -904,6 +914,12 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
   CLC_HIP(hipSetDevice(h->device));
   CLC_HIP(hipStreamSynchronize(h->stream));
   h->stream = next;
+  return CLC_OK;
+}
+
+int clc_set_auto_paths(clc_handle* h, int disable_mask) {
+  if (!h || disable_mask < 0 || disable_mask > 7) return fail(CLC_ERR_INVALID_ARG, "clc_set_auto_paths: bad argument");
+  h->auto_disable = disable_mask;
   return CLC_OK;
 }
 
@@ -1332,12 +1348,13 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
   const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->sres.d_desc);
   clc_iteration* d_trace = want_trace ? h->d_trace : nullptr;
   const int d_cap = want_trace ? h->trace_cap : 0;
-  if (opt.use_loss)
-    hipLaunchKernelGGL((clc::resident_solve_kernel<true, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
-                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done, nullptr);
-  else
-    hipLaunchKernelGGL((clc::resident_solve_kernel<false, false, 8, kResPR512, kResPL512>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, d_row,
-                       d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done, nullptr);
+#define CLC_LAUNCH_SINGLE(LOSS, CTRL)                                                                                                   \
+  hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, false, 8, kResPR512, kResPL512, CTRL>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, \
+                     d_row, d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done, nullptr)
+  const bool uni_ctrl = (h->auto_disable & 4) != 0;  // the cooperative kernel's controller here: the bit-identity test of the two
+  if (opt.use_loss) { if (uni_ctrl) CLC_LAUNCH_SINGLE(true, 1); else CLC_LAUNCH_SINGLE(true, 0); }
+  else { if (uni_ctrl) CLC_LAUNCH_SINGLE(false, 1); else CLC_LAUNCH_SINGLE(false, 0); }
+#undef CLC_LAUNCH_SINGLE
   CLC_HIP(hipGetLastError());
   // The kernel sets the flag (system-scope release) after the outcome is written: polling it avoids the wake-up latency of a
   // blocking stream synchronisation (~15 us of a ~120 us solve).  Bounded: a wedged queue falls through to the synchronisation,
@@ -1373,8 +1390,8 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
                std::chrono::steady_clock::time_point t0) {
   if (h->coop_checked == 0) {
     int a = 0, b = 0;
-    const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, clc::coop_solve_kernel<true, false>, clc::COOP_NL, 0);
-    const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, clc::coop_solve_kernel<false, false>, clc::COOP_NL, 0);
+    const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, clc::coop_solve_kernel<true, false>, clc::COOP_THREADS, 0);
+    const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, clc::coop_solve_kernel<false, false>, clc::COOP_THREADS, 0);
     h->coop_checked = (e1 == hipSuccess && e2 == hipSuccess && a >= 1 && b >= 1 && h->num_cus >= clc::COOP_WGS) ? 1 : -1;
     (void)hipGetLastError();
   }
@@ -1385,6 +1402,12 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
     CLC_HIP(hipMemsetAsync(h->d_board, 0, sizeof(clc::CoopBoard), h->stream));
     CLC_HIP(hipStreamSynchronize(h->stream));
     h->coop_tag = 1;
+    {  // (tuning hook: first-poll offsets, clc_coop.hpp)
+      unsigned long long d[2] = {0, 0};
+      if (const char* e = std::getenv("CLC_COOP_D1")) d[0] = (unsigned long long)std::atoll(e);
+      if (const char* e = std::getenv("CLC_COOP_D2")) d[1] = (unsigned long long)std::atoll(e);
+      if (d[0] || d[1]) CLC_HIP(hipMemcpy(&h->d_board->ctl[1], d, sizeof(d), hipMemcpyHostToDevice));
+    }
   }
   const unsigned int passes = (unsigned int)opt.max_num_iterations + 4u;
   if (h->coop_tag > 0xFFFFFFFFu - passes - 8u) {  // the 32-bit pass tags are used up: start over on clean boards
@@ -1418,10 +1441,10 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
   h->coop_test_drop = 0;
   if (timed) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
   if (opt.use_loss)
-    hipLaunchKernelGGL((clc::coop_solve_kernel<true, false>), dim3(wgs), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
+    hipLaunchKernelGGL((clc::coop_solve_kernel<true, false>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, d_row, d_desc,
                        h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
   else
-    hipLaunchKernelGGL((clc::coop_solve_kernel<false, false>), dim3(wgs), dim3(clc::COOP_NL), 0, h->stream, h->cres.d_xy, d_row, d_desc,
+    hipLaunchKernelGGL((clc::coop_solve_kernel<false, false>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, d_row, d_desc,
                        h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
   CLC_HIP(hipGetLastError());
   if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
@@ -1507,9 +1530,9 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 
   // a problem one workgroup holds: the whole solve in one single-workgroup launch (default flags only: the explicit flag
   // sets select the step chain / launch pair the bit-identity tests compare; profile_events = 1 asks for per-pass events)
-  if (h->sres.ok && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
+  if (h->sres.ok && h->launch_auto && (h->auto_disable & 2) == 0 && h->grid_override == 0 && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
   // a problem the 256 CUs hold together: the whole solve in one launch of 256 co-resident workgroups (same conditions)
-  if (h->cres.ok && h->launch_auto && h->grid_override == 0 && opt.profile_events != 1 && ++h->coop_eligible > h->coop_retry_at) {
+  if (h->cres.ok && h->launch_auto && (h->auto_disable & 1) == 0 && h->grid_override == 0 && opt.profile_events != 1 && ++h->coop_eligible > h->coop_retry_at) {
     const int rc = solve_coop(h, opt, pose, summary, trace, trace_cap, t0);
     if (rc != kCoopFallback) return rc;
   }
@@ -1870,7 +1893,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->bres.d_row);
     const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->bres.d_desc);
 #define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
-  hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream,        \
+  hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL, kResCtrl##NW>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream, \
                      h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, h->d_summaries, h->d_results, nullptr, nullptr)
 #define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
   do {                                                                                                                        \
@@ -2450,7 +2473,7 @@ extern "C" int clc_debug_coop_control(clc_handle* h, int drop_next, int reenable
   h->coop_test_drop = drop_next;
   if (reenable) {
     h->coop_retry_at = 0;
-    h->coop_backoff = 1024;
+    h->coop_backoff = kCoopBackoff0;
   }
   return CLC_OK;
 }
@@ -2561,6 +2584,11 @@ extern "C" int clc_debug_coop_stamps(void* dst, size_t bytes) {
   void* p = nullptr;
   if (hipGetSymbolAddress(&p, HIP_SYMBOL(clc::clc_coop_stamp_buf)) != hipSuccess) return CLC_ERR_HIP;
   return hipMemset(p, 0, sizeof(clc::clc_coop_stamp_buf)) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
+}
+extern "C" int clc_debug_lmregs_stamps(void* dst, size_t bytes) {
+  if (bytes > sizeof(clc::clc_lmu_ck)) bytes = sizeof(clc::clc_lmu_ck);
+  if (hipDeviceSynchronize() != hipSuccess) return CLC_ERR_HIP;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(clc::clc_lmu_ck), bytes) == hipSuccess ? CLC_OK : CLC_ERR_HIP;
 }
 extern "C" int clc_debug_res_ctrl_stamps(void* dst, size_t bytes) {
   if (bytes > sizeof(clc::clc_res_stamp_ctrl)) bytes = sizeof(clc::clc_res_stamp_ctrl);

@@ -73,6 +73,20 @@ __device__ __forceinline__ void lm_issue_loads(const double* __restrict__ partia
   }
 }
 
+// What the controller publishes for the other waves of the workgroup (LDS): the pose to evaluate next as rotation (row-major) +
+// translation, and whether the solve goes on.
+constexpr int LM_PUB_WORDS = 16;  // R[9], t[3], status (int in word 12)
+
+__device__ __forceinline__ void lm_pub_pose(double* pub, const double* x) {  // called by one lane
+  double R[9];
+  quat_to_rot(x + 3, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) pub[i] = R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pub[9 + i] = x[i];
+}
+__device__ __forceinline__ int lm_pub_status(const double* pub) { return reinterpret_cast<const int*>(pub + 12)[0]; }
+
 // Cycle stamps inside lm_advance_wave (debug build -DCLC_STAMPS, scripts/r02_stamps.py); nothing otherwise.
 #ifdef CLC_STAMPS
 #define CLC_CK() do { ck[nck++] = clock64(); } while (0)

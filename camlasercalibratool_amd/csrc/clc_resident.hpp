@@ -28,6 +28,7 @@
 // CU for problems of up to 512 x 44 points.
 #pragma once
 #include "clc_kernels.hpp"
+#include "clc_lmuni.hpp"
 
 namespace clc {
 
@@ -183,22 +184,37 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
 // host_done (nullable): set to 1 in host memory, system-scope release, once the outcome of EVERY problem of the launch is written
 // (done_count: device counter of finished workgroups, zero between launches; nullable for a single-workgroup launch) — the host
 // polls it instead of blocking on the stream.
-template <bool WITH_LOSS, bool NT, int NW, int PR, int PL>
+// CTRL: 1 = the wave-uniform controller with its state in the registers of wave 0 (clc_lmuni.hpp); 0 = lm_advance_wave on the LDS
+// state (the round-2/3 controller: what tests/test_gpu_lmuni.py compares the other against, bit for bit — same pass, same totals).
+template <bool WITH_LOSS, bool NT, int NW, int PR, int PL, int CTRL>
 __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, clc_iteration* __restrict__ trace,
     const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results,
     int32_t* __restrict__ host_done, unsigned int* __restrict__ done_count) {
   constexpr bool RES_LEAN = NW == 4;  // the controller next to 92 VGPRs of points: the small-footprint form (clc_controller.hpp)
+  // How the pass gets its pose: CTRL 0 — x_eval from the LDS state, every wave turning the quaternion into a wave-uniform (SGPR)
+  // rotation itself; CTRL 1 — as the cooperative kernel: rotation + translation + status published by the controller (six 16-byte
+  // LDS reads).  Same quat_to_rot on the same quaternion either way: the passes of the two forms are bit-identical.
+  constexpr bool POSE_PUB = CTRL != 0;
+#ifndef CLC_RES_PAD_ANALYTIC
+#define CLC_RES_PAD_ANALYTIC 1
+#endif
+  // Padded slots: every lane runs its ppl slots unmasked and the contribution of its zero padding — the same per padded slot — is taken
+  // out analytically once per pass (a logarithm + a reciprocal per lane).  The alternative of clc_coop.hpp (CLC_RES_PAD_ANALYTIC = 0:
+  // masked slots in the groups that some lane has padding in) was measured here and lost: the wave-uniform branch per group and the
+  // second copy of the point code cost the 4-wave form 12 % (C4 shard kernel 0.907 against 0.808 ms, C3 0.141 / 0.124, C1 0.143 / 0.134).
+  constexpr bool PAD_ANALYTIC = CLC_RES_PAD_ANALYTIC != 0;
   constexpr int NL = NW * 64;
   constexpr int NP = PR + PL;  // points a lane can hold
   constexpr int CH = 6;        // LDS points are read in chunks of CH, one chunk ahead of the arithmetic
   constexpr int NCH = (PL + CH - 1) / CH;
   __shared__ v2d sh_pts[(PL > 0 ? PL : 1) * NL];
   __shared__ double sh_state[LM_STATE_WORDS];
-  __shared__ double sh_tot[32];
+  __shared__ __attribute__((aligned(16))) double sh_tot[64];  // CTRL 1: two buffers of 32, the totals of the passes alternate (clc_lmuni.hpp)
   __shared__ double sh_wsum[NW][NACC];
   __shared__ double sh_park[32 + (sizeof(LmScratch) + 7) / 8];
+  __shared__ __attribute__((aligned(16))) double sh_pub[LM_PUB_WORDS];
   const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the iteration trace exists for the single-problem (8-wave) launches only: in the 4-wave form the controller shares the
   // register file with 92 VGPRs of points, and the trace record's code must not be there at all
@@ -251,12 +267,6 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   const double* __restrict__ gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
   const int cnt = dl.cnt;
   if (tid < 7) sh_park[tid] = pose_w;
-  if (wave == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (tid == 0) lm_init(st, opt, sh_park);
-  }
   const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
   // points processed per lane and pass: ppl rounded up to whole groups (GRP points per basic block: independent
   // dependency chains for a wave that has its SIMD to itself while the co-resident problem is in its controller)
@@ -270,6 +280,31 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   constexpr int GRP = NW == 4 ? CLC_RES_GROUP : 2;
   const int ppl_up = (ppl + GRP - 1) / GRP * GRP;
   const int ppl_eff = ppl_up < NP ? ppl_up : NP;
+  // Padding (as clc_coop.hpp): in the blocks that some lane of the wave has padded slots in, a padded slot is evaluated with
+  // r0 = 0 (cost factor exactly 1) and weight 0 (rows_point_masked): no moment moves.
+  const int cnt_m = cnt > 0 ? cnt : ppl_eff;
+  int cmin = cnt_m;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int o2 = __shfl_xor(cmin, off, 64);
+    cmin = o2 < cmin ? o2 : cmin;
+  }
+  cmin = __builtin_amdgcn_readfirstlane(cmin);
+  LmU F;
+  if (wave == cw) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (CTRL) {
+      double x0[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) x0[i] = sh_park[i];
+      lmu_init(F, st, opt, x0, lane);
+      lmu_publish(sh_pub, x0, CLC_RUNNING, lane);
+    } else if (tid == 0) {
+      lm_init(st, opt, sh_park);
+    }
+  }
   __syncthreads();
   RES_STAMP(3, clock64());
 #pragma unroll
@@ -277,9 +312,11 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; }
   int pass_no = 0;  // (debug stamps)
 
-  // one evaluation pass at st.x_eval: the wave's 28 totals -> sh_wsum[wave]
+  // one evaluation pass at the published pose: the wave's 28 totals -> sh_wsum[wave]
   auto pass = [&]() {
     RES_STAMP(4 + 6 * pass_no, clock64());
+    int t = tid;
+    asm volatile("" : "+v"(t));  // (opaque: the pass's LDS addresses are recomputed here, not hoisted out of the loop and spilled)
     // plane of the lane's scan (idle lanes: zeros, scale 0 — their moments are finite and expand to nothing)
     double nx, ny, nz, pd, ps;
     {
@@ -295,46 +332,63 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     if (PL > 0) {
 #pragma unroll
       for (int u = 0; u < CH; ++u)
-        if (u < PL) buf[0][u] = sh_pts[u * NL + tid];
+        if (u < PL) buf[0][u] = sh_pts[u * NL + t];
     }
-    PoseU P;
-    {
+    RowPlane q;
+    if (POSE_PUB) {
+      const v2d* pb = reinterpret_cast<const v2d*>(sh_pub);
+      asm volatile("" : "+v"(pb));
+      const v2d p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3], p4 = pb[4], p5 = pb[5];  // 6 broadcast 16-byte reads
+      const double Rm[9] = {p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1], p4[0]};
+      const double tv[3] = {p4[1], p5[0], p5[1]};
+      rows_plane_setup(Rm, tv, nx, ny, nz, pd, ps, q);
+    } else {
+      PoseU P;
       double x[7];
 #pragma unroll
       for (int i = 0; i < 7; ++i) x[i] = st.x_eval[i];
       load_pose(x, P);
+      rows_plane_setup(P.R, P.t, nx, ny, nz, pd, ps, q);
     }
-    RowPlane q;
-    rows_plane_setup(P.R, P.t, nx, ny, nz, pd, ps, q);
 #ifdef CLC_STAMPS
     if (wave != cw) { asm volatile("" :: "v"(q.mx), "v"(q.c0)); RES_STAMP(8 + 6 * pass_no, clock64()); }  // plane + pose have arrived
 #endif
-    const int npad = ppl_eff - cnt;
-    const double np = (double)npad;
     RowMoments M;
     rows_moments_reset<WITH_LOSS>(M);
 #pragma unroll
     for (int j0 = 0; j0 < NP; j0 += GRP) {
       if (j0 < ppl) {  // wave-uniform; the points of a group in one basic block
+        if (PAD_ANALYTIC || j0 + GRP <= cmin) {  // wave-uniform: no lane of the wave has padding in this group
 #pragma unroll
-        for (int j = j0; j < j0 + GRP && j < NP; ++j) {
-          if (j >= PR && (j - PR) % CH == 0 && (j - PR) / CH + 1 < NCH) {  // entering an LDS chunk: request the next one
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int c1 = (j - PR) / CH + 1;
+          for (int j = j0; j < j0 + GRP && j < NP; ++j) {
+            if (j >= PR && (j - PR) % CH == 0 && (j - PR) / CH + 1 < NCH) {  // entering an LDS chunk: request the next one
+              const int c1 = (j - PR) / CH + 1;
 #pragma unroll
-            for (int u = 0; u < CH; ++u)
-              if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + tid];
+              for (int u = 0; u < CH; ++u)
+                if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+            }
+            const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
+            rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);  // (rows_flush normalises an incomplete last group)
           }
-          const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
-          rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);  // (rows_flush normalises an incomplete last group)
+        } else {
+#pragma unroll
+          for (int j = j0; j < j0 + GRP && j < NP; ++j) {
+            if (j >= PR && (j - PR) % CH == 0 && (j - PR) / CH + 1 < NCH) {
+              const int c1 = (j - PR) / CH + 1;
+#pragma unroll
+              for (int u = 0; u < CH; ++u)
+                if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+            }
+            const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
+            rows_point_masked<WITH_LOSS>(q, j < cnt_m, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);
+          }
         }
       }
     }
-    RES_STAMP(5 + 6 * pass_no, clock64());
-    // the zero padding out again: npad points (0, 0) with r0 = c0 each
     double lp = 0.0;
-    {
+    if (PAD_ANALYTIC) {  // the zero padding out again: npad points (0, 0) with r0 = c0 each
+      const int npad = ppl_eff - cnt;
+      const double np = (double)npad;
       const double c0 = q.c0;
       if (WITH_LOSS) {
         const double sum_p = fma(c0 * c0, inv_lf2, 1.0);
@@ -351,12 +405,15 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
         M.T0 = fma(-cs, c0, M.T0);
         M.prod = fma(-cs * c0, c0, M.prod);
       }
+    } else {
+      rows_pad_correction<WITH_LOSS>(M, (double)(ppl_eff - cnt_m));
     }
+    RES_STAMP(5 + 6 * pass_no, clock64());
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
     rows_flush<WITH_LOSS>(q, M, acc);
-    if (WITH_LOSS) acc[27] = fma(-q.s2, lp, acc[27]);
+    if (PAD_ANALYTIC && WITH_LOSS) acc[27] = fma(-q.s2, lp, acc[27]);
     wave_reduce_butterfly(acc, sh_wsum[wave], lane);
     RES_STAMP(6 + 6 * pass_no, clock64());
   };
@@ -366,71 +423,90 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
       double s = sh_wsum[0][lane];
 #pragma unroll
       for (int w = 1; w < NW; ++w) s += sh_wsum[w][lane];
-      sh_tot[lane] = s;
+      sh_tot[(CTRL ? 32 * (1 - F.hx) : 0) + lane] = s;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-#ifndef CLC_RES_PEEL
-#define CLC_RES_PEEL 1
-#endif
   const int cap = opt.max_num_iterations + 2;
-#if CLC_RES_PEEL
-  pass();
-  __syncthreads();
-  RES_STAMP(7, clock64());
-  if (wave == cw) {
-    totals();
-    RES_STAMP(8, clock64());
-    __builtin_amdgcn_s_setprio(3);  // the serial controller wins the issue arbitration against the co-resident problem's streaming wave
-    int lane_c = lane;
-    asm volatile("" : "+v"(lane_c));  // (opaque: the controller's per-lane LDS addresses are recomputed here, not hoisted out of the pass loop and spilled)
-    lm_advance_wave<true, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);  // contains the barrier ...
-    __builtin_amdgcn_s_setprio(0);
+  if (CTRL) {
+    // one loop, the first pass told apart by a run-time flag (clc_lmuni.hpp: two inlined copies of the controller in one kernel cost the
+    // register allocator ~100 doubles of spills)
+    for (int k = 0; k <= cap && lm_pub_status(sh_pub) == CLC_RUNNING; ++k) {  // (status: published before the barrier)
+      pass();
+      __syncthreads();
+      RES_STAMP(7 + 6 * pass_no, clock64());
+      if (wave == cw) {
+        totals();
+        RES_STAMP(8 + 6 * pass_no, clock64());
+        __builtin_amdgcn_s_setprio(3);  // the controller wins the issue arbitration against the co-resident problem's streaming wave
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+        if (k > 0) lmu_pre(F, st, opt, sh_tot, tr, tr_cap, lane_c);
+        lmu_post(k == 0, F, opt, sh_tot, sh_pub, tr, tr_cap, lane_c);
+        __syncthreads();  // the other waves leave for their pass
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        __syncthreads();
+      }
+      RES_STAMP(9 + 6 * pass_no, clock64());
+      ++pass_no;
+    }
   } else {
-    __syncthreads();  // ... the other waves meet here
-  }
-  RES_STAMP(9, clock64());
-  pass_no = 1;
-  for (int k = 0; k < cap && st.status == CLC_RUNNING; ++k) {  // (status: published before the barrier)
-#else
-  for (int k = -1; k < cap && (k < 0 || st.status == CLC_RUNNING); ++k) {
-#endif
+    // (the first pass is peeled: with both controller instantiations inside one loop the kernel spilled)
     pass();
     __syncthreads();
-    RES_STAMP(7 + 6 * pass_no, clock64());
+    RES_STAMP(7, clock64());
     if (wave == cw) {
       totals();
-      RES_STAMP(8 + 6 * pass_no, clock64());
-#if CLC_RES_PEEL
-      __builtin_amdgcn_s_setprio(3);
+      RES_STAMP(8, clock64());
+      __builtin_amdgcn_s_setprio(3);  // the serial controller wins the issue arbitration against the co-resident problem's streaming wave
       int lane_c = lane;
-      asm volatile("" : "+v"(lane_c));
-#if defined(CLC_STAMPS) && !defined(CLC_RES_NO_CROW)
-      // the controller's own phase stamps (CLC_CK in lm_advance_wave: packed 16-bit cycle deltas into words 15 and 6 of the row)
-      unsigned long long* crow = (blockIdx.x >= CLC_RES_STAMP_BASE && blockIdx.x < CLC_RES_STAMP_BASE + RES_STAMP_WGS)
-                                     ? reinterpret_cast<unsigned long long*>(&clc_res_stamp_ctrl[blockIdx.x - CLC_RES_STAMP_BASE][0]) : nullptr;
-      lm_advance_wave<false, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c, crow);
-#else
-      lm_advance_wave<false, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
-#endif
+      asm volatile("" : "+v"(lane_c));  // (opaque: the controller's per-lane LDS addresses are recomputed here, not hoisted out of the pass loop and spilled)
+      lm_advance_wave<true, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);  // contains the barrier ...
       __builtin_amdgcn_s_setprio(0);
-#else
-      if (k < 0) lm_advance_wave<true, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane);
-      else lm_advance_wave<false, NW == 4>(st, opt, tr, tr_cap, sh_tot, sh_park, lane);
-#endif
     } else {
-      __syncthreads();
+      __syncthreads();  // ... the other waves meet here
     }
-    RES_STAMP(9 + 6 * pass_no, clock64());
-    ++pass_no;
+    RES_STAMP(9, clock64());
+    pass_no = 1;
+    for (int k = 0; k < cap && st.status == CLC_RUNNING; ++k) {  // (status: published before the barrier)
+      pass();
+      __syncthreads();
+      RES_STAMP(7 + 6 * pass_no, clock64());
+      if (wave == cw) {
+        totals();
+        RES_STAMP(8 + 6 * pass_no, clock64());
+        __builtin_amdgcn_s_setprio(3);
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+#if defined(CLC_STAMPS) && !defined(CLC_RES_NO_CROW)
+        // the controller's own phase stamps (CLC_CK in lm_advance_wave: packed 16-bit cycle deltas into words 15 and 6 of the row)
+        unsigned long long* crow = (blockIdx.x >= CLC_RES_STAMP_BASE && blockIdx.x < CLC_RES_STAMP_BASE + RES_STAMP_WGS)
+                                       ? reinterpret_cast<unsigned long long*>(&clc_res_stamp_ctrl[blockIdx.x - CLC_RES_STAMP_BASE][0]) : nullptr;
+        lm_advance_wave<false, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c, crow);
+#else
+        lm_advance_wave<false, RES_LEAN>(st, opt, tr, tr_cap, sh_tot, sh_park, lane_c);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        __syncthreads();
+      }
+      RES_STAMP(9 + 6 * pass_no, clock64());
+      ++pass_no;
+    }
   }
   RES_STAMP(1, wall_clock64());
   if (wave == cw) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (CTRL) {
+      if (F.status == CLC_RUNNING) F.status = CLC_FAILURE;  // unreachable: the controller stops at the iteration cap
+      lmu_finish(F, st, opt, sh_tot, tr, tr_cap, lane);
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     if (lane == 0) {
       if (st.status == CLC_RUNNING) st.status = CLC_FAILURE;  // unreachable: the controller stops at the iteration cap
       batched_write_outcome(st, prob, poses, summaries, results);

@@ -161,6 +161,50 @@ CLC_HD void rows_point(const RowPlane& q, const double inv_lf2, const double x, 
   M.Ty = fma(wr, y, M.Ty);
 }
 
+// The same for a slot of the on-chip lane layouts (clc_coop.hpp, clc_resident.hpp) that may be padding: valid = false (a padded slot,
+// stored as (0, 0)) must leave every moment and the cost product alone — r0 is forced to 0 (cost factor exactly 1) and the weight
+// to 0.  (Forcing r0 alone and subtracting the count of padded slots from S0 afterwards was tried first: a padded slot then weighs
+// 1, and from a start 1e4 m off, where the Cauchy weights of the real points are ~1e-11, S0 lost seven digits to the cancellation.
+// Without the loss every weight IS 1, the subtraction is exact, and a variable weight would only cost the kernel its constant
+// folding: there the caller calls rows_pad_correction.)
+template <bool WITH_LOSS>
+CLC_HD void rows_point_masked(const RowPlane& q, const bool valid, const double inv_lf2, const double x, const double y, RowMoments& M,
+                              const bool renorm = true) {
+  const double r1 = fma(q.my, y, fma(q.mx, x, q.c0));
+  const double r0 = valid ? r1 : 0.0;
+  double w = 1.0;
+  if (WITH_LOSS) {
+    const double sum = fma(r0 * r0, inv_lf2, 1.0);
+    w = rcp_ge1_weight(sum);
+    const double pr = M.prod * sum;
+    if (renorm) {
+      int e;
+      M.prod = frexp_pos(pr, e);
+      M.expo += e;
+    } else {
+      M.prod = pr;
+    }
+  } else {
+    M.prod = fma(r0, r0, M.prod);
+  }
+  if (WITH_LOSS) w = valid ? w : 0.0;  // (without loss the weight is the constant 1: the caller takes the count of padded slots out of S0 — exact)
+  const double wx = w * x, wy = w * y, wr = w * r0;
+  M.S0 += w;
+  M.Sx += wx;
+  M.Sy += wy;
+  M.Sxx = fma(wx, x, M.Sxx);
+  M.Sxy = fma(wx, y, M.Sxy);
+  M.Syy = fma(wy, y, M.Syy);
+  M.T0 += wr;
+  M.Tx = fma(wr, x, M.Tx);
+  M.Ty = fma(wr, y, M.Ty);
+}
+
+template <bool WITH_LOSS>
+CLC_HD void rows_pad_correction(RowMoments& M, const double n_padded_slots) {
+  if (!WITH_LOSS) M.S0 -= n_padded_slots;
+}
+
 // Expand a lane's moments of one scan segment into its 28 accumulators
 // (acc[0..20] H upper triangle row-major, acc[21..26] g, acc[27] sum s^2 log(sum) or sum s^2 r0^2; finalize_cost()
 // applies lf^2/2 resp. 1/2 afterwards, as for the per-point path).

@@ -135,6 +135,11 @@ class Solver:
     def set_stream(self, hip_stream: Optional[int]):
         check(self._L.clc_set_stream(self._h, C.c_void_p(hip_stream or 0)), "clc_set_stream")
 
+    def set_auto_paths(self, disable_mask: int = 0):
+        """clc_set_auto_paths: 1 = no cooperative one-launch solve, 2 = no single-workgroup on-chip solve,
+        4 = the single-workgroup solve runs the cooperative kernel's register-resident controller; 0 = library default."""
+        check(self._L.clc_set_auto_paths(self._h, C.c_int(disable_mask)), "clc_set_auto_paths")
+
     def set_launch(self, grid_blocks: int = 0, flags: int = 0):
         check(self._L.clc_set_launch(self._h, C.c_int(grid_blocks), C.c_int(flags)), "clc_set_launch")
 

@@ -158,6 +158,18 @@ int clc_set_stream(clc_handle* h, void* hip_stream);
  * the array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 
+/* Which of the size-chosen default paths of clc_solve (flags = -1 above) may run; disable_mask is a sum of
+ * 1 = not the cooperative one-launch solve (11 264 < n <= 2.6e6 observations: 256 co-resident workgroups keep the problem on
+ *     chip and exchange their rows through device memory — fast on an otherwise idle GPU; a launch whose workgroups are not all
+ *     resident within 0.2 ms aborts, falls back to the step chain and rests the path on the handle for 16 solves, doubling):
+ *     a process that shares the GPU with long-running kernels can switch it off here and keep every other default;
+ * 2 = not the single-workgroup on-chip solve (n <= 11 264 observations);
+ * 4 = the single-workgroup solve runs the LM controller of the cooperative kernel (wave-uniform arithmetic, state in registers)
+ *     instead of its own (state in LDS) — same arithmetic, bit-identical results, slower there; how the cooperative kernel's
+ *     controller is compared with the serial one on identical totals (tests/test_gpu_lmuni.py).
+ * 0 = library default.  The environment variable CLC_AUTO_PATHS_DISABLE sets the initial mask of every handle. */
+int clc_set_auto_paths(clc_handle* h, int disable_mask);
+
 /* ---- problem assembly (host) --------------------------------------------------------
  * Replaces the residual-block construction loop of CamLaserCalibration,
  * src/LaseCamCalCeres.cpp:222-295 (plane per pose :227-231, scale :239-240, board-edge

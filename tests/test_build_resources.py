@@ -53,7 +53,9 @@ def test_hot_kernels_do_not_spill(usage):
             # in scratch; the point loop reloads two 8-byte values per pass (checked in the ISA).  Bound it so it cannot grow
             # back into the streaming loop unnoticed (it was 376 bytes, with 13 points of every lane in scratch, before the
             # LEAN controller).
-            assert usage[k]["ScratchSize"] <= 128, (k, usage[k])
+            # (the 8-wave form with the cooperative kernel's controller on wave 0 — CTRL = 1, the bit-identity test's vehicle, not a
+            # default path — holds that controller's ~115 VGPRs of state next to the pass and parks ~35 of them)
+            assert usage[k]["ScratchSize"] <= (160 if "Li8ELi4ELi18ELi1E" in k else 128), (k, usage[k])
         else:
             assert usage[k]["ScratchSize"] == 0, (k, usage[k])
         assert usage[k]["VGPRs"] <= 256, (k, usage[k])

@@ -148,9 +148,10 @@ def test_cooperative_solve_at_c2_full_size(sv, oracle_mod):
 
 
 def test_cooperative_solve_that_cannot_complete_falls_back_and_is_disabled(sv, oracle_mod):
-    """The safety net on hardware: a launch that is one workgroup short (test hook) cannot complete its exchange — every poll times out
-    (20 ms), nothing is written, clc_solve answers through the step chain and the handle rests the path (1 024 solves, doubling); re-enabled, it works again
-    on the same boards (the aborted launch's tags are behind the next solve's)."""
+    """The safety net on hardware: a launch that is one workgroup short (test hook) cannot complete its first exchange — the leader that
+    misses a row gives up after the census timeout (200 us), raises the launch's abort word, which every waiting workgroup reads, and the
+    whole grid leaves; nothing is written, clc_solve answers through the step chain within milliseconds and the handle rests the path
+    (16 solves, doubling); re-enabled, it works again on the same boards (the aborted launch's tags are behind the next solve's)."""
     import time
     rec = clc.flatten_observations(sd.sim_fixed_count(13, 120, 400, noise_sigma=0.01), False)
     sv.set_launch(0, -1)
@@ -166,7 +167,7 @@ def test_cooperative_solve_that_cannot_complete_falls_back_and_is_disabled(sv, o
         dt = time.perf_counter() - t0
         _, _, solves, aborts, off = sv.debug_coop()
         assert aborts == aborts0 + 1 and off and solves == solves0, drop
-        assert 0.015 < dt < 2.0, dt  # the timeouts, not a hang
+        assert 0.0002 < dt < 0.005, dt  # the census timeout + the step chain, not 20-60 ms of chained timeouts
         assert r.summary.termination == good.summary.termination and r.summary.num_iterations == good.summary.num_iterations
         assert np.abs(r.pose - good.pose).max() <= 1e-9  # the step chain's answer
         r = sv.solve(X0)  # disabled: the step chain again, at once
@@ -176,12 +177,24 @@ def test_cooperative_solve_that_cannot_complete_falls_back_and_is_disabled(sv, o
         _, _, solves0, aborts0, off0 = sv.debug_coop()
         assert solves0 == solves + 1 and not off0
         assert np.array_equal(r.pose, good.pose) and r.summary.final_cost == good.summary.final_cost
+    # without the hook: the path comes back by itself after 16 eligible solves
+    sv.debug_coop_control(drop_next=1)
+    sv.solve(X0)
+    assert sv.debug_coop()[4]
+    n = 0
+    while sv.debug_coop()[4] and n < 64:
+        sv.solve(X0)
+        n += 1
+    assert n <= 17
+    r = sv.solve(X0)
+    assert np.array_equal(r.pose, good.pose)
+    sv.debug_coop_control(reenable=True)
 
 
 def test_two_handles_solving_at_once(oracle_mod):
     """Two handles (two streams) on the one GPU, driven from two threads: their cooperative launches compete for the same 256 CUs.
-    Whatever the dispatcher does — one launch after the other, or interleaved workgroups that time out and fall back — both
-    answers are right and nothing hangs."""
+    Whatever the dispatcher does — one launch after the other, or interleaved workgroups that give up at the census and fall back —
+    both answers are right, nothing hangs, and the whole exercise stays within a second."""
     import threading
     rec = clc.flatten_observations(sd.sim_fixed_count(17, 100, 500, noise_sigma=0.01), False)
     ref = oracle_mod.solve(rec, X0, linear_solver="qr")
@@ -195,12 +208,17 @@ def test_two_handles_solving_at_once(oracle_mod):
         finally:
             s.close()
 
+    import time
     th = [threading.Thread(target=work, args=(k,)) for k in ("a", "b")]
+    t_all = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
         t.join(timeout=120)
+    t_all = time.perf_counter() - t_all
     assert all(not t.is_alive() for t in th)
+    print("two handles: wall %.3f s, aborts a/b %d/%d" % (t_all, out["a"][-1][3], out["b"][-1][3]))
+    assert t_all < 5.0  # (uploads and context creation included)
     for k in ("a", "b"):
         *res, dbg = out[k]
         for r in res:
