@@ -296,7 +296,7 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
                 rk = _o.solve(r_k, x0[k], linear_solver="qr")
                 w = max(w, float(np.abs(sd.T_from_pose7(mine[k, :7]) - sd.T_from_pose7(rk.pose)).max()))
             res["T_cl_max_abs_err_vs_oracle_sample"] = w
-            res["oracle_sample"] = f"{len(keep)} of {ss.hi - ss.lo} problems of rank 0 (tests/test_gpu_parity.py::test_c4_full_size_shard checks 64 of 8192)"
+            res["oracle_sample"] = f"{len(keep)} of {ss.hi - ss.lo} problems of rank 0 (tests/test_gpu_parity.py::test_c4_full_size_shard checks 512 of 8192)"
     ss.close()
     return res
 
@@ -626,7 +626,7 @@ def main():
                 rk = _o.solve(recs[k], xb[k], linear_solver="qr")
                 w = max(w, float(np.abs(sd.T_from_pose7(pb[k]) - sd.T_from_pose7(rk.pose)).max()))
             out["batched_c3"]["T_cl_max_abs_err_vs_oracle_sample"] = w
-            out["batched_c3"]["oracle_sample"] = f"{len(sample)} of {Pb} problems (tests/test_gpu_parity.py::test_c3_full_size_batch checks 64)"
+            out["batched_c3"]["oracle_sample"] = f"{len(sample)} of {Pb} problems (tests/test_gpu_parity.py::test_c3_full_size_batch checks all 1024)"
 
     # ---- CPU baseline + parity (rank 0, N=1): the oracle's DENSE_QR Ceres restatement, 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

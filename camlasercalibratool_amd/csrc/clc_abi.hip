@@ -595,7 +595,10 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   CLC_HIP(hipMemcpyAsync(&any_z, bzflag.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
   CLC_HIP(hipStreamSynchronize(h->stream));
   const size_t G = (size_t)last_gid + 1;
-  if (G * 4 > n_total) return CLC_OK;  // does not group: not worth it
+  // fewer than 4 points per scan on average: the streaming layouts do not pay (the step chain keeps the 64-byte tiles) — the on-chip
+  // layouts, where a lane carries its own plane anyway, are still built
+  const bool sparse = G * 4 > n_total;
+  if (sparse && T.res == nullptr && T.coop == nullptr) return CLC_OK;
   DevBuf<long long> bstarts(&h->pool);
   CLC_HIP(bstarts.alloc(G + 1));
   hipLaunchKernelGGL(clc::scan_starts_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, h->stream,
@@ -638,7 +641,7 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
     CLC_HIP(hipMemcpyAsync(&total_rows, brbeg.p + G, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     CLC_HIP(hipStreamSynchronize(h->stream));
     R = (long long)total_rows;
-    rows_ok = R > 0 && (size_t)R * clc::ROW <= 3 * n_total + 64 * P;  // rows at least a third full on average
+    rows_ok = !sparse && R > 0 && (size_t)R * clc::ROW <= 3 * n_total + 64 * P;  // rows at least a third full on average
   }
   if (rows_ok) {
     // one padding row each: the streaming loop's prologue loads run unconditionally from clamped row indices
@@ -667,7 +670,7 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   }
   if (T.coop != nullptr) {
     T.coop->ok = false;
-    if (!any_z && P == 1 && h->num_cus >= clc::COOP_WGS) {
+    if (!any_z && P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && !(T.res != nullptr && T.res->ok)) {
       // the one problem in COOP_WGS chunks of equal record counts (a chunk may begin and end inside a scan: res_scan_extent)
       std::vector<long long> chunk(clc::COOP_WGS + 1);
       for (int c = 0; c <= clc::COOP_WGS; ++c) chunk[c] = (long long)((__int128)n * c / clc::COOP_WGS);
@@ -681,7 +684,7 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   }
   CLC_HIP(hipStreamSynchronize(h->stream));  // the temporaries above are freed on return
   *T.n_groups = (long long)G;
-  *T.compact_ok = true;
+  *T.compact_ok = !sparse;
   *T.n_rows = R;
   *T.rows_ok = rows_ok;
   return CLC_OK;
@@ -974,8 +977,10 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
                            // a problem one workgroup can hold (<= 512 lanes x 22 points) also gets the lane layout: clc_solve then runs
                            // its whole LM loop in ONE single-workgroup launch from registers + LDS (solve_resident_single)
                            n <= (size_t)512 * (kResPR512 + kResPL512) ? &h->sres : nullptr, &h->rows_z,
-                           // larger ones, up to 256 x 512 x 16 points, are dealt to 256 workgroups: the cooperative solve (clc_coop.hpp)
-                           (n > (size_t)512 * (kResPR512 + kResPL512) && n <= (size_t)clc::COOP_WGS * clc::COOP_NL * (clc::COOP_PR + clc::COOP_PL)) ? &h->cres : nullptr};
+                           // what one workgroup cannot hold (more points; or more than 512 scans, or scans whose lengths leave
+                           // too many half-filled lanes: a lane holds points of ONE scan), up to 65 536 lanes x 40 points, is
+                           // dealt to 256 workgroups: the cooperative solve (clc_coop.hpp)
+                           n <= (size_t)clc::COOP_WGS * clc::COOP_NL * (clc::COOP_PR + clc::COOP_PL) ? &h->cres : nullptr};
   return build_layouts(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, T);
 }
 

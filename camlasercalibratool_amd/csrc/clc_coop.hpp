@@ -187,6 +187,7 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     }
     __syncthreads();  // barrier 0: the first pose is published
     bool aborted = false;
+
     // When to look: a poll is 17 (5) buffer loads per lane and takes ~1 us to come back, and a poll that goes out before the words it
     // looks for costs a whole round trip more — with the leaders' first poll at barrier A the pass was 1.1 us longer than with that poll
     // 1 000 cycles later.  What follows barrier A does not depend on the problem (the point waves finish and publish the row in ~950
@@ -232,28 +233,45 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
         double s = coop_value(w[0]);
 #pragma unroll
         for (int i = 1; i < 16; ++i) s += coop_value(w[i]);
-        const double o2 = __shfl_xor(s, 32, 64);
-        if (mine && fine) {  // (lanes < 28 are half 0: members 0-15 first)
+        double s_lo = s, s_hi = s;
+        swap_halves(s_lo, s_hi);  // lanes < 32: own half (members 0-15) + the other half's (16-31)
+        if (mine && fine) {
 #pragma unroll
-          for (int r = 0; r < COOP_REPLICAS; ++r) coop_put(rs, coop_row_b(par, (r + grp) % COOP_REPLICAS, grp), lane, s + o2, tag);
+          for (int r = 0; r < COOP_REPLICAS; ++r) coop_put(rs, coop_row_b(par, (r + grp) % COOP_REPLICAS, grp), lane, s_lo + s_hi, tag);
         }
         COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 4);
       }
-      // what does not need the totals, while the (group) rows travel
-      if (k > 0) lmu_pre(S, st, opt, sh_tot, tr, tr_cap, lane);
-      COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 11);
+      // What does not need the totals (lmu_pre), while the (group) rows travel.  A follower has the whole of hop 1 for it and looks at
+      // the group rows afterwards; a leader has just published its group row — its first look at the 8 group rows goes out BEFORE its
+      // lmu_pre and is evaluated behind it (lmu_pre is about as long as the hop: issued after it, that poll cost the leaders, and with
+      // them every workgroup's next pass, ~700 cycles).
+      if (k > 0 && !leader) lmu_pre(S, st, opt, sh_tot, tr, tr_cap, lane);
+      if (!leader) COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 11);
       if (fine) {
         // the 8 group rows: groups 4 h .. 4 h + 3
         coop_wait_until(t_a + d2);
-        v4u w[4];
         const unsigned int base = coop_row_b(par, wg % COOP_REPLICAS, 4 * h) + 16u * (unsigned int)e;
         const unsigned long long t0 = wall_clock64();
+        bool pre_due = k > 0 && leader;
+        // One look in flight at a time.  Measured and dropped: 2-3 looks in flight 256 cycles apart (6.8-7.1 us per pass against
+        // 6.2: the extra requests slow the rows they look for), copies of the group-row board (8 or 32: the leaders' extra stores
+        // cost more than the shorter queues save), a leader taking its own group row from registers with its first look issued
+        // before its store (+0.15 us: that look goes out too early, see d2).
+        v4u w[4];
         for (;;) {
           bool ok = true;
           unsigned int bo = base;
           asm volatile("" : "+v"(bo));  // (a fresh sample every iteration)
 #pragma unroll
           for (int i = 0; i < 4; ++i) w[i] = coop_get(rs, bo + (unsigned int)(i * COOP_ROW_WORDS * 8));
+          if (pre_due) {  // (wave-uniform; the loads above stay in flight: nothing below touches their registers)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            lmu_pre(S, st, opt, sh_tot, tr, tr_cap, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 11);
+            pre_due = false;
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) ok = ok && coop_valid(w[i], tag);
           if (__all(ok)) break;
@@ -269,8 +287,9 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
         double s = coop_value(w[0]);
 #pragma unroll
         for (int i = 1; i < 4; ++i) s += coop_value(w[i]);
-        const double o2 = __shfl_xor(s, 32, 64);
-        if (mine) sh_tot[32 * (1 - S.hx) + lane] = s + o2;
+        double s_lo = s, s_hi = s;
+        swap_halves(s_lo, s_hi);  // lanes < 32: s_lo = own half, s_hi = the other half's sum (two v_permlane32_swap: a third of a ds_bpermute shuffle)
+        if (mine) sh_tot[32 * (1 - S.hx) + lane] = s_lo + s_hi;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();

@@ -264,7 +264,7 @@ __device__ __forceinline__ void lmu_post(const bool first, LmU& S, const clc_opt
                                          clc_iteration* __restrict__ trace, const int trace_cap, const int lane) {
   constexpr int NP = 6, NA = 7;
   constexpr double DMAX = 1.7976931348623157e308;
-  LMU_CK(0);
+  LMU_CK(7);  // (slot 0 at the end: the last pass of a solve leaves at its tolerance test)
   double T[28];
   lmu_read_totals(tot2 + 32 * (1 - S.hx), T);
   if (__builtin_expect(S.deferred != 0, 0)) {  // (wave-uniform, rare) the pass under way was evaluated for nothing
@@ -447,6 +447,9 @@ __device__ __forceinline__ void lmu_post(const bool first, LmU& S, const clc_opt
   // ---- what the other waves wait for: the next pose to evaluate ----
   lmu_publish(pub, S.xe, CLC_RUNNING, lane);
   LMU_CK(6);
+#ifdef CLC_STAMPS
+  if (blockIdx.x == 8 && lane == 0 && !first) clc_lmu_ck[0] = clc_lmu_ck[7];
+#endif
 }
 
 // End of the solve: the last iteration's record, and the outputs into the LDS state (batched_write_outcome / lm_fill_summary read

@@ -2,7 +2,8 @@
 """Small profiling targets (one per invocation) to run under rocprofv3 with a timeout:
    resident P      batched solve of P problems x 1e4 observations on the resident kernel (5 solves) and on the round-2 path (5 solves)
    step N          5 clc_solve of an N-observation problem through the step-kernel chain
-   coop N          5 default clc_solve of an N-observation problem: one coop_solve_kernel launch each (csrc/clc_coop.hpp)
+   coop N [ITERS]  5 default clc_solve of an N-observation problem: one coop_solve_kernel launch each (csrc/clc_coop.hpp); ITERS caps
+                   max_num_iterations (two pass counts give the instructions per pass)
    eval N          20 launches of the row-layout evaluation kernel on N observations + 20 of the 64-byte-tile kernel (PMC calibration)"""
 import json, os, sys, time
 import numpy as np
@@ -33,8 +34,11 @@ elif what == "coop":
     rec = clc.flatten_observations(sd.sim_fixed_count(1000, n // 500, 500, noise_sigma=0.01), False)
     sv.upload(rec)
     built, ppl, _, _, _ = sv.debug_coop()
+    o = clc.default_options()
+    if len(sys.argv) > 3:
+        o.max_num_iterations = int(sys.argv[3])
     for _ in range(5):
-        r = sv.solve(x0, trace_cap=0)
+        r = sv.solve(x0, o, trace_cap=0)
     _, _, solves, aborts, off = sv.debug_coop()
     out.update(coop_built=built, points_per_lane=ppl, coop_solves=solves, aborts=aborts, passes=int(r.summary.num_evaluations), solve_ms=r.summary.solve_ms,
                lane_layout_bytes=256 * ppl * 256 * 16 + 256 * 256 * 8 + (n // 500) * 48)

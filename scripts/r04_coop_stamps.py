@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Where a pass of coop_solve_kernel goes, round 4 (C2 shape): a -DCLC_STAMPS build (python scripts/r04_coop_stamps.py --build where
 hipcc is) stamps, per pass, wave 0 (and wave 3) of workgroups 0 and 7 (leaders), 8 and 255 with the shader clock — slots of
-csrc/clc_coop.hpp: 0 pass start, 8 pose + plane set up, 9 points done, 10 expansion done, 1 partials in LDS, 2 row published (behind the
-pass barrier), 11 lm_regs_pre done, 3 group rows gathered / 4 group row published (leaders), 5 the 8 group rows arrived, 6 totals in
-LDS, 7 controller done (behind its barrier and the iteration record).
+csrc/clc_coop.hpp: 0 pass start, 8 pose + plane set up, 9 points done, 10 expansion done, 1 partials in LDS, 2 row published (behind
+barrier A), 3 group rows gathered / 4 group row published (leaders), 11 lmu_pre done (leaders: after 4), 5 the 8 group rows arrived,
+6 totals in LDS, 7 lmu_post done (before barrier B).  Slots 0-2, 8-10 are point wave 0's, the others the controller wave's.
 usage (GPU box): CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_stamps.so python scripts/r04_coop_stamps.py [n_poses] [pts]"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,19 +28,19 @@ sv.upload(rec)
 x0 = sd.pose7_from_T(np.eye(4))
 print("coop:", sv.debug_coop())
 for _ in range(3):
-    sv.solve(x0)
+    sv.solve(x0, trace_cap=0)
 NP, PP = 16, 12
 buf = np.zeros((4, 2, PP * NP + 2), dtype=np.int64)
 L.clc_debug_coop_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.clc_debug_coop_stamps(buf.ctypes.data, buf.nbytes) == 0  # clears
 o = clc.default_options(); o.profile_events = 2
-r = sv.solve(x0, o)
+r = sv.solve(x0, o, trace_cap=0)  # (no trace: its device stores would make workgroup 0 the slowest)
 assert L.clc_debug_coop_stamps(buf.ctypes.data, buf.nbytes) == 0
 ne = r.summary.num_evaluations
 print(f"evaluations {ne}, kernel {1e3 * r.summary.eval_kernel_ms:.1f} us (stamped build)")
 wgs = ["wg 0 (leader)", "wg 7 (leader)", "wg 8", "wg 255"]
-names = ["pose + plane set-up", "points", "expansion (rows_flush)", "butterfly 28 -> 7 + LDS", "barrier + row finished + published", "lm_regs_pre",
-         "gather group rows + publish (leaders)", "8 group rows arrive", "totals -> LDS", "controller + barrier + record", "-> next pass start"]
+names = ["pose + plane set-up", "points", "expansion (rows_flush)", "butterfly 28 -> 7 + LDS", "barrier A + row finished + published", "gather the group's 32 rows (leaders)",
+         "group row summed + published (leaders)", "lmu_pre (leaders: behind their first look)", "8 group rows arrive (after lmu_pre)", "totals -> LDS", "lmu_post + barrier B", "-> next pass start"]
 for w in range(4):
     t = buf[w, 0]
     t3 = buf[w, 1]
@@ -50,8 +50,8 @@ for w in range(4):
         s = t[PP * p: PP * p + PP]
         nxt = t[PP * (p + 1)]
         lead = s[3] != 0
-        d = [s[8] - s[0], s[9] - s[8], s[10] - s[9], s[1] - s[10], s[2] - s[1], s[11] - s[2], (s[4] - s[11]) if lead else 0, s[5] - (s[4] if lead else s[11]),
-             s[6] - s[5], s[7] - s[6], nxt - s[7]]
+        d = [s[8] - s[0], s[9] - s[8], s[10] - s[9], s[1] - s[10], s[2] - s[1], (s[3] - s[2]) if lead else 0, (s[4] - s[3]) if lead else 0,
+             s[11] - (s[4] if lead else s[2]), s[5] - s[11], s[6] - s[5], s[7] - s[6], nxt - s[7]]
         per.append(d)
     per = np.array(per, dtype=float)
     for i, nm in enumerate(names):
@@ -64,10 +64,8 @@ print("entry -> last controller done (cycles):", span.tolist(), " => shader cloc
 ck = np.zeros(16, dtype=np.int64)
 L.clc_debug_lmregs_stamps.argtypes = [C.c_void_p, C.c_size_t]
 if L.clc_debug_lmregs_stamps(ck.ctypes.data, ck.nbytes) == 0:
-    nm = ["totals read, acceptance, selects", "scaling, damped diagonal", "Cholesky", "forward + backward substitution", "finite test, model cost change",
-          "Plus x 2 + gradient norm + status tests", "commit", "publish"]
-    print("lmu_post of workgroup 8 (cycles; the last pass ends at its tolerance test, so slot 0 is one pass newer than the rest):",
-          ", ".join(f"{n} {ck[i+1]-ck[i]}" for i, n in enumerate(nm)), f"; slots 1..8 {ck[8]-ck[1]}")
+    nm = ["totals read (14 LDS), acceptance, selects, x / g / H at x", "scaling, damped diagonal", "Cholesky", "forward + backward substitution", "Plus (candidate)", "rotation + publish"]
+    print("lmu_post of workgroup 8, a steady-state pass (cycles, each slot incl. its own stamp ~60):", ", ".join(f"{n} {ck[i+1]-ck[i]}" for i, n in enumerate(nm)), f"; total {ck[6]-ck[0]}")
 # chronological timeline of one steady-state pass per stamped workgroup (cycles since that workgroup's pass start)
 slot_names = {0: "pass start", 8: "plane set up", 9: "points done", 10: "expansion done", 1: "partials in LDS", 2: "row published", 3: "group rows gathered (leader)",
               4: "group row published (leader)", 11: "lmu_pre done", 5: "8 group rows arrived", 6: "totals in LDS", 7: "pose published (before barrier B)"}

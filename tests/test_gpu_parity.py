@@ -610,7 +610,7 @@ def test_c3_full_size_batch(sv, oracle_mod):
     """configs[2] at full size: 1 024 independent T_cl problems x 10^4 observations (655 MB).
     Size-independent properties on all problems (every problem terminates by convergence at a
     cost no higher than where it started, recovers its own ground truth to the noise level, the
-    batch is permutation-equivariant) + oracle parity on a sample."""
+    batch is permutation-equivariant) + oracle parity on ALL 1 024 problems (~15 s of CPU)."""
     P = 1024
     probs, gts = sd.sim_batch(4242, P, 20, 500, noise_sigma=0.01)
     recs = [clc.flatten_observations(p, False) for p in probs]
@@ -641,10 +641,10 @@ def test_c3_full_size_batch(sv, oracle_mod):
         assert sms[k].final_cost <= sms[k].initial_cost
         assert np.abs(sd.T_from_pose7(poses[k]) - gts[k]).max() < 0.02, k
         assert abs(np.linalg.norm(poses[k, 3:]) - 1) < 1e-14
-    for k in range(0, P, 16):  # 64 of the 1 024 problems against the oracle's DENSE_QR solve
+    for k in range(P):  # every problem against the oracle's DENSE_QR solve
         ref = oracle_mod.solve(recs[k], x0[k], linear_solver="qr")
-        assert sms[k].num_iterations == ref.summary.num_iterations
-        assert _dT(poses[k], ref.pose) <= T_TOL and abs(sms[k].final_cost - ref.summary.final_cost) <= COST_TOL
+        assert sms[k].num_iterations == ref.summary.num_iterations and sms[k].termination == ref.summary.termination, k
+        assert _dT(poses[k], ref.pose) <= T_TOL and abs(sms[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
     # permutation equivariance: reversing the problem order reverses the results bit for bit
     perm = np.arange(P)[::-1]
     off2 = np.zeros(P + 1, dtype=np.int64)
@@ -894,8 +894,8 @@ def test_c4_full_size_shard(sv, oracle_mod):
     """configs[3], one GPU's share at full size: 8 192 independent T_cl problems x 10^4 observations (5.2 GB of
     records), solved by clc_solve_batched and gathered through RCCL.  Size-independent properties on ALL problems
     (termination by convergence at a cost no higher than the start, unit quaternions, own ground truth recovered to the
-    noise level, solving twice is bitwise repeatable) + oracle parity (DENSE_QR Ceres restatement) on 64 sampled
-    problems regenerated one by one from (seed, global index)."""
+    noise level, solving twice is bitwise repeatable) + oracle parity (DENSE_QR Ceres restatement) on 512 sampled
+    problems (every 16th) regenerated one by one from (seed, global index)."""
     from camlasercalibratool_amd import dist as cdist
 
     P, n_poses, K, seed, lo = 8192, 20, 500, 65536, 3 * 8192  # the shard rank 3 of 8 would own
@@ -915,7 +915,7 @@ def test_c4_full_size_shard(sv, oracle_mod):
     assert np.abs(np.linalg.norm(raw[:, 3:7], axis=1) - 1).max() < 1e-14
     worst = max(np.abs(sd.T_from_pose7(raw[k, :7]) - gt[k]).max() for k in range(P))
     assert worst < 0.02, worst
-    for k in range(0, P, 128):  # 64 problems
+    for k in range(0, P, 16):  # 512 problems
         one = sd.sim_shard(seed, lo + k, lo + k + 1, n_poses, K, 0.01)
         r1, _ = one.records()
         ref = oracle_mod.solve(r1, x0[k], linear_solver="qr")
