@@ -18,7 +18,14 @@ ONLY ITS OWN contiguous shard (problem k is a pure function of (seed, k)), keeps
 (clc_upload_batched), and a step is: clc_solve_batched of the shard + ONE RCCL all-gather over xGMI of the
 12-double result records of all 8 192 x N problems (clc_gather_results, include/clc.h), inside the timed region.
 No collective on the data path.  At N=1 the same shard workload (with a world-size-1 RCCL communicator) is reported
-as the `batched_c4_shard` sub-object, the like-for-like base of the 1 -> 8 curve.
+as the `batched_c4_shard` sub-object, the like-for-like base of the 1 -> 8 curve: the N=1 line carries it at top level as
+`scale_base` {workload, value}, the N>1 lines carry `per_gpu_value` (= value / N) to set against it.
+
+`roofline` is the dominant kernel of the timed region.  Both whole-solve kernels (coop_solve_kernel at C2, resident_solve_kernel
+at C4) read the data from HBM once per SOLVE and are bound by FP64 VALU issue / latency: their object has "bound": "valu_f64"
+and `frac` = VALU lane-instructions (constants of the build x this run's passes) / this run's kernel time / issue peak;
+`frac_moved` (bytes moved / time / 8 TB/s, bounded by 1) and `contract_64B_frac` (the contract's 64 algorithmic bytes per evaluation,
+not a bandwidth) are siblings.  The streaming kernels' objects have "bound": "hbm" with `frac` = `frac_moved`.
 
 value = residual+Jacobian evaluations per second, whole job:
         sum over ranks of (observations x evaluation passes) / max-over-ranks wall time.
@@ -45,9 +52,27 @@ MIN_BYTES_PER_POINT = 16     # what the reference's own container holds per obse
 MIN_BYTES_PER_SCAN = 40      # ... plus one plane (4 doubles) and one scale per Oberserve (include/LaseCamCalCeres.h:11-24)
 INFINITY_CACHE_BYTES = 256 * 2**20
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: FP64 (and any other) VALU issue peak
-# VALU instructions one wave issues per evaluation pass of resident_solve_kernel<loss, nt, 4 waves, 23 + 19 points> at 42 points
-# per lane (static count of the pass in the gfx950 ISA, scripts/isa_hist.py; profiles/r03_resident.md): 1 310, of them ~1 050 FP64
-RESIDENT_VALU_PER_WAVE_PASS_42 = 1310
+# VALU wave-instructions of resident_solve_kernel<loss, nt, 4 waves, 23 + 19 points> per wave and evaluation pass at 42 points per
+# lane, the controller's share (wave 0, between passes) included: the pass's instruction stream does not depend on the data, so
+# the count per pass is a constant of the build — PMC SQ_INSTS_VALU / (passes x 4 waves) of profiles/r04_resident.md (1 478; the
+# static count of the pass alone in the ISA, scripts/isa_hist.py, is 1 310)
+RESIDENT_VALU_PER_WAVE_PASS_42 = 1478
+# coop_solve_kernel<loss> at 16 points per lane (C2): VALU wave-instructions one WORKGROUP (4 point waves + the controller wave)
+# issues per evaluation pass, and once per launch outside the passes — the difference of a 13-pass and a 5-pass launch under
+# --pmc SQ_INSTS_VALU, profiles/r04_coop.md (the pass's instruction stream does not depend on the data)
+COOP_VALU_PER_WG_PASS = {16: 3298}
+COOP_VALU_PER_WG_ONCE = {16: 1041}
+
+
+def hbm_figures(moved_bytes, contract_bytes, sec):
+    """The figures of an HBM-bound launch: `achieved` / `frac` price the bytes the layout actually MOVES (a bandwidth, bounded by 1);
+    the contract's pricing — 64 algorithmic bytes per residual+Jacobian evaluation, which a lossless 3.7x smaller
+    layout or data held on chip can exceed the peak with — is kept next to it as contract_64B_*."""
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": moved_bytes / sec / 1e9, "frac": moved_bytes / sec / 1e9 / HBM_PEAK_GBS,
+            "frac_moved": moved_bytes / sec / 1e9 / HBM_PEAK_GBS, "moved_bytes_per_launch": int(moved_bytes),
+            "algorithmic_bytes_per_launch": int(contract_bytes), "contract_64B_GBps": contract_bytes / sec / 1e9,
+            "contract_64B_frac": contract_bytes / sec / 1e9 / HBM_PEAK_GBS}
 
 
 def pricings(n_obs, n_scans, moved_bytes, seconds):
@@ -118,25 +143,38 @@ def resident_kernel_report(clc, solver, x_start, n_problems, n_obs_total, n_scan
     evals = float(sum(sms[k].num_evaluations for k in range(n_problems))) * per
     moved = rows * lanes * 16 + n_problems * lanes * 8 + n_scans_total * 48  # point rows + lane descriptors + plane table, once
     sec = best * 1e-3
-    rep = {"bound": "valu_f64", "kernel": f"clc::resident_solve_kernel<loss=1, {lanes // 64} waves per problem> (whole LM solve of every problem in ONE launch; "
-                                          f"{lanes} lanes x {ppl} points per problem held in registers + LDS)",
+    rep = {"bound": "valu_f64", "peak": VALU_PEAK_LANE_INSTR / 1e12, "unit": "T VALU lane-instructions/s", "achieved": None, "frac": None,
+           "kernel": f"clc::resident_solve_kernel<loss=1, {lanes // 64} waves per problem> (whole LM solve of every problem in ONE launch; "
+                     f"{lanes} lanes x {ppl} points per problem held in registers + LDS)",
            "launches_per_batch": 1, "avg_kernel_ms": best, "evaluation_passes": passes,
-           "moved_bytes_per_launch": int(moved), "achieved_moved": moved / sec / 1e9, "frac_moved": moved / sec / 1e9 / HBM_PEAK_GBS,
+           "moved_bytes_per_launch": int(moved), "achieved_moved_GBps": moved / sec / 1e9, "frac_moved": moved / sec / 1e9 / HBM_PEAK_GBS,
            "served_from": "infinity_cache" if moved <= INFINITY_CACHE_BYTES else "hbm", "traffic_measured_in_run": False, "traffic": None,
            "hbm_passes_over_the_data_per_solve": 1,
-           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * evals, "achieved": BYTES_PER_EVAL * evals / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": BYTES_PER_EVAL * evals / sec / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * evals, "contract_64B_GBps": BYTES_PER_EVAL * evals / sec / 1e9,
+           "contract_64B_frac": BYTES_PER_EVAL * evals / sec / 1e9 / HBM_PEAK_GBS,
            "pricings": pricings(evals, n_scans_total * passes / max(1, n_problems), moved, sec),
            "timing": "hipEvent pair around the launch on the solver's stream (profile_events = 1), best of 5",
-           "note": "`frac` prices the launch at the contract's 64 algorithmic bytes per evaluation x all passes and exceeds 1: the data crosses "
-                   "HBM once per SOLVE, not once per pass; `frac_moved` is the HBM fraction (bounded by 1); the kernel is VALU-issue bound (`valu_issue`)"}
-    if lanes == 256 and ppl == 42:
-        lane_instr = passes * 4.0 * RESIDENT_VALU_PER_WAVE_PASS_42 * 64
-        rep["valu_issue"] = {"valu_instructions_per_wave_and_pass": RESIDENT_VALU_PER_WAVE_PASS_42, "lane_instructions": lane_instr,
-                             "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR, "frac": lane_instr / sec / VALU_PEAK_LANE_INSTR,
-                             "note": "static VALU count of one pass in the ISA (42 points per lane: 21.5 per point + per-pass moment expansion, padding "
-                                     "correction and wave reduction) x waves x passes, against 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz; the serial LM "
-                                     "controller between passes (~5 000 cycles on one wave) is not counted as work"}
+           "note": "the data crosses HBM once per SOLVE, not once per pass (`frac_moved`, bounded by 1); the launch is bound by FP64 VALU issue: "
+                   "`frac` = VALU lane-instructions / kernel time / issue peak.  `contract_64B_frac` prices the launch at the contract's 64 algorithmic "
+                   "bytes per evaluation x all passes and is not a bandwidth"}
+    tfile = os.path.join(ROOT, "profiles", "r04_resident_traffic.json")
+    if os.path.exists(tfile) and n_problems == 8192:
+        try:
+            rep["traffic"] = json.load(open(tfile)).get("pmc_read_bytes_per_batch")
+            rep["traffic_source"] = "profiles/r04_resident.md (rocprofv3 --pmc FETCH_SIZE of the builder's run; 1.009 x one pass over the lane layout)"
+        except Exception:
+            pass
+    # per wave and pass: 21.5 VALU instructions per point + what does not depend on the points; exact at 42 points per lane (PMC), an
+    # estimate elsewhere
+    per_wave_pass = RESIDENT_VALU_PER_WAVE_PASS_42 + 21.5 * (ppl - 42)
+    lane_instr = passes * (lanes / 64.0) * per_wave_pass * 64
+    rep["achieved"] = lane_instr / sec / 1e12
+    rep["frac"] = lane_instr / sec / VALU_PEAK_LANE_INSTR
+    rep["valu_issue"] = {"valu_instructions_per_wave_and_pass": per_wave_pass, "exact": bool(lanes == 256 and ppl == 42), "lane_instructions": lane_instr,
+                         "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR, "frac": lane_instr / sec / VALU_PEAK_LANE_INSTR,
+                         "note": "VALU wave-instructions per wave and pass (a constant of the build at 42 points per lane: 21.5 per point + the per-pass moment "
+                                 "expansion, padding correction, wave reduction and the controller's share; profiles/r04_resident.md) x waves x this "
+                                 "run's passes x 64 lanes, over this run's kernel time, against 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz"}
     return rep
 
 
@@ -166,24 +204,34 @@ def coop_kernel_report(clc, solver, x0, n_obs, n_scans):
     # lane layout (16 B per point slot, zero-padded to ppl per lane) + lane descriptors + plane table, read once; + the exchange words
     moved = COOP_WGS * ppl * COOP_LANES * 16 + COOP_WGS * COOP_LANES * 8 + n_scans * 48
     exchange = passes * (COOP_WGS * 448 * 2 + 8 * 448 * (1 + COOP_WGS))  # rows written + read by the 8 leaders, group rows written + read by all
-    rep = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "kernel": f"clc::coop_solve_kernel<loss=1> (the whole LM solve in ONE launch: {COOP_WGS} co-resident workgroups x {COOP_LANES} lanes x {ppl} points "
-                     "per lane in registers + LDS; per pass: lane moments -> two-level exchange of the 28 totals through tagged words -> LM controller in every workgroup)",
+    vp, vo = COOP_VALU_PER_WG_PASS.get(ppl), COOP_VALU_PER_WG_ONCE.get(ppl, 0)
+    lane_instr = 64.0 * COOP_WGS * (passes * vp + vo) if vp else None
+    rep = {"bound": "valu_f64", "peak": VALU_PEAK_LANE_INSTR / 1e12, "unit": "T VALU lane-instructions/s",
+           "achieved": lane_instr / sec / 1e12 if vp else None, "frac": lane_instr / sec / VALU_PEAK_LANE_INSTR if vp else None,
+           "kernel": f"clc::coop_solve_kernel<loss=1> (the whole LM solve in ONE launch: {COOP_WGS} co-resident workgroups x ({COOP_LANES} point lanes x {ppl} points "
+                     "per lane in registers + LDS, + one controller wave); per pass: lane moments -> two-level exchange of the 28 totals through tagged words -> "
+                     "LM controller (csrc/clc_lmuni.hpp) on the controller wave of every workgroup)",
            "launches_per_solve": 1, "avg_kernel_ms": best, "evaluation_passes": passes, "us_per_pass": 1e3 * best / passes,
-           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * evals, "achieved": BYTES_PER_EVAL * evals / sec / 1e9,
-           "frac": BYTES_PER_EVAL * evals / sec / 1e9 / HBM_PEAK_GBS,
-           "moved_bytes_per_launch": int(moved + exchange), "achieved_moved": (moved + exchange) / sec / 1e9,
+           "valu_issue": {"valu_wave_instructions_per_workgroup_and_pass": vp, "valu_wave_instructions_per_workgroup_once": vo,
+                          "lane_instructions_per_launch": lane_instr, "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR,
+                          "note": "instruction counts are constants of the build at this many points per lane (profiles/r04_coop.md: --pmc SQ_INSTS_VALU of a 13-pass and "
+                                  "a 5-pass launch); x 256 workgroups x this run's passes x 64 lanes, over this run's kernel time, against 256 CUs x 4 SIMDs x "
+                                  "16 lanes/clk x 2.4 GHz.  A fifth of the issue peak: the launch waits more than it computes, see `limited_by`"},
+           "limited_by": "latency: a pass is the serial chain [pose + lane moments + expansion + wave reduction, FP64 issue on one wave per SIMD, ~2.3 us at 16 points "
+                         "per lane] -> [exchange: 32 rows -> 8 group leaders -> everyone, two store-to-load hops through device memory of ~1.1 us each] -> "
+                         "[LM controller's critical part on one wave, ~1.5 us]; stamps of a -DCLC_STAMPS build in profiles/r04_coop.md",
+           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * evals, "contract_64B_GBps": BYTES_PER_EVAL * evals / sec / 1e9,
+           "contract_64B_frac": BYTES_PER_EVAL * evals / sec / 1e9 / HBM_PEAK_GBS,
+           "moved_bytes_per_launch": int(moved + exchange), "achieved_moved_GBps": (moved + exchange) / sec / 1e9,
            "frac_moved": (moved + exchange) / sec / 1e9 / HBM_PEAK_GBS,
            "hbm_passes_over_the_data_per_solve": 1, "exchange_bytes_per_launch": int(exchange),
            "served_from": "infinity_cache" if moved <= INFINITY_CACHE_BYTES else "hbm", "traffic_measured_in_run": False, "traffic": None,
            "pricings": pricings(evals, n_scans * passes, moved + exchange, sec),
-           "limited_by": "latency, not bandwidth: a pass is the serial chain lane moments + expansion + wave reduction (~2.1 us at 16 points per lane, FP64 issue "
-                         "on one wave per SIMD) -> exchange (2 hops through device memory, ~2.5 us) -> LM controller (~2.4 us on one wave); scripts/r03_coop_stamps.py",
            "timing": "hipEvent pair around the launch on the solver's stream (profile_events = 2), best of 7",
            "cooperative_launch_timeouts": aborts,
-           "note": "`frac` prices the launch at the contract's 64 algorithmic bytes per evaluation x all passes and exceeds 1: the observations cross HBM once "
-                   "per SOLVE (then live in registers + LDS), not once per pass; `frac_moved` = bytes actually moved / time / 8 TB/s is the HBM fraction "
-                   "(bounded by 1) and is small because the launch is latency-bound — see `limited_by`, and `roofline_step_chain` / `roofline_large` for the streaming kernels"}
+           "note": "the observations cross HBM once per SOLVE (then live in registers + LDS): `frac_moved` = bytes actually moved / time / 8 TB/s is the HBM "
+                   "fraction (bounded by 1, and small: the launch is not bandwidth-bound); `contract_64B_frac` prices the launch at the contract's 64 "
+                   "algorithmic bytes per evaluation x all passes and is not a bandwidth.  `roofline_step_chain` / `roofline_large` are the streaming kernels"}
     return rep
 
 
@@ -275,17 +323,11 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         kms = min(ss.solver.time_batched_eval(x0, reps=10) for _ in range(3))
         _, _, brows_ok, bn_rows = ss.solver.debug_rows()
         streamed = bn_rows * ROW_BYTES if brows_ok else COMPACT_BYTES_PER_EVAL * n_obs_local
-        res["roofline"] = {"bound": "hbm", "traffic": None,
-                           "kernel": ("clc::batched_rows_eval_kernel<loss=1,nt=1>" if brows_ok else "clc::batched_eval_kernel<compact,deep>")
-                                     + " (all problems of the shard active)",
-                           "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs_local, "streamed_bytes_per_launch": int(streamed),
-                           "avg_kernel_ms": kms,
-                           "achieved": BYTES_PER_EVAL * n_obs_local / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": BYTES_PER_EVAL * n_obs_local / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "achieved_streamed": streamed / (kms * 1e-3) / 1e9, "frac_streamed": streamed / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "frac_moved": streamed / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "served_from": "infinity_cache" if streamed <= INFINITY_CACHE_BYTES else "hbm", "traffic_measured_in_run": False,
-                           "timing": "hipEvent pair around 10 back-to-back launches on the solver's stream (best of 3)"}
+        res["roofline"] = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs_local, kms * 1e-3), traffic=None,
+                               kernel=("clc::batched_rows_eval_kernel<loss=1,nt=1>" if brows_ok else "clc::batched_eval_kernel<compact,deep>")
+                                      + " (all problems of the shard active)",
+                               avg_kernel_ms=kms, served_from="infinity_cache" if streamed <= INFINITY_CACHE_BYTES else "hbm",
+                               traffic_measured_in_run=False, timing="hipEvent pair around 10 back-to-back launches on the solver's stream (best of 3)")
         if rk is not None:
             rk["streaming_eval_kernel"] = res["roofline"]
             res["roofline"] = rk
@@ -365,6 +407,10 @@ def main():
                 "problems_per_s": c4["problems_per_s"], "lm_iters_per_s": c4["lm_iters_per_s"],
                 "roofline": c4.pop("roofline"),
                 "batched_c4_shard": c4,
+                # the N=1 line's `value` is C2 (the configuration the metric is quoted on, a single problem that does not shard); the base
+                # of THIS curve is the same line's top-level `scale_base.value` (= its batched_c4_shard.evals_per_s)
+                "per_gpu_value": c4["evals_per_s"] / world,
+                "scale_base_field": "scale_base.value of the `bench.py --gpus 1` line (this workload, one GPU's shard)",
                 "single_gpu_base": "run `bench.py --gpus 1`: its `batched_c4_shard` sub-object is this workload on one GPU",
             }
             _emit(out)
@@ -470,28 +516,16 @@ def main():
         streamed = (n_rows * ROW_BYTES) if rows_ok else COMPACT_BYTES_PER_EVAL * n_obs
         layout = ("rows (16 B point + 64 B descriptor per row of 64 points, per-scan moments)" if rows_ok
                   else "compact (24 B point + 4 B group id per observation; group table per scan)")
-        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "kernel": ("clc::step_kernel<loss=1,nt=0,mode=2,layout=rows,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::step_kernel<loss=1,deep=0,mode=2,layout=compact>")
-                          + " (controller prologue + streaming loop)",
-                "algorithmic_bytes_per_launch": BYTES_PER_EVAL * n_obs,
-                "achieved": BYTES_PER_EVAL * n_obs / (step_ms * 1e-3) / 1e9, "avg_kernel_ms": step_ms,
-                "timing": f"hipEvent pair on the solver's stream around launches 2..{passes - 1} (steady state, back to back) of one "
-                          "clc_solve, / number of launches (best of 5)",
-                "timed_region_wall_ms_per_pass": wall_ms_per_pass,
-                "layout": layout, "streamed_bytes_per_launch": int(streamed),
-                "streaming_alone": {"kernel": "clc::eval_rows_kernel<loss=1,nt=0,512,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
-                                    "avg_kernel_ms": b2b, "achieved": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9,
-                                    "frac": BYTES_PER_EVAL * n_obs / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "achieved_streamed": streamed / (b2b * 1e-3) / 1e9,
-                                    "frac_streamed": streamed / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "frac_moved": streamed / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "timing": "hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)"}}
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        roof["achieved_streamed"] = streamed / (step_ms * 1e-3) / 1e9
-        roof["frac_streamed"] = roof["achieved_streamed"] / HBM_PEAK_GBS
-        # the bounded figure first: bytes MOVED / time / peak.  `frac` above is the contract's pricing (64 algorithmic bytes per
-        # evaluation) of a launch that moves 3.7x fewer bytes and is served by the Infinity Cache at this size
-        roof["frac_moved"] = roof["frac_streamed"]
+        roof = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs, step_ms * 1e-3), traffic=None,
+                    kernel=("clc::step_kernel<loss=1,nt=0,mode=2,layout=rows,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::step_kernel<loss=1,deep=0,mode=2,layout=compact>")
+                           + " (controller prologue + streaming loop)",
+                    avg_kernel_ms=step_ms,
+                    timing=f"hipEvent pair on the solver's stream around launches 2..{passes - 1} (steady state, back to back) of one "
+                           "clc_solve, / number of launches (best of 5)",
+                    timed_region_wall_ms_per_pass=wall_ms_per_pass, layout=layout, streamed_bytes_per_launch=int(streamed))
+        roof["streaming_alone"] = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs, b2b * 1e-3),
+                                       kernel="clc::eval_rows_kernel<loss=1,nt=0,512,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
+                                       avg_kernel_ms=b2b, timing="hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)")
         roof["pricings"] = pricings(n_obs, args.poses, streamed, step_ms * 1e-3)
         roof["frac_algorithmic_min"] = roof["pricings"]["reference_container_min"]["frac_of_hbm_peak"]
         roof["served_from"] = "infinity_cache" if streamed <= INFINITY_CACHE_BYTES else "hbm"
@@ -502,16 +536,12 @@ def main():
         solver.set_launch(0, 6)
         b2b64 = min(solver.time_eval(x0, reps=200) for _ in range(3))
         solver.set_launch(0, -1)
-        roof["compact28"] = {"avg_kernel_ms": b2bc, "achieved": BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9,
-                             "frac": BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "frac_streamed": COMPACT_BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "frac_moved": COMPACT_BYTES_PER_EVAL * n_obs / (b2bc * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        roof["tiled64"] = {"avg_kernel_ms": b2b64, "achieved": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9,
-                           "frac": BYTES_PER_EVAL * n_obs / (b2b64 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "note": "64-byte records streamed as stored: achieved == actual HBM rate"}
+        roof["compact28"] = dict(hbm_figures(COMPACT_BYTES_PER_EVAL * n_obs, BYTES_PER_EVAL * n_obs, b2bc * 1e-3), avg_kernel_ms=b2bc)
+        roof["tiled64"] = dict(hbm_figures(BYTES_PER_EVAL * n_obs, BYTES_PER_EVAL * n_obs, b2b64 * 1e-3), avg_kernel_ms=b2b64,
+                               note="64-byte records streamed as stored: bytes moved == the contract's algorithmic bytes")
         roof["note"] = (f"{streamed / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state passes are served on-die, and "
                         "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 1.7, the LM controller 2.2, reductions 1.4: scripts/r02_stamps.py); "
-                        "`frac_moved` (= `frac_streamed`) is bytes moved / time / 8 TB/s and is bounded by 1; `frac` prices the launch at the contract's 64 algorithmic bytes per "
+                        "`frac` (= `frac_moved`) is bytes moved / time / 8 TB/s and is bounded by 1; `contract_64B_frac` prices the launch at the contract's 64 algorithmic bytes per "
                         "evaluation; see roofline_large for a working set beyond the cache")
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -526,19 +556,12 @@ def main():
         # its own object.
         coop = coop_kernel_report(clc, solver, x0, n_obs, args.poses)
         if coop is not None:
-            cfile = os.path.join(ROOT, "profiles", "r03_coop_traffic.json")
+            cfile = os.path.join(ROOT, "profiles", "r04_coop_traffic.json")
             if os.path.exists(cfile):
                 try:
                     cj = json.load(open(cfile))
                     coop["traffic"] = cj.get("hbm_bytes_per_launch")
                     coop["traffic_source"] = cj.get("source")
-                    if cj.get("valu_wave_instructions_per_launch"):
-                        lane_instr = 64.0 * cj["valu_wave_instructions_per_launch"]
-                        coop["valu_issue"] = {"lane_instructions_per_launch": lane_instr, "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR,
-                                              "frac": lane_instr / (coop["avg_kernel_ms"] * 1e-3) / VALU_PEAK_LANE_INSTR,
-                                              "note": "PMC SQ_INSTS_VALU of the builder's profile (profiles/r03_coop.md) x 64 lanes over this run's kernel time, against "
-                                                      "256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: a fifth of the issue peak — the launch waits (exchange, controller on "
-                                                      "one wave) more than it computes"}
                 except Exception:
                     pass
             coop["timed_region_wall_ms_per_solve"] = 1e3 * elapsed_max / args.steps
@@ -563,24 +586,18 @@ def main():
         solver.set_launch(0, 6)
         ms64 = min(solver.time_eval(x0, reps=10) for _ in range(3))
         solver.set_launch(0, -1)
-        gbs = BYTES_PER_EVAL * nb / (ms * 1e-3) / 1e9
-        out["roofline_large"] = {
-            "observations": nb, "algorithmic_bytes": int(BYTES_PER_EVAL * nb), "streamed_bytes": int(streamed_l),
-            "beyond_infinity_cache": bool(streamed_l > 256 * 2**20),
-            "kernel": "clc::eval_rows_kernel<loss=1,nt=1,512,weighted=1>" if rows_ok_l else "clc::eval_kernel (compact, deep)",
-            "avg_kernel_ms": ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "achieved_streamed": streamed_l / (ms * 1e-3) / 1e9, "frac_streamed": streamed_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "evals_per_s": nb / (ms * 1e-3),
-            "frac_moved": streamed_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "pricings": pricings(nb, (nb + args.pts - 1) // args.pts, streamed_l, ms * 1e-3),
-            "served_from": "infinity_cache" if streamed_l <= INFINITY_CACHE_BYTES else "hbm", "traffic_measured_in_run": False,
-            "note": "frac_moved (= frac_streamed) = bytes the layout moves / time / 8 TB/s is the HBM fraction; frac prices the same launch at the "
-                    "contract's 64 algorithmic bytes per evaluation and exceeds 1 because the layout is a 3.8x lossless compression",
-            "compact28": {"avg_kernel_ms": msc, "streamed_bytes": COMPACT_BYTES_PER_EVAL * nb,
-                          "frac_streamed": COMPACT_BYTES_PER_EVAL * nb / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "frac": BYTES_PER_EVAL * nb / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "tiled64": {"avg_kernel_ms": ms64, "achieved": BYTES_PER_EVAL * nb / (ms64 * 1e-3) / 1e9,
-                        "frac": BYTES_PER_EVAL * nb / (ms64 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        out["roofline_large"] = dict(
+            hbm_figures(streamed_l, BYTES_PER_EVAL * nb, ms * 1e-3),
+            observations=nb, algorithmic_bytes=int(BYTES_PER_EVAL * nb), streamed_bytes=int(streamed_l),
+            beyond_infinity_cache=bool(streamed_l > 256 * 2**20),
+            kernel="clc::eval_rows_kernel<loss=1,nt=1,512,weighted=1>" if rows_ok_l else "clc::eval_kernel (compact, deep)",
+            avg_kernel_ms=ms, evals_per_s=nb / (ms * 1e-3),
+            pricings=pricings(nb, (nb + args.pts - 1) // args.pts, streamed_l, ms * 1e-3),
+            served_from="infinity_cache" if streamed_l <= INFINITY_CACHE_BYTES else "hbm", traffic_measured_in_run=False,
+            note="`frac` (= `frac_moved`) = bytes the layout moves / time / 8 TB/s is the HBM fraction; `contract_64B_frac` prices the same launch at the "
+                 "contract's 64 algorithmic bytes per evaluation and exceeds 1 because the layout is a 3.8x lossless compression",
+            compact28=dict(hbm_figures(COMPACT_BYTES_PER_EVAL * nb, BYTES_PER_EVAL * nb, msc * 1e-3), avg_kernel_ms=msc),
+            tiled64=dict(hbm_figures(BYTES_PER_EVAL * nb, BYTES_PER_EVAL * nb, ms64 * 1e-3), avg_kernel_ms=ms64))
         solver.upload(rec)
 
     # ---- BASELINE.json configs[2] (C3): 1 024 independent T_cl problems x 10^4 observations ----
@@ -612,12 +629,9 @@ def main():
         kb = min(solver.time_batched_eval(xb, reps=20) for _ in range(3))
         _, _, brows_ok, bn_rows = solver.debug_rows()
         sb = bn_rows * ROW_BYTES if brows_ok else COMPACT_BYTES_PER_EVAL * int(offb[-1])
-        out["batched_c3"]["eval_kernel"] = {"avg_kernel_ms": kb, "streamed_bytes": int(sb),
-                                            "frac": BYTES_PER_EVAL * int(offb[-1]) / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "frac_streamed": sb / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "frac_moved": sb / (kb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            "served_from": "infinity_cache" if sb <= INFINITY_CACHE_BYTES else "hbm",
-                                            "note": "the streaming evaluation launch of the lockstep path (one pass over all problems), not what the default solve runs"}
+        out["batched_c3"]["eval_kernel"] = dict(hbm_figures(sb, BYTES_PER_EVAL * int(offb[-1]), kb * 1e-3), avg_kernel_ms=kb,
+                                                served_from="infinity_cache" if sb <= INFINITY_CACHE_BYTES else "hbm",
+                                                note="the streaming evaluation launch of the lockstep path (one pass over all problems), not what the default solve runs")
         if not args.no_cpu_baseline:
             import oracle as _o
             w = 0.0
@@ -741,6 +755,11 @@ def main():
         dog.start()
         out["batched_c4_shard"] = run_c4_shard(args, torch, None, 0, 1, local_rank, args.shard_steps, 2)
         dog.cancel()
+        # what the --gpus N>1 lines scale from: their `value` / N (`per_gpu_value`) against this figure, not against `value` above
+        out["scale_base"] = {"workload": "C4 shard", "value": out["batched_c4_shard"]["evals_per_s"], "unit": "evals/s",
+                             "ms_per_step": out["batched_c4_shard"]["ms_per_step"],
+                             "note": "one GPU's share of the --gpus N>1 workload (8 192 problems x 1e4 observations, clc_solve_batched + result gather); "
+                                     "the N>1 lines report `per_gpu_value` = value / N to set against it"}
 
     if rank == 0:
         _emit(out)

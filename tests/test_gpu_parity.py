@@ -818,7 +818,10 @@ def test_bench_two_rank_path_dry_run():
     assert first[11] == 0.0 and last[11] == 191.0 and first[:7] != last[:7]
     assert all(abs(sum(x * x for x in r[3:7]) - 1) < 1e-12 for r in (first, last))
     assert c4["max_abs_T_err_vs_ground_truth_sampled"] < 0.05 and c4["T_cl_max_abs_err_vs_oracle_sample"] <= T_TOL
-    assert d["roofline"]["frac"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "valu_f64" and 0 < rf["frac"] <= 1 and 0 < rf["frac_moved"] <= 1  # no HBM fraction above 1 anywhere
+    assert rf["streaming_eval_kernel"]["bound"] == "hbm" and 0 < rf["streaming_eval_kernel"]["frac"] <= 1
+    assert abs(d["per_gpu_value"] * 2 - d["value"]) <= 1e-9 * d["value"] and "scale_base" in d["scale_base_field"]
 
 
 def test_bench_eight_rank_path_uneven_shards_dry_run():
