@@ -124,6 +124,17 @@ def parse():
 C4_SEED = 65536
 
 
+def hooks_solver(clc, device):
+    """A second handle on the -DCLC_TEST_HOOKS build of the library (same translation units + clc_time_* / clc_debug_*), for the
+    kernel-only measurements next to the timed region — the timed region itself runs on the product library, which does not
+    export them.  None when that build is absent."""
+    try:
+        return clc.Solver(device, library="hooks")
+    except Exception as e:  # the side measurements are optional
+        print(f"bench.py: no hooks build ({e}); kernel-only sub-objects skipped", file=sys.stderr)
+        return None
+
+
 def resident_kernel_report(clc, solver, x_start, n_problems, n_obs_total, n_scans_total):
     """Roofline object of the batched solve when it runs as ONE launch of resident_solve_kernel (csrc/clc_resident.hpp): every
     problem is read from HBM once and solved on chip, so the launch is bound by VALU issue (FP64), not by HBM.  The kernel
@@ -256,6 +267,9 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
     t_up = time.perf_counter() - t_up0
     n_obs_local = int(off[-1])
     keep = {k: rec[off[k]:off[k + 1]].copy() for k in (0, len(off) - 2)} if rank == 0 else {}
+    hs = hooks_solver(clc, local_rank) if rank == 0 else None  # (rank 0, outside the timed region: the streaming kernel's own timing)
+    if hs is not None:
+        hs.upload_batched(rec, off)
     del rec
     dev_name, n_cus = ss.solver.device_info()
 
@@ -320,14 +334,16 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         res["resident"] = dict(zip(("built", "lanes_per_problem", "max_points_per_lane", "rows"), ss.solver.debug_resident()))
         rk = resident_kernel_report(clc, ss.solver, x0, ss.hi - ss.lo, n_obs_local, (ss.hi - ss.lo) * args.shard_poses)
         # batched_eval_kernel over the whole shard (all problems active)
-        kms = min(ss.solver.time_batched_eval(x0, reps=10) for _ in range(3))
         _, _, brows_ok, bn_rows = ss.solver.debug_rows()
         streamed = bn_rows * ROW_BYTES if brows_ok else COMPACT_BYTES_PER_EVAL * n_obs_local
+        kms = min(hs.time_batched_eval(x0, reps=10) for _ in range(3)) if hs is not None else float("nan")
         res["roofline"] = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs_local, kms * 1e-3), traffic=None,
                                kernel=("clc::batched_rows_eval_kernel<loss=1,nt=1>" if brows_ok else "clc::batched_eval_kernel<compact,deep>")
                                       + " (all problems of the shard active)",
                                avg_kernel_ms=kms, served_from="infinity_cache" if streamed <= INFINITY_CACHE_BYTES else "hbm",
                                traffic_measured_in_run=False, timing="hipEvent pair around 10 back-to-back launches on the solver's stream (best of 3)")
+        if hs is None:
+            res["roofline"] = None
         if rk is not None:
             rk["streaming_eval_kernel"] = res["roofline"]
             res["roofline"] = rk
@@ -339,6 +355,8 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
                 w = max(w, float(np.abs(sd.T_from_pose7(mine[k, :7]) - sd.T_from_pose7(rk.pose)).max()))
             res["T_cl_max_abs_err_vs_oracle_sample"] = w
             res["oracle_sample"] = f"{len(keep)} of {ss.hi - ss.lo} problems of rank 0 (tests/test_gpu_parity.py::test_c4_full_size_shard checks 512 of 8192)"
+    if hs is not None:
+        hs.close()
     ss.close()
     return res
 
@@ -464,6 +482,7 @@ def main():
         block_ms.append(1e3 * (time.perf_counter() - tb0) / args.steps)
 
     out = None
+    hs = None
     if rank == 0:
         value = evals_total / elapsed_max
         out = {
@@ -504,53 +523,58 @@ def main():
         # per-dispatch figure it must agree with.  The wall time of the timed region per pass is reported next to it.
         passes = res.summary.num_evaluations
         wall_ms_per_pass = (1e3 * elapsed_max / args.steps) / passes
-        # HIP events on the solver's stream right before launch 2 and right after launch passes-1 of a solve: the
-        # steady-state launches, every one of which consumed a pass and streamed the array
-        step_ms = min(solver.time_steps(x0, 2, passes - 1)[0] for _ in range(5)) if passes >= 4 else wall_ms_per_pass
-        # the streaming part alone: HIP events on the solver's stream around 200 back-to-back launches of the
-        # evaluation kernel (same loop, same layout, no controller prologue) on the same resident array and pose
-        b2b = min(solver.time_eval(x0, reps=200) for _ in range(3))
-        rows_ok, n_rows, _, _ = solver.debug_rows()
-        # The default layout is a lossless re-encoding of the 64-byte records: per scan one plane, per point (x, y)
-        # [z == 0] in rows of 64 points + a 64-byte descriptor per row.  The bytes actually streamed per launch:
-        streamed = (n_rows * ROW_BYTES) if rows_ok else COMPACT_BYTES_PER_EVAL * n_obs
-        layout = ("rows (16 B point + 64 B descriptor per row of 64 points, per-scan moments)" if rows_ok
-                  else "compact (24 B point + 4 B group id per observation; group table per scan)")
-        roof = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs, step_ms * 1e-3), traffic=None,
-                    kernel=("clc::step_kernel<loss=1,nt=0,mode=2,layout=rows,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::step_kernel<loss=1,deep=0,mode=2,layout=compact>")
-                           + " (controller prologue + streaming loop)",
-                    avg_kernel_ms=step_ms,
-                    timing=f"hipEvent pair on the solver's stream around launches 2..{passes - 1} (steady state, back to back) of one "
-                           "clc_solve, / number of launches (best of 5)",
-                    timed_region_wall_ms_per_pass=wall_ms_per_pass, layout=layout, streamed_bytes_per_launch=int(streamed))
-        roof["streaming_alone"] = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs, b2b * 1e-3),
-                                       kernel="clc::eval_rows_kernel<loss=1,nt=0,512,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
-                                       avg_kernel_ms=b2b, timing="hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)")
-        roof["pricings"] = pricings(n_obs, args.poses, streamed, step_ms * 1e-3)
-        roof["frac_algorithmic_min"] = roof["pricings"]["reference_container_min"]["frac_of_hbm_peak"]
-        roof["served_from"] = "infinity_cache" if streamed <= INFINITY_CACHE_BYTES else "hbm"
-        roof["traffic_measured_in_run"] = False  # `traffic` below is the rocprofv3 PMC figure of profiles/pmc_traffic.json (builder's box)
-        # the same evaluation on the other layouts (A/B through clc_set_launch): compact 28 B/obs, 64-byte tiles
-        solver.set_launch(0, 2 | 16 | 32)
-        b2bc = min(solver.time_eval(x0, reps=200) for _ in range(3))
-        solver.set_launch(0, 6)
-        b2b64 = min(solver.time_eval(x0, reps=200) for _ in range(3))
-        solver.set_launch(0, -1)
-        roof["compact28"] = dict(hbm_figures(COMPACT_BYTES_PER_EVAL * n_obs, BYTES_PER_EVAL * n_obs, b2bc * 1e-3), avg_kernel_ms=b2bc)
-        roof["tiled64"] = dict(hbm_figures(BYTES_PER_EVAL * n_obs, BYTES_PER_EVAL * n_obs, b2b64 * 1e-3), avg_kernel_ms=b2b64,
-                               note="64-byte records streamed as stored: bytes moved == the contract's algorithmic bytes")
-        roof["note"] = (f"{streamed / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state passes are served on-die, and "
-                        "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 1.7, the LM controller 2.2, reductions 1.4: scripts/r02_stamps.py); "
-                        "`frac` (= `frac_moved`) is bytes moved / time / 8 TB/s and is bounded by 1; `contract_64B_frac` prices the launch at the contract's 64 algorithmic bytes per "
-                        "evaluation; see roofline_large for a working set beyond the cache")
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = tj.get("source")
-            except Exception:
-                pass
+        # kernel-only measurements: on a second handle of the hooks build (same code + clc_time_*), same resident array and pose
+        hs = hooks_solver(clc, local_rank)
+        roof = None
+        if hs is not None:
+            hs.upload(rec)
+            # HIP events on the solver's stream right before launch 2 and right after launch passes-1 of a solve: the
+            # steady-state launches, every one of which consumed a pass and streamed the array
+            step_ms = min(hs.time_steps(x0, 2, passes - 1)[0] for _ in range(5)) if passes >= 4 else wall_ms_per_pass
+            # the streaming part alone: HIP events on the solver's stream around 200 back-to-back launches of the
+            # evaluation kernel (same loop, same layout, no controller prologue) on the same resident array and pose
+            b2b = min(hs.time_eval(x0, reps=200) for _ in range(3))
+            rows_ok, n_rows, _, _ = solver.debug_rows()
+            # The default layout is a lossless re-encoding of the 64-byte records: per scan one plane, per point (x, y)
+            # [z == 0] in rows of 64 points + a 64-byte descriptor per row.  The bytes actually streamed per launch:
+            streamed = (n_rows * ROW_BYTES) if rows_ok else COMPACT_BYTES_PER_EVAL * n_obs
+            layout = ("rows (16 B point + 64 B descriptor per row of 64 points, per-scan moments)" if rows_ok
+                      else "compact (24 B point + 4 B group id per observation; group table per scan)")
+            roof = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs, step_ms * 1e-3), traffic=None,
+                        kernel=("clc::step_kernel<loss=1,nt=0,mode=2,layout=rows,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::step_kernel<loss=1,deep=0,mode=2,layout=compact>")
+                               + " (controller prologue + streaming loop)",
+                        avg_kernel_ms=step_ms,
+                        timing=f"hipEvent pair on the solver's stream around launches 2..{passes - 1} (steady state, back to back) of one "
+                               "clc_solve, / number of launches (best of 5)",
+                        timed_region_wall_ms_per_pass=wall_ms_per_pass, layout=layout, streamed_bytes_per_launch=int(streamed))
+            roof["streaming_alone"] = dict(hbm_figures(streamed, BYTES_PER_EVAL * n_obs, b2b * 1e-3),
+                                           kernel="clc::eval_rows_kernel<loss=1,nt=0,512,weighted=0 (equal shares at scan starts)>" if rows_ok else "clc::eval_kernel<loss=1,jac=1,deep=0,nt=0,compact=1,512>",
+                                           avg_kernel_ms=b2b, timing="hipEvent pair around 200 back-to-back launches on the solver's stream (best of 3)")
+            roof["pricings"] = pricings(n_obs, args.poses, streamed, step_ms * 1e-3)
+            roof["frac_algorithmic_min"] = roof["pricings"]["reference_container_min"]["frac_of_hbm_peak"]
+            roof["served_from"] = "infinity_cache" if streamed <= INFINITY_CACHE_BYTES else "hbm"
+            roof["traffic_measured_in_run"] = False  # `traffic` below is the rocprofv3 PMC figure of profiles/pmc_traffic.json (builder's box)
+            # the same evaluation on the other layouts (A/B through clc_set_launch): compact 28 B/obs, 64-byte tiles
+            hs.set_launch(0, 2 | 16 | 32)
+            b2bc = min(hs.time_eval(x0, reps=200) for _ in range(3))
+            hs.set_launch(0, 6)
+            b2b64 = min(hs.time_eval(x0, reps=200) for _ in range(3))
+            hs.set_launch(0, -1)
+            roof["compact28"] = dict(hbm_figures(COMPACT_BYTES_PER_EVAL * n_obs, BYTES_PER_EVAL * n_obs, b2bc * 1e-3), avg_kernel_ms=b2bc)
+            roof["tiled64"] = dict(hbm_figures(BYTES_PER_EVAL * n_obs, BYTES_PER_EVAL * n_obs, b2b64 * 1e-3), avg_kernel_ms=b2b64,
+                                   note="64-byte records streamed as stored: bytes moved == the contract's algorithmic bytes")
+            roof["note"] = (f"{streamed / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state passes are served on-die, and "
+                            "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 1.7, the LM controller 2.2, reductions 1.4: scripts/r02_stamps.py); "
+                            "`frac` (= `frac_moved`) is bytes moved / time / 8 TB/s and is bounded by 1; `contract_64B_frac` prices the launch at the contract's 64 algorithmic bytes per "
+                            "evaluation; see roofline_large for a working set beyond the cache")
+            tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = tj.get("source")
+                except Exception:
+                    pass
         # The default clc_solve at this size is ONE launch of the cooperative kernel (csrc/clc_coop.hpp): that is the dominant kernel of
         # the timed region; the step chain (what runs beyond 2.6e6 observations, with p.z != 0, or with explicit launch flags) keeps
         # its own object.
@@ -566,26 +590,27 @@ def main():
                     pass
             coop["timed_region_wall_ms_per_solve"] = 1e3 * elapsed_max / args.steps
             out["roofline"] = coop
-            roof["note"] = "clc_solve as the step chain (clc_set_launch with explicit flags; the default beyond what the chip holds). " + roof["note"]
-            out["roofline_step_chain"] = roof
+            if roof is not None:
+                roof["note"] = "clc_solve as the step chain (clc_set_launch with explicit flags; the default beyond what the chip holds). " + roof["note"]
+                out["roofline_step_chain"] = roof
         else:
             out["roofline"] = roof
 
     # ---- working set beyond the 256 MiB Infinity Cache IN THE LAYOUT STREAMED: evaluation kernel only (rank 0, N=1) ----
-    if rank == 0 and world == 1 and args.large_obs > 0:
+    if rank == 0 and world == 1 and args.large_obs > 0 and hs is not None:
         reps = (args.large_obs + n_obs - 1) // n_obs
         big = np.ascontiguousarray(np.tile(rec, (reps, 1))[: args.large_obs])
         nb = int(big.shape[0])
-        solver.upload(big)
+        hs.upload(big)
         del big
-        rows_ok_l, n_rows_l, _, _ = solver.debug_rows()
+        rows_ok_l, n_rows_l, _, _ = hs.debug_rows()
         streamed_l = (n_rows_l * ROW_BYTES) if rows_ok_l else COMPACT_BYTES_PER_EVAL * nb
-        ms = min(solver.time_eval(x0, reps=20) for _ in range(3))
-        solver.set_launch(0, 2 | 16 | 32)
-        msc = min(solver.time_eval(x0, reps=10) for _ in range(3))
-        solver.set_launch(0, 6)
-        ms64 = min(solver.time_eval(x0, reps=10) for _ in range(3))
-        solver.set_launch(0, -1)
+        ms = min(hs.time_eval(x0, reps=20) for _ in range(3))
+        hs.set_launch(0, 2 | 16 | 32)
+        msc = min(hs.time_eval(x0, reps=10) for _ in range(3))
+        hs.set_launch(0, 6)
+        ms64 = min(hs.time_eval(x0, reps=10) for _ in range(3))
+        hs.set_launch(0, -1)
         out["roofline_large"] = dict(
             hbm_figures(streamed_l, BYTES_PER_EVAL * nb, ms * 1e-3),
             observations=nb, algorithmic_bytes=int(BYTES_PER_EVAL * nb), streamed_bytes=int(streamed_l),
@@ -598,7 +623,7 @@ def main():
                  "contract's 64 algorithmic bytes per evaluation and exceeds 1 because the layout is a 3.8x lossless compression",
             compact28=dict(hbm_figures(COMPACT_BYTES_PER_EVAL * nb, BYTES_PER_EVAL * nb, msc * 1e-3), avg_kernel_ms=msc),
             tiled64=dict(hbm_figures(BYTES_PER_EVAL * nb, BYTES_PER_EVAL * nb, ms64 * 1e-3), avg_kernel_ms=ms64))
-        solver.upload(rec)
+        hs.upload(rec[:64])  # (frees nothing: the handle keeps its capacity; the large array is simply no longer referenced)
 
     # ---- BASELINE.json configs[2] (C3): 1 024 independent T_cl problems x 10^4 observations ----
     if rank == 0 and world == 1 and not args.no_batched:
@@ -626,10 +651,12 @@ def main():
         rk3 = resident_kernel_report(clc, solver, xb, Pb, int(offb[-1]), Pb * 20)
         if rk3 is not None:
             out["batched_c3"]["solve_kernel"] = rk3
-        kb = min(solver.time_batched_eval(xb, reps=20) for _ in range(3))
         _, _, brows_ok, bn_rows = solver.debug_rows()
         sb = bn_rows * ROW_BYTES if brows_ok else COMPACT_BYTES_PER_EVAL * int(offb[-1])
-        out["batched_c3"]["eval_kernel"] = dict(hbm_figures(sb, BYTES_PER_EVAL * int(offb[-1]), kb * 1e-3), avg_kernel_ms=kb,
+        if hs is not None:
+            hs.upload_batched(np.concatenate(recs), offb)
+            kb = min(hs.time_batched_eval(xb, reps=20) for _ in range(3))
+            out["batched_c3"]["eval_kernel"] = dict(hbm_figures(sb, BYTES_PER_EVAL * int(offb[-1]), kb * 1e-3), avg_kernel_ms=kb,
                                                 served_from="infinity_cache" if sb <= INFINITY_CACHE_BYTES else "hbm",
                                                 note="the streaming evaluation launch of the lockstep path (one pass over all problems), not what the default solve runs")
         if not args.no_cpu_baseline:
@@ -763,6 +790,8 @@ def main():
 
     if rank == 0:
         _emit(out)
+    if hs is not None:
+        hs.close()
     solver.close()
 
 

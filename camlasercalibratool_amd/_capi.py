@@ -32,6 +32,14 @@ EXPORTED = [
     "clc_gather_results", "clc_comm_records",
     "clc_store_observations", "clc_select_observations", "clc_upload_batched_device", "clc_line_fit_batched_device",
     "clc_scan_to_points_device", "clc_pinned_alloc", "clc_pinned_free", "clc_store_generation", "clc_batched_host_buffers",
+    "clc_get_path_info", "clc_device_info", "clc_comm_library",
+]
+# test / profiling hooks: NOT in include/clc.h and not in the product library; exported by the -DCLC_TEST_HOOKS builds
+# (csrc/libclc_hip_hooks.so, csrc/libclc_hip_legacy.so) only (tests/test_abi_symbols.py checks both directions)
+HOOKS = [
+    "clc_debug_flatten_device", "clc_debug_wave_reduce", "clc_debug_eval_timeline", "clc_debug_build_features", "clc_debug_rows",
+    "clc_debug_wave_split", "clc_debug_resident", "clc_debug_resident_single", "clc_debug_coop", "clc_debug_coop_control",
+    "clc_debug_coop_set_tag", "clc_debug_layout", "clc_debug_lm_profile", "clc_time_steps", "clc_time_batched_eval", "clc_time_eval",
 ]
 
 
@@ -86,6 +94,14 @@ class Summary(C.Structure):
     ]
 
 
+class PathInfo(C.Structure):
+    """clc_path_info (include/clc.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("single_resident", "single_lanes", "single_points_per_lane", "coop_resident", "coop_points_per_lane",
+                                         "coop_resting", "coop_timeouts", "batched_resident", "batched_lanes", "batched_points_per_lane",
+                                         "rows_layout", "batched_rows_layout")] + \
+               [(n, C.c_int64) for n in ("coop_solves", "batched_lane_rows", "n_rows", "batched_n_rows")]
+
+
 class ClcError(RuntimeError):
     def __init__(self, code: int, where: str, detail: str):
         super().__init__(f"{where}: {ERRORS.get(code, code)} — {detail}")
@@ -122,11 +138,14 @@ def _preload_process_hip_runtime() -> None:
         pass  # fall back to whatever the dynamic loader resolves
 
 
-def lib():
-    """Load csrc/libclc_hip.so (raises if the HIP extension has not been built)."""
-    global _lib
-    if _lib is None:
-        path = _build.LIB_PATH
+_libs = {}
+
+
+def load(path: str):
+    """Load one build of the library (cached per path) and declare the non-int signatures."""
+    path = os.path.abspath(path)
+    L = _libs.get(path)
+    if L is None:
         if not os.path.exists(path):
             raise RuntimeError(
                 f"HIP extension {path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -149,13 +168,32 @@ def lib():
         L.clc_comm_library.restype = C.c_char_p
         L.clc_comm_records.argtypes = [C.c_void_p]
         L.clc_comm_records.restype = C.POINTER(C.c_double)
-        _lib = L
+        L.clc_get_path_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.has_hooks = hasattr(L, "clc_debug_build_features")
+        _libs[path] = L
+    return L
+
+
+def lib():
+    """The library the package runs on: csrc/libclc_hip.so (the product build) unless CLC_LIBRARY names another build."""
+    global _lib
+    if _lib is None:
+        _lib = load(_build.LIB_PATH)
     return _lib
+
+
+def hooks_lib():
+    """The -DCLC_TEST_HOOKS build (product + clc_debug_* / clc_time_*): the default library itself when it has the hooks."""
+    L = lib()
+    return L if L.has_hooks else load(_build.HOOKS_LIB_PATH)
 
 
 def check(rc: int, where: str) -> None:
     if rc != CLC_OK:
-        raise ClcError(rc, where, lib().clc_last_error().decode("utf-8", "replace"))
+        # clc_last_error is per library (and thread): with more than one build loaded, take the message of the call that failed
+        msgs = [L.clc_last_error().decode("utf-8", "replace") for L in _libs.values()]
+        detail = next((m for m in msgs if m.startswith(where)), next((m for m in msgs if m), ""))
+        raise ClcError(rc, where, detail)
 
 
 def dptr(a):

@@ -1,0 +1,196 @@
+// abi_comm.hip — multi-GPU: RCCL all-gather of the sharded batch's result records.
+// (one of the translation units of the C-ABI; see clc_abi_internal.hpp)
+#include "clc_abi_internal.hpp"
+
+using namespace clc_abi;
+
+#include <dlfcn.h>
+#include <link.h>
+
+#include <rccl/rccl.h>  // types and prototypes only: the functions are bound at run time (no link dependency)
+
+namespace {
+
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;        // optional: what RCCL itself says the communicator spans
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;  // optional
+  std::string origin;
+  std::string error;
+};
+
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
+  const char* name = info->dlpi_name;
+  if (name && std::strstr(name, "librccl")) {
+    *static_cast<std::string*>(data) = name;
+    return 1;
+  }
+  return 0;
+}
+
+// One RCCL per process: reuse the copy that is already mapped (PyTorch bundles its own), else load the system one.
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<std::string> candidates;
+    if (const char* env = std::getenv("CLC_RCCL_LIBRARY")) candidates.push_back(env);
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    if (!loaded.empty()) candidates.push_back(loaded);
+    candidates.push_back("librccl.so.1");
+    candidates.push_back("librccl.so");
+    candidates.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& c : candidates) {
+      api.lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (api.lib) { api.origin = c; break; }
+      const char* why = dlerror();
+      api.error += c + ": " + (why ? why : "?") + "; ";
+    }
+    if (!api.lib) return;
+#define CLC_BIND(field, sym)                                                   \
+  api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, sym));      \
+  if (!api.field) { api.error += std::string("missing symbol ") + sym + "; "; }
+    CLC_BIND(GetUniqueId, "ncclGetUniqueId")
+    CLC_BIND(CommInitRank, "ncclCommInitRank")
+    CLC_BIND(CommDestroy, "ncclCommDestroy")
+    CLC_BIND(AllGather, "ncclAllGather")
+    CLC_BIND(GetErrorString, "ncclGetErrorString")
+#undef CLC_BIND
+    api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
+      api.lib = nullptr;
+    }
+  });
+  return api;
+}
+
+int rccl_fail(const char* what, ncclResult_t r) {
+  char buf[512];
+  std::snprintf(buf, sizeof(buf), "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error");
+  g_last_error = buf;
+  return CLC_ERR_COMM;
+}
+
+}  // namespace
+
+struct clc_comm {
+  clc_handle* h = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  double* d_send = nullptr;
+  double* d_recv = nullptr;
+  double* h_recv = nullptr;  // pinned
+  size_t cap = 0;            // records per rank the buffers hold
+};
+
+extern "C" {
+
+int clc_comm_unique_id(char id[CLC_COMM_ID_BYTES]) {
+  if (!id) return fail(CLC_ERR_INVALID_ARG, "clc_comm_unique_id: NULL id");
+  static_assert(sizeof(ncclUniqueId) == CLC_COMM_ID_BYTES, "ncclUniqueId size");
+  RcclApi& api = rccl();
+  if (!api.lib) return fail(CLC_ERR_COMM, ("clc_comm_unique_id: RCCL not available: " + api.error).c_str());
+  ncclUniqueId u;
+  ncclResult_t r = api.GetUniqueId(&u);
+  if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+  std::memcpy(id, u.internal, CLC_COMM_ID_BYTES);
+  return CLC_OK;
+}
+
+int clc_comm_create(clc_comm** out, clc_handle* h, const char id[CLC_COMM_ID_BYTES], int rank, int world) {
+  if (!out || !h || !id || world < 1 || rank < 0 || rank >= world)
+    return fail(CLC_ERR_INVALID_ARG, "clc_comm_create: bad argument");
+  *out = nullptr;
+  RcclApi& api = rccl();
+  if (!api.lib) return fail(CLC_ERR_COMM, ("clc_comm_create: RCCL not available: " + api.error).c_str());
+  CLC_HIP(hipSetDevice(h->device));
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, CLC_COMM_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = api.CommInitRank(&comm, world, u, rank);
+  if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+  clc_comm* c = new clc_comm();
+  c->h = h;
+  c->comm = comm;
+  c->rank = rank;
+  c->world = world;
+  // what RCCL itself reports for the communicator (clc_comm_world / clc_comm_rank return these): a SCALE record can then
+  // show that RCCL saw N ranks, not just that N was passed in
+  int n = 0;
+  if (api.CommCount && api.CommCount(comm, &n) == ncclSuccess && n > 0) c->world = n;
+  if (api.CommUserRank && api.CommUserRank(comm, &n) == ncclSuccess) c->rank = n;
+  *out = c;
+  return CLC_OK;
+}
+
+void clc_comm_destroy(clc_comm* c) {
+  if (!c) return;
+  if (c->h) {
+    (void)hipSetDevice(c->h->device);
+    (void)hipStreamSynchronize(c->h->stream);
+  }
+  if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+  if (c->d_send) (void)hipFree(c->d_send);
+  if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->h_recv) (void)hipHostFree(c->h_recv);
+  delete c;
+}
+
+int clc_comm_rank(const clc_comm* c) { return c ? c->rank : -1; }
+int clc_comm_world(const clc_comm* c) { return c ? c->world : 0; }
+// which RCCL was bound ("" before the first comm call) — diagnostics / tests
+const char* clc_comm_library(void) { return rccl().origin.c_str(); }
+
+int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_rank, clc_result_record* all_records) {
+  if (!c || cap_per_rank == 0 || first_global_index < 0)
+    return fail(CLC_ERR_INVALID_ARG, "clc_gather_results: bad argument");
+  clc_handle* h = c->h;
+  size_t n_local = h->results_valid;
+  // This is a collective: a rank that returned before the all-gather would leave every other rank blocked in it.  A rank
+  // with a LOCAL problem therefore still enters the collective — with an all-padding send buffer — and reports its error
+  // afterwards.  (Arguments every rank passes alike — a NULL communicator, cap_per_rank == 0 — are rejected above on all
+  // ranks together; a failed device allocation below cannot be papered over: the communicator is then unusable.)
+  int local_rc = CLC_OK;
+  const char* local_msg = nullptr;
+  if (n_local > cap_per_rank) { local_rc = CLC_ERR_INVALID_ARG; local_msg = "clc_gather_results: cap_per_rank < local problems (this rank contributed padding only)"; n_local = 0; }
+  else if (n_local > 0 && !h->d_results) { local_rc = CLC_ERR_NO_DATA; local_msg = "clc_gather_results: no solved batch on the handle (this rank contributed padding only)"; n_local = 0; }
+  CLC_HIP(hipSetDevice(h->device));
+  if (cap_per_rank > c->cap) {
+    if (c->d_send) CLC_HIP(hipFree(c->d_send));
+    if (c->d_recv) CLC_HIP(hipFree(c->d_recv));
+    if (c->h_recv) CLC_HIP(hipHostFree(c->h_recv));
+    c->d_send = c->d_recv = c->h_recv = nullptr;
+    c->cap = 0;
+    CLC_HIP(hipMalloc(&c->d_send, sizeof(clc_result_record) * cap_per_rank));
+    CLC_HIP(hipMalloc(&c->d_recv, sizeof(clc_result_record) * cap_per_rank * (size_t)c->world));
+    CLC_HIP(hipHostMalloc(&c->h_recv, sizeof(clc_result_record) * cap_per_rank * (size_t)c->world, hipHostMallocDefault));
+    c->cap = cap_per_rank;
+  }
+  const int threads = 256;
+  hipLaunchKernelGGL(clc::pack_results_kernel, dim3((unsigned)((cap_per_rank + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, h->d_results, (long long)n_local, (long long)cap_per_rank, (double)first_global_index,
+                     c->d_send);
+  CLC_HIP(hipGetLastError());
+  const size_t count = cap_per_rank * (sizeof(clc_result_record) / sizeof(double));
+  ncclResult_t r = rccl().AllGather(c->d_send, c->d_recv, count, ncclDouble, c->comm, h->stream);
+  if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+  const size_t bytes = sizeof(clc_result_record) * cap_per_rank * (size_t)c->world;
+  CLC_HIP(hipMemcpyAsync(c->h_recv, c->d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  if (all_records) std::memcpy(all_records, c->h_recv, bytes);
+  if (local_rc != CLC_OK) return fail(local_rc, local_msg);
+  return CLC_OK;
+}
+
+const clc_result_record* clc_comm_records(const clc_comm* c) {
+  return c ? reinterpret_cast<const clc_result_record*>(c->h_recv) : nullptr;
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+// abi_layouts.hip — the upload paths: staged records -> 64-byte tiles, scan structure, compact / row / lane layouts; stored scans.
+// (one of the translation units of the C-ABI; see clc_abi_internal.hpp)
+#include "clc_abi_internal.hpp"
+
+using namespace clc_abi;
+
+namespace {
+
+int retile_into(clc_handle* h, const double* d_aos, size_t n, double** d_tiles, size_t* cap_bytes) {
+  const size_t n_padded = ((n + clc::TILE - 1) / clc::TILE) * clc::TILE;
+  const size_t bytes = std::max<size_t>(n_padded, clc::TILE) * 8 * sizeof(double);
+  if (bytes > *cap_bytes) {
+    if (*d_tiles) CLC_HIP(hipFree(*d_tiles));
+    *d_tiles = nullptr;
+    *cap_bytes = 0;
+    CLC_HIP(hipMalloc(d_tiles, bytes));
+    *cap_bytes = bytes;
+  }
+  if (n_padded > 0) {
+    const int threads = 256;
+    const long long blocks = ((long long)n_padded + threads - 1) / threads;
+    hipLaunchKernelGGL(clc::retile_kernel, dim3((unsigned)blocks), dim3(threads), 0, h->stream, d_aos,
+                       *d_tiles, (long long)n, (long long)n_padded);
+    CLC_HIP(hipGetLastError());
+  }
+  return CLC_OK;
+}
+
+// Upload-time re-encoding of staged AoS records, entirely on the device (O(1) host work, a few words copied back):
+//   * scans = runs of records with bit-identical (n, d, scale) (and never across two problems): flags, prefix sum ->
+//     scan index per record, scan starts;
+//   * compact layout (clc_kernels.hpp "Compact layout"): group table + 28-byte tiles, bitwise lossless;
+//   * row layout (clc_rows.hpp): every scan padded to whole rows of 64 points, (x, y) rows + one descriptor per row —
+//     only when every record has p.z == 0 and the padding at most doubles the array.
+// Nothing is kept when the records do not group at least 4:1 (hand-made arrays without scan structure).
+template <class TIn>
+int device_scan(clc_handle* h, const TIn* d_in, long long n, unsigned int minus_one, unsigned int* d_out,
+                unsigned long long* d_totals /* [blocks + 1] */) {
+  const long long blocks = (n + clc::SCAN_CHUNK - 1) / clc::SCAN_CHUNK;
+  hipLaunchKernelGGL((clc::scan_block_totals_kernel<TIn>), dim3((unsigned)blocks), dim3(clc::SCAN_THREADS), 0, h->stream,
+                     d_in, n, d_totals);
+  hipLaunchKernelGGL(clc::scan_totals_kernel, dim3(1), dim3(clc::SCAN_THREADS), 0, h->stream, d_totals, blocks);
+  hipLaunchKernelGGL((clc::scan_apply_kernel<TIn>), dim3((unsigned)blocks), dim3(clc::SCAN_THREADS), 0, h->stream, d_in, n,
+                     d_totals, minus_one, d_out);
+  CLC_HIP(hipGetLastError());
+  return CLC_OK;
+}
+
+
+// The lane layout of the batched problems (clc_resident.hpp) from the staged records and their scan structure: plan
+// (points per lane of every problem, on the device), offsets (O(P) on the host), lane descriptors + j-major point rows.
+// Leaves L.ok false — and the streaming layouts in charge — when some problem does not fit a workgroup.
+int build_resident(clc_handle* h, ResLayout& L, int first_try, const double* d_aos, long long n, size_t P, size_t G,
+                   const long long* d_rec_off, const unsigned int* d_gid, const long long* d_starts, int max_ppl_override = 0) {
+  L.ok = false;
+  L.lanes = 0;
+  L.max_ppl = 0;
+  L.rows = 0;
+  if ((h->launch_flags & clc::FLAG_NO_RESIDENT) != 0) return CLC_OK;
+  const int threads = 256;
+  DevBuf<unsigned int> bppl(&h->pool), bfail(&h->pool);
+  CLC_HIP(bppl.alloc(P));
+  CLC_HIP(bfail.alloc(1));
+  std::vector<unsigned int> ppl(P);
+  int lanes = 0;
+  for (int nl = first_try; nl <= (max_ppl_override > 0 ? first_try : 512) && lanes == 0; nl *= 2) {
+    unsigned int failed = 0;
+    CLC_HIP(hipMemsetAsync(bfail.p, 0, sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(clc::res_plan_kernel, dim3((unsigned)((P + threads - 1) / threads)), dim3(threads), 0, h->stream, d_rec_off,
+                       d_gid, d_starts, (long long)P, n, (long long)G, nl, max_ppl_override > 0 ? max_ppl_override : (nl == 256 ? kResPR256 + kResPL256 : kResPR512 + kResPL512), bppl.p, bfail.p);
+    CLC_HIP(hipGetLastError());
+    CLC_HIP(hipMemcpyAsync(&failed, bfail.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    CLC_HIP(hipMemcpyAsync(ppl.data(), bppl.p, sizeof(unsigned int) * P, hipMemcpyDeviceToHost, h->stream));
+    CLC_HIP(hipStreamSynchronize(h->stream));
+    if (!failed) lanes = nl;
+  }
+  if (lanes == 0) return CLC_OK;  // some problem is too long (or has too many scans) for one workgroup
+  std::vector<unsigned int> row(P + 1, 0u);
+  unsigned long long total = 0;
+  unsigned int max_ppl = 0;
+  bool uniform = true;
+  for (size_t k = 0; k < P; ++k) {
+    row[k] = (unsigned int)total;
+    total += ppl[k];
+    max_ppl = std::max(max_ppl, ppl[k]);
+    uniform = uniform && ppl[k] == ppl[0];
+  }
+  if (total >= 0xFFFFFFF0ull) return CLC_OK;
+  row[P] = (unsigned int)total;
+  int rc = ensure_bytes(&L.d_row, &L.row_cap, (P + 1) * sizeof(unsigned int));
+  if (rc != CLC_OK) return rc;
+  rc = ensure_bytes(&L.d_desc, &L.desc_cap, P * (size_t)lanes * sizeof(clc::ResLane));
+  if (rc != CLC_OK) return rc;
+  // one padding row: the kernel's loads run unconditionally from clamped row indices (an empty last problem reads it)
+  rc = ensure_bytes(&L.d_xy, &L.xy_cap, ((size_t)total + 1) * (size_t)lanes * 2 * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  CLC_HIP(hipMemcpyAsync(L.d_row, row.data(), (P + 1) * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemsetAsync(L.d_xy + (size_t)total * (size_t)lanes * 2, 0, (size_t)lanes * 2 * sizeof(double), h->stream));
+  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(L.d_row);
+  clc::ResLane* d_desc = reinterpret_cast<clc::ResLane*>(L.d_desc);
+  if (lanes == 256)
+    hipLaunchKernelGGL((clc::res_build_kernel<256>), dim3((unsigned)P), dim3(256), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
+                       (long long)G, d_row, d_desc, L.d_xy);
+  else
+    hipLaunchKernelGGL((clc::res_build_kernel<512>), dim3((unsigned)P), dim3(512), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
+                       (long long)G, d_row, d_desc, L.d_xy);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));  // `row` is a host temporary
+  L.lanes = lanes;
+  L.max_ppl = (int)max_ppl;
+  L.uni_ppl = uniform && P > 0 ? (int)ppl[0] : -1;
+  L.rows = (long long)total;
+  L.ok = true;
+  return CLC_OK;
+}
+
+}  // namespace
+
+namespace clc_abi {
+
+int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std::vector<long long>& rec_off,
+                  const std::vector<long long>& tile_off, const LayoutTargets& T) {
+  *T.compact_ok = false;
+  *T.rows_ok = false;
+  *T.n_groups = 0;
+  *T.n_rows = 0;
+  const size_t P = rec_off.size() - 1;
+  if (n_total == 0 || P == 0) return CLC_OK;
+  if (n_total >= 0xFFFFFFF0ull) return CLC_OK;  // scan indices are 32-bit; such arrays keep the 64-byte tiles
+  const long long n = (long long)n_total;
+  const int threads = 256;
+  const long long scan_blocks = (n + clc::SCAN_CHUNK - 1) / clc::SCAN_CHUNK;
+  DevBuf<unsigned char> bflag(&h->pool);
+  DevBuf<unsigned int> bgid(&h->pool), bzflag(&h->pool);
+  DevBuf<unsigned long long> btotals(&h->pool);
+  DevBuf<long long> broff(&h->pool), btoff(&h->pool);
+  CLC_HIP(bflag.alloc(n_total));
+  CLC_HIP(bgid.alloc(n_total));
+  CLC_HIP(bzflag.alloc(1));
+  CLC_HIP(btotals.alloc((size_t)scan_blocks + 1));
+  CLC_HIP(broff.alloc(P + 1));
+  CLC_HIP(btoff.alloc(P + 1));
+  CLC_HIP(hipMemcpyAsync(broff.p, rec_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemcpyAsync(btoff.p, tile_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipMemsetAsync(bzflag.p, 0, sizeof(unsigned int), h->stream));
+  hipLaunchKernelGGL(clc::scan_flag_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, h->stream, d_aos,
+                     n, bflag.p, bzflag.p);
+  hipLaunchKernelGGL(clc::mark_problem_starts_kernel, dim3((unsigned)((P + threads - 1) / threads)), dim3(threads), 0,
+                     h->stream, broff.p, (long long)P, n, bflag.p);
+  CLC_HIP(hipGetLastError());
+  int rc = device_scan<unsigned char>(h, bflag.p, n, 1u, bgid.p, btotals.p);
+  if (rc != CLC_OK) return rc;
+  unsigned int last_gid = 0, any_z = 0;
+  CLC_HIP(hipMemcpyAsync(&last_gid, bgid.p + (n - 1), sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipMemcpyAsync(&any_z, bzflag.p, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  const size_t G = (size_t)last_gid + 1;
+  // fewer than 4 points per scan on average: the streaming layouts do not pay (the step chain keeps the 64-byte tiles) — the on-chip
+  // layouts, where a lane carries its own plane anyway, are still built
+  const bool sparse = G * 4 > n_total;
+  if (sparse && T.res == nullptr && T.coop == nullptr) return CLC_OK;
+  DevBuf<long long> bstarts(&h->pool);
+  CLC_HIP(bstarts.alloc(G + 1));
+  hipLaunchKernelGGL(clc::scan_starts_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                     bflag.p, bgid.p, n, (long long)G, bstarts.p);
+  CLC_HIP(hipGetLastError());
+  // ---- compact layout ----
+  const size_t total_tiles = (size_t)tile_off[P];
+  rc = ensure_bytes(T.d_ct, T.ct_cap, std::max<size_t>(total_tiles, 1) * clc::CTILE_DOUBLES * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  rc = ensure_bytes(T.d_gr, T.gr_cap, G * clc::GROUP_DOUBLES * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  hipLaunchKernelGGL(clc::build_groups_dev_kernel, dim3((unsigned)((G + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                     d_aos, bstarts.p, (long long)G, *T.d_gr);
+  {
+    long long max_padded = 0;
+    for (size_t k = 0; k < P; ++k) max_padded = std::max(max_padded, (tile_off[k + 1] - tile_off[k]) * clc::TILE);
+    const unsigned ydim = (unsigned)std::min<long long>(4096, std::max<long long>(1, (max_padded + threads - 1) / threads));
+    hipLaunchKernelGGL(clc::build_ctiles_kernel, dim3((unsigned)P, ydim), dim3(threads), 0, h->stream, d_aos, bgid.p, broff.p,
+                       btoff.p, *T.d_ct);
+  }
+  CLC_HIP(hipGetLastError());
+  // ---- row layout ----
+  bool rows_ok = false;
+  long long R = 0;
+  DevBuf<unsigned int> brows(&h->pool), brbeg(&h->pool);
+  DevBuf<unsigned long long> btot2(&h->pool);
+  const size_t row_doubles = any_z ? clc::ROW_DOUBLES_Z : clc::ROW_DOUBLES;
+  if (T.rows_z) *T.rows_z = any_z != 0;
+  {
+    const long long gblocks = ((long long)G + clc::SCAN_CHUNK - 1) / clc::SCAN_CHUNK;
+    CLC_HIP(brows.alloc(G));
+    CLC_HIP(brbeg.alloc(G + 1));
+    CLC_HIP(btot2.alloc((size_t)gblocks + 1));
+    hipLaunchKernelGGL(clc::scan_rows_kernel, dim3((unsigned)((G + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                       bstarts.p, (long long)G, brows.p);
+    CLC_HIP(hipMemsetAsync(brbeg.p, 0, sizeof(unsigned int), h->stream));
+    rc = device_scan<unsigned int>(h, brows.p, (long long)G, 0u, brbeg.p + 1, btot2.p);
+    if (rc != CLC_OK) return rc;
+    unsigned int total_rows = 0;
+    CLC_HIP(hipMemcpyAsync(&total_rows, brbeg.p + G, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    CLC_HIP(hipStreamSynchronize(h->stream));
+    R = (long long)total_rows;
+    rows_ok = !sparse && R > 0 && (size_t)R * clc::ROW <= 3 * n_total + 64 * P;  // rows at least a third full on average
+  }
+  if (rows_ok) {
+    // one padding row each: the streaming loop's prologue loads run unconditionally from clamped row indices
+    rc = ensure_bytes(T.d_rxy, T.rxy_cap, ((size_t)R + 1) * row_doubles * sizeof(double));
+    if (rc != CLC_OK) return rc;
+    rc = ensure_bytes(T.d_rdesc, T.rdesc_cap, ((size_t)R + 1) * sizeof(clc::RowDesc) + clc::wave_split_bytes(R));  // + the wave split table
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(hipMemsetAsync(*T.d_rxy + (size_t)R * row_doubles, 0, row_doubles * sizeof(double), h->stream));
+    CLC_HIP(hipMemsetAsync(reinterpret_cast<char*>(*T.d_rdesc) + (size_t)R * sizeof(clc::RowDesc), 0, sizeof(clc::RowDesc), h->stream));
+    const long long slots = R * clc::ROW;
+    hipLaunchKernelGGL(clc::build_rows_kernel, dim3((unsigned)((slots + threads - 1) / threads)), dim3(threads), 0, h->stream,
+                       d_aos, bstarts.p, brbeg.p, (long long)G, R, (int)row_doubles, *T.d_rxy, reinterpret_cast<clc::RowDesc*>(*T.d_rdesc));
+    if (T.d_prob_row)
+      hipLaunchKernelGGL(clc::problem_rows_kernel, dim3((unsigned)((P + 1 + threads - 1) / threads)), dim3(threads), 0,
+                         h->stream, broff.p, bgid.p, brbeg.p, (long long)P, n, R, *T.d_prob_row);
+    CLC_HIP(hipGetLastError());
+  }
+  if (T.res != nullptr) {
+    T.res->ok = false;
+    if (!any_z) {
+      // batches: 256 lanes (two problems per CU) unless flag 8192; a single problem: 512 lanes (it has its CU to itself)
+      const int first_try = (T.d_prob_row == nullptr || (h->launch_flags & clc::FLAG_RESIDENT_WG512) != 0) ? 512 : 256;
+      rc = build_resident(h, *T.res, first_try, d_aos, n, P, G, broff.p, bgid.p, bstarts.p);
+      if (rc != CLC_OK) return rc;
+    }
+  }
+  if (T.coop != nullptr) {
+    T.coop->ok = false;
+    if (!any_z && P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && !(T.res != nullptr && T.res->ok)) {
+      // the one problem in COOP_WGS chunks of equal record counts (a chunk may begin and end inside a scan: res_scan_extent)
+      std::vector<long long> chunk(clc::COOP_WGS + 1);
+      for (int c = 0; c <= clc::COOP_WGS; ++c) chunk[c] = (long long)((__int128)n * c / clc::COOP_WGS);
+      DevBuf<long long> bchunk(&h->pool);
+      CLC_HIP(bchunk.alloc(chunk.size()));
+      CLC_HIP(hipMemcpyAsync(bchunk.p, chunk.data(), chunk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+      CLC_HIP(hipStreamSynchronize(h->stream));
+      rc = build_resident(h, *T.coop, clc::COOP_NL, d_aos, n, (size_t)clc::COOP_WGS, G, bchunk.p, bgid.p, bstarts.p, clc::COOP_PR + clc::COOP_PL);
+      if (rc != CLC_OK) return rc;
+    }
+  }
+  CLC_HIP(hipStreamSynchronize(h->stream));  // the temporaries above are freed on return
+  *T.n_groups = (long long)G;
+  *T.compact_ok = !sparse;
+  *T.n_rows = R;
+  *T.rows_ok = rows_ok;
+  return CLC_OK;
+}
+
+}  // namespace clc_abi
+
+extern "C" {
+
+int clc_flatten_observations(int n_poses, const double* tag_q_wxyz, const double* tag_t,
+                             const int64_t* pts_off, const double* pts, const int64_t* ptl_off,
+                             const double* ptl, int use_linefitting_data,
+                             int use_boundary_constraint, clc_observation* records,
+                             int64_t* n_records) {
+  if (n_poses < 0 || !n_records || (n_poses > 0 && (!tag_q_wxyz || !tag_t || !pts_off || !ptl_off)))
+    return fail(CLC_ERR_INVALID_ARG, "clc_flatten_observations: bad argument");
+  int rc = clc::host::flatten(n_poses, tag_q_wxyz, tag_t, pts_off, pts, ptl_off, ptl,
+                              use_linefitting_data != 0, use_boundary_constraint != 0, records, n_records);
+  if (rc == CLC_ERR_EMPTY_SCAN)
+    return fail(rc, "clc_flatten_observations: boundary constraint on an empty scan (reference: std::out_of_range at LaseCamCalCeres.cpp:278)");
+  return rc;
+}
+
+int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t n) {
+  if (!h || (n > 0 && !records_dev)) return fail(CLC_ERR_INVALID_ARG, "clc_upload_device: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  h->compact_ok = false;
+  h->rows_ok = false;
+  h->sres.ok = false;
+  h->cres.ok = false;
+  h->split_grid = -1;
+  int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
+  if (rc != CLC_OK) return rc;
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  h->n_obs = n;
+  const std::vector<long long> rec_off = {0, (long long)n};
+  const std::vector<long long> tile_off = {0, (long long)((n + clc::TILE - 1) / clc::TILE)};
+  const LayoutTargets T = {&h->d_ctiles, &h->ctiles_cap_bytes, &h->d_groups, &h->groups_cap_bytes, &h->n_groups, &h->compact_ok,
+                           &h->d_rxy, &h->rxy_cap_bytes, &h->d_rdesc, &h->rdesc_cap_bytes, &h->n_rows, &h->rows_ok, nullptr,
+                           // a problem one workgroup can hold (<= 512 lanes x 22 points) also gets the lane layout: clc_solve then runs
+                           // its whole LM loop in ONE single-workgroup launch from registers + LDS (solve_resident_single)
+                           n <= (size_t)512 * (kResPR512 + kResPL512) ? &h->sres : nullptr, &h->rows_z,
+                           // what one workgroup cannot hold (more points; or more than 512 scans, or scans whose lengths leave
+                           // too many half-filled lanes: a lane holds points of ONE scan), up to 65 536 lanes x 40 points, is
+                           // dealt to 256 workgroups: the cooperative solve (clc_coop.hpp)
+                           n <= (size_t)clc::COOP_WGS * clc::COOP_NL * (clc::COOP_PR + clc::COOP_PL) ? &h->cres : nullptr};
+  return build_layouts(h, reinterpret_cast<const double*>(records_dev), n, rec_off, tile_off, T);
+}
+
+int clc_upload(clc_handle* h, const clc_observation* records, size_t n) {
+  if (!h || (n > 0 && !records)) return fail(CLC_ERR_INVALID_ARG, "clc_upload: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  DevBuf<double> aos(&h->pool);
+  if (n > 0) {
+    CLC_HIP(aos.alloc(n * 8));
+    CLC_HIP(hipMemcpy(aos.p, records, n * sizeof(clc_observation), hipMemcpyHostToDevice));
+  }
+  return clc_upload_device(h, reinterpret_cast<const clc_observation*>(aos.p), n);
+}
+
+}  // extern "C"
+
+// ---- resident scans + device-side problem assembly ---------------------------------------------------------------
+namespace {
+
+int grow(double** p, size_t* cap, size_t bytes) { return ensure_bytes(p, cap, std::max<size_t>(bytes, 8)); }
+
+// per-pose record offsets of a selection (host, O(poses)); CLC_ERR_EMPTY_SCAN mirrors the reference's .at(0) throw
+
+int selection_offsets(const clc_handle* h, bool linefit, bool boundary, std::vector<long long>* rec_off) {
+  const int P = h->store_poses;
+  rec_off->assign((size_t)P + 1, 0);
+  const std::vector<long long>& off = linefit ? h->s_ptl_off : h->s_pts_off;
+  for (int i = 0; i < P; ++i) {
+    long long c = off[(size_t)i + 1] - off[(size_t)i];
+    if (boundary && linefit) {
+      if (h->s_pts_off[(size_t)i + 1] - h->s_pts_off[(size_t)i] <= 0) return CLC_ERR_EMPTY_SCAN;
+      c += 2;
+    }
+    (*rec_off)[(size_t)i + 1] = (*rec_off)[(size_t)i] + c;
+  }
+  return CLC_OK;
+}
+
+
+}  // namespace
+
+namespace clc_abi {
+// builds the records of the selection on the device into *aos (allocated here)
+int flatten_on_device(clc_handle* h, bool linefit, bool boundary, DevBuf<double>* aos, long long* n_out) {
+  if (h->store_poses < 0) return fail(CLC_ERR_NO_DATA, "clc_select_observations: no scans stored (clc_store_observations)");
+  std::vector<long long> rec_off;
+  const int rc = selection_offsets(h, linefit, boundary, &rec_off);
+  if (rc == CLC_ERR_EMPTY_SCAN)
+    return fail(rc, "clc_select_observations: boundary constraint on an empty scan (reference: std::out_of_range at LaseCamCalCeres.cpp:278)");
+  const int P = h->store_poses;
+  const long long N = rec_off[(size_t)P];
+  *n_out = N;
+  CLC_HIP(aos->alloc((size_t)std::max<long long>(N, 1) * 8));
+  if (N == 0 || P == 0) return CLC_OK;
+  long long* d_off = reinterpret_cast<long long*>(h->d_soff);
+  CLC_HIP(hipMemcpyAsync(d_off + 2 * ((size_t)P + 1), rec_off.data(), sizeof(long long) * ((size_t)P + 1), hipMemcpyHostToDevice,
+                         h->stream));
+  hipLaunchKernelGGL(clc::flatten_kernel, dim3((unsigned)P), dim3(clc::BLOCK), 0, h->stream, P, h->d_sq, h->d_st, d_off,
+                     h->d_spts, d_off + ((size_t)P + 1), h->d_sptl, linefit ? 1 : 0, boundary ? 1 : 0,
+                     d_off + 2 * ((size_t)P + 1), aos->p);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));  // rec_off (host vector) must outlive the copy
+  return CLC_OK;
+}
+
+
+}  // namespace clc_abi
+
+extern "C" {
+
+int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz, const double* tag_t,
+                           const int64_t* pts_off, const double* pts, const int64_t* ptl_off, const double* ptl) {
+  if (!h || n_poses < 0 || (n_poses > 0 && (!tag_q_wxyz || !tag_t || !pts_off || !ptl_off)))
+    return fail(CLC_ERR_INVALID_ARG, "clc_store_observations: bad argument");
+  const size_t P = (size_t)n_poses;
+  h->store_poses = -1;
+  h->s_pts_off.assign(P + 1, 0);
+  h->s_ptl_off.assign(P + 1, 0);
+  for (size_t i = 0; i <= P && P > 0; ++i) {
+    h->s_pts_off[i] = pts_off[i] - pts_off[0];
+    h->s_ptl_off[i] = ptl_off[i] - ptl_off[0];
+    if (i > 0 && (h->s_pts_off[i] < h->s_pts_off[i - 1] || h->s_ptl_off[i] < h->s_ptl_off[i - 1]))
+      return fail(CLC_ERR_INVALID_ARG, "clc_store_observations: offsets not monotone");
+  }
+  const size_t M = (size_t)h->s_pts_off[P], ML = (size_t)h->s_ptl_off[P];
+  if ((M > 0 && !pts) || (ML > 0 && !ptl)) return fail(CLC_ERR_INVALID_ARG, "clc_store_observations: NULL points");
+  CLC_HIP(hipSetDevice(h->device));
+  int rc = grow(&h->d_sq, &h->sq_cap, P * 4 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_st, &h->st_cap, P * 3 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_spts, &h->spts_cap, M * 3 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_sptl, &h->sptl_cap, ML * 3 * sizeof(double));
+  if (rc == CLC_OK) rc = grow(&h->d_soff, &h->soff_cap, 3 * (P + 1) * sizeof(long long));
+  if (rc != CLC_OK) return rc;
+  if (P > 0) {
+    CLC_HIP(hipMemcpyAsync(h->d_sq, tag_q_wxyz, P * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CLC_HIP(hipMemcpyAsync(h->d_st, tag_t, P * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    long long* d_off = reinterpret_cast<long long*>(h->d_soff);
+    CLC_HIP(hipMemcpyAsync(d_off, h->s_pts_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    CLC_HIP(hipMemcpyAsync(d_off + (P + 1), h->s_ptl_off.data(), (P + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  }
+  if (M > 0) CLC_HIP(hipMemcpyAsync(h->d_spts, pts + 3 * pts_off[0], M * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (ML > 0) CLC_HIP(hipMemcpyAsync(h->d_sptl, ptl + 3 * ptl_off[0], ML * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));  // the caller's arrays may go away
+  h->store_poses = n_poses;
+  h->store_generation++;
+  return CLC_OK;
+}
+
+int64_t clc_store_generation(const clc_handle* h) { return h ? h->store_generation : -1; }
+
+int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_boundary_constraint, int64_t* n_records) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_select_observations: NULL handle");
+  CLC_HIP(hipSetDevice(h->device));
+  DevBuf<double> aos(&h->pool);
+  long long N = 0;
+  int rc = flatten_on_device(h, use_linefitting_data != 0, use_boundary_constraint != 0, &aos, &N);
+  if (rc != CLC_OK) return rc;
+  if (n_records) *n_records = (int64_t)N;
+  return clc_upload_device(h, reinterpret_cast<const clc_observation*>(aos.p), (size_t)N);
+}
+
+
+}  // extern "C"
+
+// ---- batched ---------------------------------------------------------------------------
+namespace {
+// records: host pointer (on_device = false: staged through a temporary device buffer) or device pointer
+int upload_batched_impl(clc_handle* h, const clc_observation* records, bool on_device, const int64_t* offsets,
+                        size_t n_problems) {
+  if (!h || !offsets || (n_problems > 0 && !records))
+    return fail(CLC_ERR_INVALID_ARG, "clc_upload_batched: bad argument");
+  CLC_HIP(hipSetDevice(h->device));
+  const size_t P = n_problems;
+  std::vector<long long> tile_off(P + 1, 0), nobs(P, 0);
+  long long max_tiles = 0;
+  for (size_t k = 0; k < P; ++k) {
+    const int64_t n = offsets[k + 1] - offsets[k];
+    if (n < 0) return fail(CLC_ERR_INVALID_ARG, "clc_upload_batched: offsets not monotone");
+    nobs[k] = n;
+    tile_off[k + 1] = tile_off[k] + (n + clc::TILE - 1) / clc::TILE;
+    max_tiles = std::max<long long>(max_tiles, tile_off[k + 1] - tile_off[k]);
+  }
+  h->batch_max_tiles = max_tiles;
+  const size_t total_tiles = (size_t)tile_off[P];
+  h->batch_total_tiles = total_tiles;
+  const size_t bytes = std::max<size_t>(total_tiles, 1) * clc::TILE_DOUBLES * sizeof(double);
+  if (bytes > h->btiles_cap_bytes) {
+    if (h->d_btiles) CLC_HIP(hipFree(h->d_btiles));
+    h->d_btiles = nullptr; h->btiles_cap_bytes = 0;
+    CLC_HIP(hipMalloc(&h->d_btiles, bytes));
+    h->btiles_cap_bytes = bytes;
+  }
+  if (P > h->problems_cap) {
+    void* olds[] = {h->d_tile_off, h->d_nobs, h->d_states, h->d_results, h->d_prob_row};
+    for (void* p : olds) if (p) CLC_HIP(hipFree(p));
+    if (h->h_poses) CLC_HIP(hipHostFree(h->h_poses));
+    if (h->h_summaries) CLC_HIP(hipHostFree(h->h_summaries));
+    h->h_poses = nullptr; h->h_summaries = nullptr;
+    h->d_tile_off = nullptr; h->d_nobs = nullptr; h->d_poses = nullptr; h->d_summaries = nullptr;
+    h->d_states = nullptr; h->d_results = nullptr; h->results_valid = 0; h->d_prob_row = nullptr;
+    h->problems_cap = 0;
+    CLC_HIP(hipMalloc(&h->d_tile_off, sizeof(long long) * (P + 1)));
+    CLC_HIP(hipMalloc(&h->d_nobs, sizeof(long long) * P));
+    CLC_HIP(hipHostMalloc(&h->h_poses, sizeof(double) * 7 * P, hipHostMallocMapped));
+    CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_poses), h->h_poses, 0));
+    CLC_HIP(hipHostMalloc(&h->h_summaries, sizeof(clc_summary) * P, hipHostMallocMapped));
+    CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_summaries), h->h_summaries, 0));
+    CLC_HIP(hipMalloc(&h->d_states, sizeof(clc::LmState) * P));
+    CLC_HIP(hipMalloc(&h->d_results, sizeof(clc_result_record) * P));
+    CLC_HIP(hipMalloc(&h->d_prob_row, sizeof(long long) * (P + 1)));
+    h->problems_cap = P;
+  }
+  if (P == 0) { h->n_problems = 0; return CLC_OK; }
+  CLC_HIP(hipMemcpy(h->d_tile_off, tile_off.data(), sizeof(long long) * (P + 1), hipMemcpyHostToDevice));
+  CLC_HIP(hipMemcpy(h->d_nobs, nobs.data(), sizeof(long long) * P, hipMemcpyHostToDevice));
+  // stage the AoS records, then re-tile every problem into its own whole tiles
+  const size_t n_total = (size_t)(offsets[P] - offsets[0]);
+  DevBuf<double> baos(&h->pool);
+  DevBuf<long long> boff(&h->pool);
+  double* d_aos = nullptr;
+  if (n_total > 0 && on_device) {
+    d_aos = const_cast<double*>(reinterpret_cast<const double*>(records + offsets[0]));
+  } else if (n_total > 0) {
+    CLC_HIP(baos.alloc(n_total * 8));
+    CLC_HIP(hipMemcpy(baos.p, records + offsets[0], n_total * sizeof(clc_observation), hipMemcpyHostToDevice));
+    d_aos = baos.p;
+  }
+  std::vector<long long> rel(P + 1);
+  for (size_t k = 0; k <= P; ++k) rel[k] = offsets[k] - offsets[0];
+  CLC_HIP(boff.alloc(P + 1));
+  long long* d_off = boff.p;
+  CLC_HIP(hipMemcpy(d_off, rel.data(), sizeof(long long) * (P + 1), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(clc::retile_batched_kernel, dim3((unsigned)P), dim3(256), 0, h->stream, d_aos, d_off,
+                     h->d_tile_off, h->d_btiles);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  int crc = CLC_OK;
+  h->bcompact_ok = false;
+  h->brows_ok = false;
+  h->bres.ok = false;
+  h->results_valid = 0;
+  if (e == hipSuccess && d_aos) {
+    const LayoutTargets T = {&h->d_bctiles, &h->bctiles_cap_bytes, &h->d_bgroups, &h->bgroups_cap_bytes, &h->bn_groups,
+                             &h->bcompact_ok, &h->d_brxy, &h->brxy_cap_bytes, &h->d_brdesc, &h->brdesc_cap_bytes, &h->bn_rows,
+                             &h->brows_ok, &h->d_prob_row, &h->bres, &h->brows_z};
+    crc = build_layouts(h, d_aos, n_total, rel, tile_off, T);
+  }
+  if (e != hipSuccess) return fail(CLC_ERR_HIP, "clc_upload_batched: retile", e);
+  if (crc != CLC_OK) return crc;
+  h->batch_max_rows = 0;
+  if (h->brows_ok) {  // O(P) words back: the whole-solve kernel is chosen on the real longest problem, not an estimate
+    std::vector<long long> pr(P + 1);
+    CLC_HIP(hipMemcpy(pr.data(), h->d_prob_row, sizeof(long long) * (P + 1), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < P; ++k) h->batch_max_rows = std::max(h->batch_max_rows, pr[k + 1] - pr[k]);
+  }
+  h->n_problems = P;
+  return CLC_OK;
+}
+}  // namespace
+
+int clc_upload_batched(clc_handle* h, const clc_observation* records, const int64_t* offsets, size_t n_problems) {
+  return upload_batched_impl(h, records, false, offsets, n_problems);
+}
+
+int clc_upload_batched_device(clc_handle* h, const clc_observation* records_dev, const int64_t* offsets, size_t n_problems) {
+  return upload_batched_impl(h, records_dev, true, offsets, n_problems);
+}
+
+size_t clc_num_problems(const clc_handle* h) { return h ? h->n_problems : 0; }
+

@@ -116,7 +116,7 @@ __device__ __forceinline__ void coop_wait_until(const long long t) {
 // gathered, 4 group row published, 5 the 8 group rows arrived, 6 totals in LDS, 7 controller done (behind its barrier); inside the pass:
 // 8 pose + plane set up, 9 points done, 10 expansion done; 11 lmu_pre done.  Slot 12 * COOP_STAMP_PASSES: kernel entry, + 1: points in.
 constexpr int COOP_STAMP_PASSES = 16, COOP_STAMP_PER_PASS = 12, COOP_STAMP_SLOTS = COOP_STAMP_PER_PASS * COOP_STAMP_PASSES + 2;
-__device__ long long clc_coop_stamp_buf[4][2][COOP_STAMP_SLOTS];
+static __device__ long long clc_coop_stamp_buf[4][2][COOP_STAMP_SLOTS];
 #define COOP_STAMP(slot)                                                                                                     \
   do {                                                                                                                       \
     if (lane == 0 && (wave == 0 || wave >= COOP_NW - 1) && (wg == 0 || wg == 7 || wg == 8 || wg == 255) && (slot) < COOP_STAMP_SLOTS)  \

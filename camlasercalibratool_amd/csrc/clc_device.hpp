@@ -347,7 +347,7 @@ __device__ __forceinline__ WaveRun wave_run(const RowDesc* __restrict__ desc, lo
 // was measured and rejected: with scans of a whole number of rows the boundaries snap to scan starts, so unequal nominal
 // shares turn into one wave with two scans next to waves with one: 8.7 -> 9.7-10.0 us per step launch at C2 for any share
 // between 5:6 and 0:6, no change at 2.5e5 observations or with 32-row scans; scripts/r03_wave0_share.py, profiles/r03_wave0_share.md.)
-__global__ void wave_split_kernel(const RowDesc* __restrict__ desc, const int n_rows, const int n_blocks, int* __restrict__ out) {
+static __global__ void wave_split_kernel(const RowDesc* __restrict__ desc, const int n_rows, const int n_blocks, int* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x, total = n_blocks * 8 + 1;
   if (t >= total) return;
   if (t == total - 1) { out[t] = n_rows; return; }

@@ -12,7 +12,7 @@ namespace clc {
 // ---------------------------------------------------------------------------------------
 // PointInPlaneFactor::Evaluate per record, literal operation order of
 // src/LaseCamCalCeres.cpp:43-66 (pt_c = R p + t; r = s (n.pt_c + d); J = s [n, n^T(-R [p]x), 0]).
-__global__ void factor_kernel(const double* __restrict__ tiles, long long n,
+static __global__ void factor_kernel(const double* __restrict__ tiles, long long n,
                               const double* __restrict__ pose, double* __restrict__ residuals,
                               double* __restrict__ jac7) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,7 +45,7 @@ __global__ void factor_kernel(const double* __restrict__ tiles, long long n,
 }
 
 // PoseLocalParameterization::Plus, one thread per (x, delta) pair.
-__global__ void plus_kernel(const double* __restrict__ x, const double* __restrict__ delta,
+static __global__ void plus_kernel(const double* __restrict__ x, const double* __restrict__ delta,
                             double* __restrict__ out, long long n) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -58,7 +58,7 @@ __global__ void plus_kernel(const double* __restrict__ x, const double* __restri
 
 // Debug/test entry: run only the wave reduction on caller-provided lane values
 // in[64][28] -> out[28].
-__global__ void wave_reduce_test_kernel(const double* __restrict__ in, double* __restrict__ out,
+static __global__ void wave_reduce_test_kernel(const double* __restrict__ in, double* __restrict__ out,
                                         int reduce_mode) {
   const int lane = threadIdx.x & 63;
   double acc[NACC];
@@ -96,7 +96,7 @@ __device__ __forceinline__ void accumulate_normal9(double nx, double ny, double 
     for (int j = 0; j < 3; ++j) acc[36 + 3 * i + j] = fma(bv[i] * nv[j], md, acc[36 + 3 * i + j]);
 }
 
-__global__ __launch_bounds__(BLOCK) void normal9_kernel(const double* __restrict__ tiles,
+static __global__ __launch_bounds__(BLOCK) void normal9_kernel(const double* __restrict__ tiles,
                                                         const long long n,
                                                         double* __restrict__ partials) {
   double acc[NACC9];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void normal9_kernel(const double* __restrict
 // Fixed-order sum of the 45-column block partials.  Thread (c, rg) sums rows rg, rg + 4, ... of column c with 16 independent
 // loads in flight per round (a dependent load chain over 256 rows cost 16 us here — more than K5 itself), then the four
 // row groups are combined in order.
-__global__ __launch_bounds__(BLOCK) void reduce9_kernel(const double* __restrict__ partials,
+static __global__ __launch_bounds__(BLOCK) void reduce9_kernel(const double* __restrict__ partials,
                                                         int n_blocks, double* __restrict__ out) {
   __shared__ double red[4][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(BLOCK) void line_fit_kernel(const double* __restric
 // theta = angle_min[s] + i * angle_increment[s] -> (r cos, r sin, 0), or (1000, 1000, 0) when the
 // range is outside [range_min[s], 30).  One thread per ray; streaming, 4 B in / 24 B out.
 // ---------------------------------------------------------------------------------------
-__global__ void scan_to_points_kernel(const float* __restrict__ ranges, const long long* __restrict__ off,
+static __global__ void scan_to_points_kernel(const float* __restrict__ ranges, const long long* __restrict__ off,
                                       const int n_scans, const float* __restrict__ angle_min,
                                       const float* __restrict__ angle_inc, const float* __restrict__ range_min,
                                       double* __restrict__ points) {
@@ -307,7 +307,7 @@ __global__ void scan_to_points_kernel(const float* __restrict__ ranges, const lo
 }
 
 // The same for device-resident scans of any count: one thread per ray, its scan found by binary search in the offsets.
-__global__ void scan_to_points_flat_kernel(const float* __restrict__ ranges, const long long* __restrict__ off,
+static __global__ void scan_to_points_flat_kernel(const float* __restrict__ ranges, const long long* __restrict__ off,
                                            const long long n_scans, const long long n_rays,
                                            const float* __restrict__ angle_min, const float* __restrict__ angle_inc,
                                            const float* __restrict__ range_min, double* __restrict__ points) {

@@ -1,5 +1,5 @@
 // clc_kernels.hpp — the evaluation and solve kernels of the point-to-plane extrinsic path (gfx950 / CDNA4, wave64).
-// Included by clc_abi.hip only.  See DESIGN.md §3 for the measurements.
+// Included by the abi_*.hip translation units (through clc_abi_internal.hpp).  See DESIGN.md §3 for the measurements.
 //
 //   eval_rows_kernel / eval_kernel    K1: fused residual + analytic 6-DoF Jacobian (a3) + Cauchy corrector (a4) + reduction of
 //                                     {H(21), g(6), cost} into one 28-double partial row per workgroup (clc_eval, the
@@ -116,7 +116,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
   __syncthreads();
 }
 
-__global__ __launch_bounds__(BLOCK) void reduce_kernel(const double* __restrict__ partials,
+static __global__ __launch_bounds__(BLOCK) void reduce_kernel(const double* __restrict__ partials,
                                                        int n_blocks, int with_loss, double lf,
                                                        double* __restrict__ out28) {
   __shared__ double red[BLOCK / 32][32];
@@ -192,7 +192,7 @@ static_assert(LM_STATE_WORDS + PRM_WORDS <= 256, "one block word per thread");
 #ifdef CLC_STAMPS
 // Debug build only (scripts/r02_stamps.py): wall-clock (100 MHz) stamps of every workgroup of the first 64 launches.
 constexpr int STAMP_LAUNCHES = 64, STAMP_WGS = 512, STAMP_SLOTS = 16;
-__device__ unsigned long long clc_stamp_buf[STAMP_LAUNCHES][STAMP_WGS][STAMP_SLOTS];
+static __device__ unsigned long long clc_stamp_buf[STAMP_LAUNCHES][STAMP_WGS][STAMP_SLOTS];
 #define CLC_STAMP(slot, tid)                                                                                        \
   do {                                                                                                              \
     if (threadIdx.x == (tid) && blockIdx.x < STAMP_WGS && launch_index < STAMP_LAUNCHES)                            \
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(512) void step_kernel(const double* __restrict__ ro
   CLC_STAMP(7, 448);
 }
 
-__global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0,
+static __global__ void lm_init_kernel(LmState* __restrict__ state, const clc_options opt, const Pose7 pose0,
                                unsigned int* __restrict__ ticket_counter) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     *ticket_counter = 0u;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(BT) void batched_rows_eval_kernel(
     block_reduce_store<BT / 64>(acc, 0, partials + (size_t)blockIdx.x * NACC);
 }
 
-__global__ __launch_bounds__(64) void batched_init_kernel(LmState* __restrict__ states, const clc_options opt,
+static __global__ __launch_bounds__(64) void batched_init_kernel(LmState* __restrict__ states, const clc_options opt,
                                     const double* __restrict__ poses, int n_problems, unsigned int* __restrict__ active,
                                     unsigned int* __restrict__ ticket) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,7 +444,7 @@ __device__ __forceinline__ void batched_write_outcome(const LmState& s, int p, d
 }
 
 // A problem writes its outcome in the launch in which it terminates (no separate finish launch).
-__global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
+static __global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
                                   LmState* __restrict__ states, const clc_options opt,
                                   const int n_problems, unsigned int* __restrict__ active,
                                   unsigned int* __restrict__ ticket, const int launch_index,
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(BLOCK, 2) void batched_solve_kernel(
 
 // Stragglers only: problems the host loop stopped launching for while they were still running (they are reported as
 // failures by clc_solve_batched).  Normally every problem has written its outcome in batched_lm_kernel already.
-__global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_problems,
+static __global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_problems,
                                       double* __restrict__ poses, clc_summary* __restrict__ summaries,
                                       double* __restrict__ results) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -560,7 +560,7 @@ __global__ void batched_finish_kernel(const LmState* __restrict__ states, int n_
 
 // Send buffer of the all-gather: cap records per rank, the first n_local real (global index = base + local index),
 // the rest padding (global_index = -1, everything else 0).
-__global__ void pack_results_kernel(const double* __restrict__ results, long long n_local, long long cap,
+static __global__ void pack_results_kernel(const double* __restrict__ results, long long n_local, long long cap,
                                     double base_index, double* __restrict__ send) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= cap) return;

@@ -10,7 +10,7 @@ namespace clc {
 // ---------------------------------------------------------------------------------------
 // retile: AoS records -> tiles.  One thread per record (one-time cost per upload).
 // ---------------------------------------------------------------------------------------
-__global__ void retile_kernel(const double* __restrict__ aos, double* __restrict__ tiles,
+static __global__ void retile_kernel(const double* __restrict__ aos, double* __restrict__ tiles,
                               long long n, long long n_padded) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_padded) return;
@@ -31,7 +31,7 @@ __global__ void retile_kernel(const double* __restrict__ aos, double* __restrict
 
 // Batched variant: one workgroup per problem; problem k's records [rec_off[k], rec_off[k+1])
 // go to its own whole tiles starting at tile_off[k].
-__global__ void retile_batched_kernel(const double* __restrict__ aos,
+static __global__ void retile_batched_kernel(const double* __restrict__ aos,
                                       const long long* __restrict__ rec_off,
                                       const long long* __restrict__ tile_off,
                                       double* __restrict__ tiles) {
@@ -59,7 +59,7 @@ __global__ void retile_batched_kernel(const double* __restrict__ aos,
 
 // upload-time helpers of the compact layout -------------------------------------------------
 // flag[k] = 1 when record k starts a new group: (n, d, scale) differ bitwise from record k-1.
-__global__ void group_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag) {
+static __global__ void group_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   bool nw = (k == 0);
@@ -71,7 +71,7 @@ __global__ void group_flag_kernel(const double* __restrict__ aos, long long n, u
   flag[k] = nw ? 1 : 0;
 }
 
-__global__ void build_groups_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
+static __global__ void build_groups_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
                                     long long n_groups, double* __restrict__ groups) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
@@ -82,7 +82,7 @@ __global__ void build_groups_kernel(const double* __restrict__ aos, const long l
 
 // Records [rec_off[b], rec_off[b+1]) of "problem" b -> compact tiles starting at tile_off[b]
 // (single problem: one entry).  One workgroup per problem, grid-stride over y for long ones.
-__global__ void build_ctiles_kernel(const double* __restrict__ aos, const unsigned int* __restrict__ gid,
+static __global__ void build_ctiles_kernel(const double* __restrict__ aos, const unsigned int* __restrict__ gid,
                                     const long long* __restrict__ rec_off, const long long* __restrict__ tile_off,
                                     double* __restrict__ ctiles) {
   const int prob = blockIdx.x;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_totals_kernel(const T
 }
 
 // exclusive scan of the block totals in place, one workgroup; totals[n_blocks] receives the grand total
-__global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(unsigned long long* __restrict__ totals, long long n_blocks) {
+static __global__ __launch_bounds__(SCAN_THREADS) void scan_totals_kernel(unsigned long long* __restrict__ totals, long long n_blocks) {
   __shared__ unsigned long long sh[SCAN_THREADS];
   __shared__ unsigned long long carry;
   if (threadIdx.x == 0) carry = 0;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const TIn* __r
 
 // flag[k] = 1 when record k starts a new scan ((n, d, scale) differ bitwise from record k-1); *any_z is set when some
 // record has p.z != 0 (the rows then carry z: ROW_DOUBLES_Z doubles per row; the on-chip resident layout does not apply).
-__global__ void scan_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag,
+static __global__ void scan_flag_kernel(const double* __restrict__ aos, long long n, unsigned char* __restrict__ flag,
                                  unsigned int* __restrict__ any_z) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool z = false;
@@ -203,28 +203,28 @@ __global__ void scan_flag_kernel(const double* __restrict__ aos, long long n, un
 }
 
 // a problem never shares a scan with its predecessor
-__global__ void mark_problem_starts_kernel(const long long* __restrict__ rec_off, long long n_problems, long long n,
+static __global__ void mark_problem_starts_kernel(const long long* __restrict__ rec_off, long long n_problems, long long n,
                                            unsigned char* __restrict__ flag) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n_problems && rec_off[p] < n) flag[rec_off[p]] = 1;
 }
 
 // starts[g] = first record of scan g; starts[G] = n; rows[g] = rows the scan occupies (filled by scan_rows_kernel)
-__global__ void scan_starts_kernel(const unsigned char* __restrict__ flag, const unsigned int* __restrict__ gid, long long n,
+static __global__ void scan_starts_kernel(const unsigned char* __restrict__ flag, const unsigned int* __restrict__ gid, long long n,
                                    long long n_groups, long long* __restrict__ starts) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n && flag[k]) starts[gid[k]] = k;
   if (k == 0) starts[n_groups] = n;
 }
 
-__global__ void scan_rows_kernel(const long long* __restrict__ starts, long long n_groups, unsigned int* __restrict__ rows) {
+static __global__ void scan_rows_kernel(const long long* __restrict__ starts, long long n_groups, unsigned int* __restrict__ rows) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < n_groups) rows[g] = (unsigned int)((starts[g + 1] - starts[g] + ROW - 1) / ROW);
 }
 
 // row_begin[G+1]: exclusive prefix of rows[] (row_begin[0] = 0 written here).  One thread per row SLOT.
 // stride = ROW_DOUBLES, or ROW_DOUBLES_Z: the 64 z of the row are stored after its (x, y) pairs.
-__global__ void build_rows_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
+static __global__ void build_rows_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
                                   const unsigned int* __restrict__ row_begin, long long n_groups, long long n_rows,
                                   const int stride, double* __restrict__ xy, RowDesc* __restrict__ desc) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,7 +258,7 @@ __global__ void build_rows_kernel(const double* __restrict__ aos, const long lon
 }
 
 // prob_row[p] = first row of problem p (problems start scans); prob_row[P] = n_rows
-__global__ void problem_rows_kernel(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
+static __global__ void problem_rows_kernel(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
                                     const unsigned int* __restrict__ row_begin, long long n_problems, long long n,
                                     long long n_rows, long long* __restrict__ prob_row) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,7 +267,7 @@ __global__ void problem_rows_kernel(const long long* __restrict__ rec_off, const
 }
 
 // groups[g] of the compact layout, from the device-resident starts
-__global__ void build_groups_dev_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
+static __global__ void build_groups_dev_kernel(const double* __restrict__ aos, const long long* __restrict__ starts,
                                         long long n_groups, double* __restrict__ groups) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
@@ -300,7 +300,7 @@ __device__ __forceinline__ void pi_from_ppp_rn(const double* x1, const double* x
   pi[3] = -__dadd_rn(__dadd_rn(__dmul_rn(x3[0], c12[0]), __dmul_rn(x3[1], c12[1])), __dmul_rn(x3[2], c12[2]));
 }
 
-__global__ __launch_bounds__(BLOCK) void flatten_kernel(const int n_poses, const double* __restrict__ tag_q_wxyz,
+static __global__ __launch_bounds__(BLOCK) void flatten_kernel(const int n_poses, const double* __restrict__ tag_q_wxyz,
                                                         const double* __restrict__ tag_t, const long long* __restrict__ pts_off,
                                                         const double* __restrict__ pts, const long long* __restrict__ ptl_off,
                                                         const double* __restrict__ ptl, const int linefit, const int boundary,

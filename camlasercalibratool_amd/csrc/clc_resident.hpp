@@ -59,7 +59,7 @@ __device__ __forceinline__ void res_scan_extent(const long long* __restrict__ st
 
 // One thread per problem: ppl[p] = the smallest points-per-lane (<= max_ppl) with sum_s ceil(c_s / ppl) <= n_lanes;
 // 0 for an empty problem.  *fail is set when some problem does not fit.
-__global__ void res_plan_kernel(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
+static __global__ void res_plan_kernel(const long long* __restrict__ rec_off, const unsigned int* __restrict__ gid,
                                 const long long* __restrict__ starts, long long n_problems, long long n, long long n_groups,
                                 int n_lanes, int max_ppl, unsigned int* __restrict__ ppl_out, unsigned int* __restrict__ fail) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict_
 // then per pass p < RES_STAMP_PASSES at 4 + 6 p: shader clock at pass start, after the point loop, after the wave
 // reduction, after barrier 1, (wave 0) after the totals, after the controller / barrier 2.
 constexpr int RES_STAMP_WGS = 1024, RES_STAMP_PASSES = 8, RES_STAMP_SLOTS = 4 + 6 * RES_STAMP_PASSES;
-__device__ long long clc_res_stamp_buf[RES_STAMP_WGS][2][RES_STAMP_SLOTS];
-__device__ unsigned long long clc_res_stamp_ctrl[RES_STAMP_WGS][16];  // lm_advance_wave's packed phase deltas of a workgroup's last pass
+static __device__ long long clc_res_stamp_buf[RES_STAMP_WGS][2][RES_STAMP_SLOTS];
+static __device__ unsigned long long clc_res_stamp_ctrl[RES_STAMP_WGS][16];  // lm_advance_wave's packed phase deltas of a workgroup's last pass
 #ifndef CLC_RES_STAMP_BASE
 #define CLC_RES_STAMP_BASE 0
 #endif

@@ -57,7 +57,7 @@ class Comm:
 
     def __init__(self, solver: "Solver", uid: bytes, rank: int, world: int):
         assert len(uid) == COMM_ID_BYTES
-        self._L = _capi.lib()
+        self._L = solver._L
         self._c = C.c_void_p()
         self._solver = solver  # keep the handle alive
         check(self._L.clc_comm_create(C.byref(self._c), solver._h, C.c_char_p(uid), C.c_int(rank), C.c_int(world)),
@@ -106,10 +106,12 @@ class Comm:
 
 
 class Solver:
-    """One solver context on one GPU (one HIP stream).  Not thread-safe per instance."""
+    """One solver context on one GPU (one HIP stream).  Not thread-safe per instance.
+    library: None = the build the package runs on (the product library unless CLC_LIBRARY names another), "hooks" = the
+    -DCLC_TEST_HOOKS build (the debug_* / time_* methods other than the layout reports need it), or a path."""
 
-    def __init__(self, device: int = 0):
-        self._L = _capi.lib()
+    def __init__(self, device: int = 0, library: Optional[str] = None):
+        self._L = _capi.lib() if library is None else (_capi.hooks_lib() if library == "hooks" else _capi.load(library))
         self._h = C.c_void_p()
         check(self._L.clc_create(C.byref(self._h), C.c_int(device)), "clc_create")
         self.device = device
@@ -187,11 +189,11 @@ class Solver:
     def debug_flatten_device(self, use_linefitting_data: bool = True, use_boundary_constraint: bool = False) -> np.ndarray:
         """The device-built records of a selection, copied back (test hook)."""
         n = C.c_int64()
-        check(self._L.clc_debug_flatten_device(self._h, C.c_int(int(use_linefitting_data)), C.c_int(int(use_boundary_constraint)),
+        check(self._hook("clc_debug_flatten_device")(self._h, C.c_int(int(use_linefitting_data)), C.c_int(int(use_boundary_constraint)),
                                                None, C.c_int64(0), C.byref(n)), "clc_debug_flatten_device")
         rec = np.empty((n.value, 8))
         if n.value:
-            check(self._L.clc_debug_flatten_device(self._h, C.c_int(int(use_linefitting_data)), C.c_int(int(use_boundary_constraint)),
+            check(self._hook("clc_debug_flatten_device")(self._h, C.c_int(int(use_linefitting_data)), C.c_int(int(use_boundary_constraint)),
                                                    dptr(rec), C.c_int64(n.value), C.byref(n)), "clc_debug_flatten_device")
         return rec
 
@@ -335,60 +337,67 @@ class Solver:
     def debug_wave_reduce(self, lanes: np.ndarray, reduce_mode: int) -> np.ndarray:
         lanes = np.ascontiguousarray(lanes, dtype=np.float64).reshape(64, 28)
         out = np.empty(28)
-        check(self._L.clc_debug_wave_reduce(self._h, dptr(lanes), dptr(out), C.c_int(reduce_mode)), "clc_debug_wave_reduce")
+        check(self._hook("clc_debug_wave_reduce")(self._h, dptr(lanes), dptr(out), C.c_int(reduce_mode)), "clc_debug_wave_reduce")
         return out
+
+    def _hook(self, name: str):
+        f = getattr(self._L, name, None)
+        if f is None:
+            raise RuntimeError(f"{name} is a test hook: not in the product library — create the solver with library=\"hooks\" "
+                               "(csrc/libclc_hip_hooks.so) or run with CLC_LIBRARY set to a hooks build")
+        return f
+
+    def path_info(self) -> "_capi.PathInfo":
+        """clc_get_path_info: which layouts the last uploads built and how the cooperative path is doing."""
+        pi = _capi.PathInfo()
+        check(self._L.clc_get_path_info(self._h, C.byref(pi)), "clc_get_path_info")
+        return pi
 
     def debug_rows(self):
         """Row layout report -> (rows_ok, n_rows, batched_rows_ok, batched_n_rows)."""
-        r, n, br, bn = C.c_int(), C.c_longlong(), C.c_int(), C.c_longlong()
-        check(self._L.clc_debug_rows(self._h, C.byref(r), C.byref(n), C.byref(br), C.byref(bn)), "clc_debug_rows")
-        return bool(r.value), n.value, bool(br.value), bn.value
+        pi = self.path_info()
+        return bool(pi.rows_layout), pi.n_rows, bool(pi.batched_rows_layout), pi.batched_n_rows
 
     def rows_carry_z(self):
         """(single-problem rows, batched rows) carry z: some uploaded record has p.z != 0, so the rows are the 24-byte form
         (64 z after the 64 (x, y) pairs of every row, 14 moments per scan) instead of the 16-byte one."""
-        r, n, br, bn = C.c_int(), C.c_longlong(), C.c_int(), C.c_longlong()
-        check(self._L.clc_debug_rows(self._h, C.byref(r), C.byref(n), C.byref(br), C.byref(bn)), "clc_debug_rows")
-        return r.value == 2, br.value == 2
+        pi = self.path_info()
+        return pi.rows_layout == 2, pi.batched_rows_layout == 2
 
     def debug_resident(self):
         """Resident ("lane") layout report of the uploaded batch -> (built, lanes per problem, largest points per lane,
         j-rows in all); built = the batched solver keeps every problem on chip for its whole solve (clc_resident.hpp)."""
-        ok, lanes, ppl, rows = C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
-        check(self._L.clc_debug_resident(self._h, C.byref(ok), C.byref(lanes), C.byref(ppl), C.byref(rows)), "clc_debug_resident")
-        return bool(ok.value), lanes.value, ppl.value, rows.value
+        pi = self.path_info()
+        return bool(pi.batched_resident), pi.batched_lanes, pi.batched_points_per_lane, pi.batched_lane_rows
 
     def debug_resident_single(self):
         """Lane layout of the single-problem array -> (built, lanes, points per lane); built = clc_solve with the default
         flags runs the whole LM solve in ONE single-workgroup launch (problems of at most 512 x 22 points)."""
-        ok, lanes, ppl = C.c_int(), C.c_int(), C.c_int()
-        check(self._L.clc_debug_resident_single(self._h, C.byref(ok), C.byref(lanes), C.byref(ppl)), "clc_debug_resident_single")
-        return bool(ok.value), lanes.value, ppl.value
+        pi = self.path_info()
+        return bool(pi.single_resident), pi.single_lanes, pi.single_points_per_lane
 
     def debug_coop(self):
         """Cooperative whole-GPU solve of the single-problem array (csrc/clc_coop.hpp) -> (layout built, largest points per
-        lane, solves run on it, launches that timed out, disabled on this handle)."""
-        ok, ppl, solves, aborts, off = C.c_int(), C.c_int(), C.c_longlong(), C.c_int(), C.c_int()
-        self._L.clc_debug_coop.argtypes = [C.c_void_p] + [C.c_void_p] * 5
-        check(self._L.clc_debug_coop(self._h, C.byref(ok), C.byref(ppl), C.byref(solves), C.byref(aborts), C.byref(off)), "clc_debug_coop")
-        return bool(ok.value), ppl.value, solves.value, aborts.value, bool(off.value)
+        lane, solves run on it, launches that timed out, resting on this handle)."""
+        pi = self.path_info()
+        return bool(pi.coop_resident), pi.coop_points_per_lane, pi.coop_solves, pi.coop_timeouts, bool(pi.coop_resting)
 
     def debug_coop_control(self, drop_next: int = 0, reenable: bool = False):
         """Test hook: launch the next cooperative solve `drop_next` workgroups short (it must time out and fall back); clear the
         disabled state."""
-        check(self._L.clc_debug_coop_control(self._h, C.c_int(drop_next), C.c_int(int(reenable))), "clc_debug_coop_control")
+        check(self._hook("clc_debug_coop_control")(self._h, C.c_int(drop_next), C.c_int(int(reenable))), "clc_debug_coop_control")
 
     def debug_coop_set_tag(self, tag: int):
         """Test hook: first pass tag of the next cooperative solve (32-bit; exercises the wrap)."""
-        check(self._L.clc_debug_coop_set_tag(self._h, C.c_uint(tag)), "clc_debug_coop_set_tag")
+        check(self._hook("clc_debug_coop_set_tag")(self._h, C.c_uint(tag)), "clc_debug_coop_set_tag")
 
     def debug_wave_split(self, grid: int):
         """Wave split table of the row layout for `grid` workgroups -> (split[grid * 8 + 1], first[n_rows])."""
         n_rows = self.debug_rows()[1]
         split = np.zeros(grid * 8 + 1, dtype=np.int32)
         first = np.zeros(max(n_rows, 1), dtype=np.int32)
-        self._L.clc_debug_wave_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        check(self._L.clc_debug_wave_split(self._h, C.c_int(grid), split.ctypes.data, first.ctypes.data), "clc_debug_wave_split")
+        self._hook("clc_debug_wave_split").argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        check(self._hook("clc_debug_wave_split")(self._h, C.c_int(grid), split.ctypes.data, first.ctypes.data), "clc_debug_wave_split")
         return split, first[:n_rows]
 
     def time_steps(self, pose: np.ndarray, first: int, last: int) -> Tuple[float, int]:
@@ -396,7 +405,7 @@ class Solver:
         stream right before launch `first` and right after launch `last`) and the solve's number of passes."""
         ms = C.c_double()
         n = C.c_int()
-        check(self._L.clc_time_steps(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(first), C.c_int(last),
+        check(self._hook("clc_time_steps")(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(first), C.c_int(last),
                                      C.byref(ms), C.byref(n)), "clc_time_steps")
         return ms.value, n.value
 
@@ -405,7 +414,7 @@ class Solver:
         ms = C.c_double()
         P = self.num_problems
         poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(P, 7))
-        check(self._L.clc_time_batched_eval(self._h, dptr(poses), C.c_int(reps), C.byref(ms)), "clc_time_batched_eval")
+        check(self._hook("clc_time_batched_eval")(self._h, dptr(poses), C.c_int(reps), C.byref(ms)), "clc_time_batched_eval")
         return ms.value
 
     def time_eval(self, pose: np.ndarray, reps: int = 20, with_loss: bool = True, loss_scale_factor: float = 0.05,
@@ -413,7 +422,7 @@ class Solver:
         """Mean duration [ms] of `reps` back-to-back evaluation-kernel launches (HIP events on the
         handle's stream)."""
         ms = C.c_double()
-        check(self._L.clc_time_eval(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(int(with_loss)),
+        check(self._hook("clc_time_eval")(self._h, dptr(np.ascontiguousarray(pose, dtype=np.float64)), C.c_int(int(with_loss)),
                                     C.c_double(loss_scale_factor), C.c_int(int(with_jacobian)), C.c_int(reps), C.byref(ms)),
               "clc_time_eval")
         return ms.value

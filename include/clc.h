@@ -170,6 +170,33 @@ int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
  * 0 = library default.  The environment variable CLC_AUTO_PATHS_DISABLE sets the initial mask of every handle. */
 int clc_set_auto_paths(clc_handle* h, int disable_mask);
 
+/* Which layouts the last clc_upload* / clc_select_observations / clc_upload_batched* built on this handle, and how the
+ * cooperative path is doing: a caller that sizes its problems, or shares the GPU, can see whether clc_solve and
+ * clc_solve_batched run from registers + LDS in one launch or on the streaming paths (operational query; no reference
+ * counterpart). */
+typedef struct clc_path_info {
+  int32_t single_resident;         /* 1: clc_solve = ONE single-workgroup launch (<= 512 lanes x 22 points, a lane holds one scan's points) */
+  int32_t single_lanes;
+  int32_t single_points_per_lane;
+  int32_t coop_resident;           /* 1: the lane layout of the cooperative kernel is built: clc_solve = ONE launch of 256 workgroups */
+  int32_t coop_points_per_lane;    /* <= 40 */
+  int32_t coop_resting;            /* 1: after a launch that timed out the path rests (the step chain runs) until its back-off expires */
+  int32_t coop_timeouts;           /* cooperative launches that timed out on this handle */
+  int32_t batched_resident;        /* 1: clc_solve_batched = ONE launch of the resident kernel */
+  int32_t batched_lanes;           /* 256 / 512 lanes per problem */
+  int32_t batched_points_per_lane;
+  int32_t rows_layout;             /* single problem's streaming row layout: 0 none, 1 (x, y) rows, 2 rows that carry z */
+  int32_t batched_rows_layout;
+  int64_t coop_solves;             /* solves that ran on the cooperative kernel */
+  int64_t batched_lane_rows;       /* point rows of the batched lane layout (x lanes x 16 bytes = its size) */
+  int64_t n_rows;                  /* rows of 64 points of the streaming row layouts */
+  int64_t batched_n_rows;
+} clc_path_info;
+int clc_get_path_info(const clc_handle* h, clc_path_info* out);
+
+/* Name (NUL-terminated, truncated to name_cap) and compute-unit count of the handle's device; either out pointer may be NULL. */
+int clc_device_info(clc_handle* h, char* name, int name_cap, int* num_cus);
+
 /* ---- problem assembly (host) --------------------------------------------------------
  * Replaces the residual-block construction loop of CamLaserCalibration,
  * src/LaseCamCalCeres.cpp:222-295 (plane per pose :227-231, scale :239-240, board-edge
@@ -344,6 +371,9 @@ void clc_comm_destroy(clc_comm* c);
 /* Rank and size of the communicator as RCCL itself reports them (ncclCommUserRank / ncclCommCount). */
 int clc_comm_rank(const clc_comm* c);
 int clc_comm_world(const clc_comm* c);
+/* Path of the RCCL library the collectives are bound to at run time (the one already loaded in the process — torch's — or
+ * librccl.so from the loader's path); "" before the first clc_comm_* call resolved it. */
+const char* clc_comm_library(void);
 /* ncclAllGather of the result records the LAST clc_solve_batched on the comm's handle left in device
  * memory.  This rank owns global problem indices [first_global_index, first_global_index + P_local);
  * every rank contributes exactly cap_per_rank records (P_local <= cap_per_rank, the rest padded with

@@ -3,9 +3,10 @@
 import collections, os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pat = sys.argv[1] if len(sys.argv) > 1 else "eval_kernelILb1ELb1"
+unit = sys.argv[2] if len(sys.argv) > 2 else "abi_solve.hip"  # the translation unit that launches the kernel (abi_batched.hip, abi_frontend.hip)
 d = tempfile.mkdtemp()
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-c",
-                       os.path.join(root, "camlasercalibratool_amd/csrc/clc_abi.hip"), "-save-temps", "-o", "x.o"],
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-mllvm", "-amdgpu-kernarg-preload-count=8", "-c",
+                       os.path.join(root, "camlasercalibratool_amd/csrc", unit), "-save-temps", "-o", "x.o"],
                       cwd=d, stderr=subprocess.DEVNULL)
 s = open(os.path.join(d, [f for f in os.listdir(d) if f.endswith("gfx950.s")][0])).read()
 names = re.findall(r"^(_Z\w*%s\w*):" % pat, s, flags=re.M)

@@ -9,8 +9,7 @@ sys.path.insert(0, ROOT)
 STAMPS_LIB = os.path.join(ROOT, "camlasercalibratool_amd", "csrc", "libclc_hip_stamps.so")
 if "--build" in sys.argv:
     from camlasercalibratool_amd import _build as b
-    cmd = [b._hipcc()] + b.HIPCC_FLAGS + ["-DCLC_STAMPS"] + (["-DCLC_STAMPS_WARM"] if "--warm" in sys.argv else []) + [os.path.join(b.CSRC, "clc_abi.hip"), "-o", STAMPS_LIB]
-    subprocess.run(cmd, check=True)
+    b.build_variant(STAMPS_LIB, ["-DCLC_TEST_HOOKS", "-DCLC_STAMPS"] + (["-DCLC_STAMPS_WARM"] if "--warm" in sys.argv else []))
     print("built", STAMPS_LIB)
     sys.exit(0)
 import ctypes as C

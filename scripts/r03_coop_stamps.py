@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 STAMPS_LIB = os.path.join(ROOT, "camlasercalibratool_amd", "csrc", "libclc_hip_stamps.so")
 if "--build" in sys.argv:
     from camlasercalibratool_amd import _build as b
-    subprocess.run([b._hipcc()] + b.HIPCC_FLAGS + ["-DCLC_STAMPS", os.path.join(b.CSRC, "clc_abi.hip"), "-o", STAMPS_LIB], check=True)
+    b.build_variant(STAMPS_LIB, ["-DCLC_TEST_HOOKS", "-DCLC_STAMPS"])
     print("built", STAMPS_LIB)
     sys.exit(0)
 import ctypes as C

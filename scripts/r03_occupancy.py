@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "camlasercalibratool_amd", "csrc", "libclc_hip_variants.so")
 if "--build" in sys.argv:
     from camlasercalibratool_amd import _build as b
-    subprocess.run([b._hipcc()] + b.HIPCC_FLAGS + ["-DCLC_EVAL_VARIANTS", os.path.join(b.CSRC, "clc_abi.hip"), "-o", LIB], check=True)
+    b.build_variant(LIB, ["-DCLC_TEST_HOOKS", "-DCLC_EVAL_VARIANTS"])
     print("built", LIB)
     sys.exit(0)
 import numpy as np

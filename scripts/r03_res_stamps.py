@@ -12,8 +12,7 @@ if "--build" in sys.argv:
     from camlasercalibratool_amd import _build as b
     for base in (0, 4096):
         out = STAMPS_LIB if base == 0 else STAMPS_LIB.replace(".so", f"_{base}.so")
-        cmd = [b._hipcc()] + b.HIPCC_FLAGS + ["-DCLC_STAMPS", f"-DCLC_RES_STAMP_BASE={base}", os.path.join(b.CSRC, "clc_abi.hip"), "-o", out]
-        subprocess.run(cmd, check=True)
+        b.build_variant(out, ["-DCLC_TEST_HOOKS", "-DCLC_STAMPS", f"-DCLC_RES_STAMP_BASE={base}"])
         print("built", out)
     sys.exit(0)
 import ctypes as C

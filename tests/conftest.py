@@ -7,6 +7,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The suite runs on the -DCLC_TEST_HOOKS build: the same translation units as the product library csrc/libclc_hip.so plus the
+# clc_debug_* / clc_time_* hooks the tests drive and inspect the paths with (which the product library does not export:
+# tests/test_abi_symbols.py).  tests/test_gpu_product_library.py runs the product build itself and compares bit for bit.
+# CLC_LIBRARY set by the caller (e.g. the -DCLC_LEGACY_PATHS build) wins.
+_HOOKS = os.path.join(ROOT, "camlasercalibratool_amd", "csrc", "libclc_hip_hooks.so")
+if "CLC_LIBRARY" not in os.environ and os.path.exists(_HOOKS):
+    os.environ["CLC_LIBRARY"] = _HOOKS
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

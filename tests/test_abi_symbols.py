@@ -18,10 +18,29 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(clc_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(_capi.EXPORTED)
-    L = _capi.lib()
+    L = _capi.load(_build.PRODUCT_LIB_PATH)
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/clc.h but not exported"
     assert L.clc_version() == 200
+
+
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] == "T"}  # functions (kernel handles are objects)
+
+
+def test_product_library_exports_the_header_and_nothing_else():
+    """nm -D libclc_hip.so: exactly the functions include/clc.h declares — no clc_debug_* / clc_time_* hook, no helper shared
+    between the translation units (-fvisibility=hidden); the hooks exist only in the -DCLC_TEST_HOOKS builds."""
+    prod = _dynamic_symbols(_build.PRODUCT_LIB_PATH)
+    ours = {s for s in prod if not s.startswith(("_init", "_fini", "__hip", "__bss", "_edata", "_end", "__cudaRegister"))}
+    assert sum(1 for s in prod if "clc_debug" in s or "clc_time" in s) == 0  # nm -D libclc_hip.so | grep -c clc_debug == 0
+    assert {s for s in ours if s.startswith("clc_")} == set(_capi.EXPORTED)
+    stray = {s for s in ours if not s.startswith("clc_") and ("clc" in s or s.startswith("_Z"))}
+    assert not stray, sorted(stray)[:10]
+    hooks = _dynamic_symbols(_build.HOOKS_LIB_PATH)
+    assert {s for s in hooks if s.startswith("clc_")} == set(_capi.EXPORTED) | set(_capi.HOOKS)
 
 
 def test_struct_layouts_match_header():

@@ -9,20 +9,31 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "camlasercalibratool_amd", "csrc", "clc_abi.hip")
+CSRC = os.path.join(ROOT, "camlasercalibratool_amd", "csrc")
+UNITS = ["abi_solve.hip", "abi_batched.hip", "abi_frontend.hip"]  # the translation units that launch the hot kernels
 
 
 @pytest.fixture(scope="module")
 def usage(tmp_path_factory):
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, ROOT)
+    from camlasercalibratool_amd import _build
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("res") / "x.so"
-    p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on", "-mllvm", "-amdgpu-kernarg-preload-count=8", "-DCLC_LEGACY_PATHS", SRC, "-o", str(out),
-                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
+    tmp = tmp_path_factory.mktemp("res")
+
+    def one(unit):
+        p = subprocess.run([hipcc] + _build.HIPCC_FLAGS + ["-DCLC_TEST_HOOKS", "-DCLC_LEGACY_PATHS", "-c", os.path.join(CSRC, unit), "-o", str(tmp / (unit + ".o")),
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return p.stderr
+
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+        stderr = "\n".join(ex.map(one, UNITS))
     res, cur = {}, None
-    for line in p.stderr.splitlines():
+    for line in stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             cur = m.group(1)
