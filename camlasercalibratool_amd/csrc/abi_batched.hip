@@ -145,8 +145,15 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   if (opt.use_loss && !(opt.loss_scale_factor > 0.0))
     return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: loss_scale_factor must be > 0");
   const size_t P = h->n_problems;
-  for (size_t i = 0; i < 7 * P; ++i)
-    if (!std::isfinite(poses[i])) return fail(CLC_ERR_NONFINITE, "clc_solve_batched: non-finite initial pose");
+  {  // all 7 P start-pose doubles finite: exponent field not all ones — an integer OR-reduction the compiler vectorises (57 344 values at C4)
+    unsigned long long bad = 0;
+    for (size_t i = 0; i < 7 * P; ++i) {
+      unsigned long long b;
+      std::memcpy(&b, &poses[i], sizeof(b));
+      bad |= (unsigned long long)(((b >> 52) & 0x7FFull) == 0x7FFull);
+    }
+    if (bad) return fail(CLC_ERR_NONFINITE, "clc_solve_batched: non-finite initial pose");
+  }
   CLC_HIP(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
   BatchedLaunch bl;
@@ -184,7 +191,9 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
 #undef CLC_LAUNCH_RES
     CLC_HIP(hipGetLastError());
     if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
-    CLC_HIP(hipStreamSynchronize(h->stream));  // kernel completion makes the outcomes written over PCIe visible
+    // (kernel completion makes the outcomes written over PCIe visible; polling the stream with hipStreamQuery instead of this
+    // blocking call was measured: no difference — the 70-80 us between the kernel's end event and the return are not the wake-up)
+    CLC_HIP(hipStreamSynchronize(h->stream));
     float kernel_ms = 0.0f;
     if (timed) CLC_HIP(hipEventElapsedTime(&kernel_ms, h->ev[0], h->ev[1]));
     h->results_valid = P;
