@@ -6,6 +6,11 @@ using namespace clc_abi;
 
 namespace clc_abi {
 
+void warm_batched() {
+  warm_kernel(reinterpret_cast<const void*>(&clc::resident_solve_kernel<true, true, 4, kResPR256, kResPL256, kResCtrl4>));
+  warm_kernel(reinterpret_cast<const void*>(&clc::batched_init_kernel));
+}
+
 int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunch* bl) {
   const size_t P = h->n_problems;
   bl->rows = use_brows(h);

@@ -113,6 +113,13 @@ int ensure_bytes(double** p, size_t* cap, size_t bytes) {
 
 }  // namespace clc_abi
 
+namespace {
+__global__ void first_launch_kernel(unsigned int* p) {
+  if (p == nullptr) return;
+  p[0] = 0u;
+}
+}  // namespace
+
 extern "C" {
 
 int clc_version(void) { return CLC_VERSION; }
@@ -177,6 +184,36 @@ int clc_create(clc_handle** out, int device) {
   CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_spose), h->h_spose, 0));
   h->h_ssummary = reinterpret_cast<clc_summary*>(h->h_spose + 8);
   h->d_ssummary = reinterpret_cast<clc_summary*>(h->d_spose + 8);
+  // The code objects of the units that hold kernels are loaded here, not by the first call that launches one of their kernels: the
+  // reference's programs call the path once per process, and that one call then took 20 ms instead of 1 (CLC_LAZY_MODULES=1: leave
+  // it to the first launches — a process that creates handles it may never use).
+  if (!std::getenv("CLC_LAZY_MODULES")) {
+    warm_layouts();
+    warm_solve();
+    warm_frontend();
+    warm_batched();
+    // ... and what else only the FIRST launch / copy / allocation of a process pays: the stream's hardware queue (first launch), the
+    // runtime's staging buffers for pageable copies (first hipMemcpy each way), the buffers every solve uses
+    hipLaunchKernelGGL(first_launch_kernel, dim3(1), dim3(64), 0, h->stream, h->d_queue);
+    double tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CLC_HIP(hipMemcpyAsync(h->d_small, tmp, sizeof(tmp), hipMemcpyHostToDevice, h->stream));
+    CLC_HIP(hipMemcpyAsync(tmp, h->d_small, sizeof(tmp), hipMemcpyDeviceToHost, h->stream));
+    CLC_HIP(hipStreamSynchronize(h->stream));
+    CLC_HIP(hipMemcpy(h->d_small, tmp, sizeof(tmp), hipMemcpyHostToDevice));
+    CLC_HIP(hipMemcpy(tmp, h->d_small, sizeof(tmp), hipMemcpyDeviceToHost));
+    {  // (copies of hundreds of kilobytes from pageable memory take another path than tiny ones: 7 ms the first time)
+      std::vector<double> big((size_t)1 << 17, 0.0);
+      DevBuf<double> dbig(&h->pool);
+      CLC_HIP(dbig.alloc(big.size()));
+      CLC_HIP(hipMemcpy(dbig.p, big.data(), big.size() * sizeof(double), hipMemcpyHostToDevice));
+      CLC_HIP(hipMemcpy(big.data(), dbig.p, big.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    int rc = ensure_partials(h, h->num_cus);
+    if (rc == CLC_OK) rc = ensure_trace(h, 128);
+    if (rc == CLC_OK) rc = ensure_events(h, 2);
+    if (rc != CLC_OK) { clc_destroy(h); return rc; }
+    CLC_HIP(hipStreamSynchronize(h->stream));
+  }
   *out = h;
   return CLC_OK;
 }

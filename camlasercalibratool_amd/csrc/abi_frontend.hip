@@ -4,6 +4,14 @@
 
 using namespace clc_abi;
 
+namespace clc_abi {
+void warm_frontend() {
+  warm_kernel(reinterpret_cast<const void*>(&clc::factor_kernel));
+  warm_kernel(reinterpret_cast<const void*>(&clc::normal9_kernel));
+  warm_kernel(reinterpret_cast<const void*>(&clc::line_fit_kernel<true>));
+}
+}  // namespace clc_abi
+
 extern "C" {
 
 int clc_factor_evaluate(clc_handle* h, const double pose[7], double* residuals, double* jacobians) {

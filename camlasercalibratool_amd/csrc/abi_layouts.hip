@@ -118,6 +118,15 @@ int build_resident(clc_handle* h, ResLayout& L, int first_try, const double* d_a
 
 namespace clc_abi {
 
+void warm_layouts() {
+  warm_kernel(reinterpret_cast<const void*>(&clc::retile_kernel));
+  warm_kernel(reinterpret_cast<const void*>(&clc::scan_flag_kernel));
+  warm_kernel(reinterpret_cast<const void*>(&clc::build_rows_kernel));
+  warm_kernel(reinterpret_cast<const void*>(&clc::res_plan_kernel));
+  warm_kernel(reinterpret_cast<const void*>(&clc::res_build_kernel<512>));
+  warm_kernel(reinterpret_cast<const void*>(&clc::flatten_kernel));
+}
+
 int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std::vector<long long>& rec_off,
                   const std::vector<long long>& tile_off, const LayoutTargets& T) {
   *T.compact_ok = false;

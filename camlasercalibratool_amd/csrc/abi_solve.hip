@@ -111,6 +111,11 @@ void launch_eval(clc_handle* h, int grid, bool with_loss, const double* d_pose,
 }  // namespace
 
 namespace clc_abi {
+void warm_solve() {
+  warm_kernel(reinterpret_cast<const void*>(&clc::resident_solve_kernel<true, false, 8, kResPR512, kResPL512, 0>));
+  warm_kernel(reinterpret_cast<const void*>(&clc::coop_solve_kernel<true, false>));
+}
+
 void launch_eval(clc_handle* h, int grid, bool with_jac, bool with_loss, const double* d_pose, const int32_t* d_status, double lf,
                  const clc::Pose7* pose_arg) {
   if (with_jac) ::launch_eval<true>(h, grid, with_loss, d_pose, d_status, lf, pose_arg);
@@ -317,10 +322,17 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, false, 8, kResPR512, kResPL512, CTRL>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, \
                      d_row, d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done, nullptr)
   const bool uni_ctrl = (h->auto_disable & 4) != 0;  // the cooperative kernel's controller here: the bit-identity test of the two
+  const bool timed = opt.profile_events == 2;  // an event pair around the one launch -> eval_kernel_ms, eval_kernel_launches = 1
+  if (timed) {
+    const int rc = ensure_events(h, 2);
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(hipEventRecord(h->ev[0], h->stream));
+  }
   if (opt.use_loss) { if (uni_ctrl) CLC_LAUNCH_SINGLE(true, 1); else CLC_LAUNCH_SINGLE(true, 0); }
   else { if (uni_ctrl) CLC_LAUNCH_SINGLE(false, 1); else CLC_LAUNCH_SINGLE(false, 0); }
 #undef CLC_LAUNCH_SINGLE
   CLC_HIP(hipGetLastError());
+  if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
   // The kernel sets the flag (system-scope release) after the outcome is written: polling it avoids the wake-up latency of a
   // blocking stream synchronisation (~15 us of a ~120 us solve).  Bounded: a wedged queue falls through to the synchronisation,
   // which reports the error.
@@ -333,16 +345,18 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_spin).count() > 30.0) break;
       }
     }
-    if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == 0 || want_trace) CLC_HIP(hipStreamSynchronize(h->stream));
+    if (__atomic_load_n(h_done, __ATOMIC_ACQUIRE) == 0 || want_trace || timed) CLC_HIP(hipStreamSynchronize(h->stream));
   }
+  float kernel_ms = 0.0f;
+  if (timed) CLC_HIP(hipEventElapsedTime(&kernel_ms, h->ev[0], h->ev[1]));
   *summary = *h->h_ssummary;
   for (int i = 0; i < 7; ++i) pose[i] = h->h_spose[i];
   if (want_trace) {
     const int n = std::min(std::min(summary->num_iterations + 1, trace_cap), h->trace_cap);
     if (n > 0) CLC_HIP(hipMemcpy(trace, h->d_trace, sizeof(clc_iteration) * (size_t)n, hipMemcpyDeviceToHost));
   }
-  summary->eval_kernel_ms = 0.0;
-  summary->eval_kernel_launches = 0;
+  summary->eval_kernel_ms = timed ? (double)kernel_ms : 0.0;
+  summary->eval_kernel_launches = timed ? 1 : 0;
   summary->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!all_finite(pose, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve: non-finite result");
   return CLC_OK;

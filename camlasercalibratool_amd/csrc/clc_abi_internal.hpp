@@ -252,6 +252,17 @@ bool use_brows(const clc_handle* h);
 bool rows_nontemporal(const clc_handle* h, long long n_rows, bool z = false);
 void ensure_wave_split(clc_handle* h, int grid);
 
+// Every unit with kernels: load its code object on the current device now (hipFuncGetAttributes on a kernel of the unit), so that
+// the first call after clc_create does not pay the lazy module load (~2-8 ms per unit).
+void warm_layouts();
+void warm_solve();
+void warm_frontend();
+void warm_batched();
+inline void warm_kernel(const void* f) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, f) != hipSuccess) (void)hipGetLastError();  // (never fatal: the launch itself reports a real problem)
+}
+
 // ---- abi_layouts.hip ----
 // Resident layout limits: what the instantiations of resident_solve_kernel hold per lane (registers + LDS).
 // 256-lane form: 256-thread workgroups, two problems per CU; 512-lane form: one 512-thread workgroup per CU (problems with more

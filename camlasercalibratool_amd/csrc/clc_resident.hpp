@@ -22,10 +22,14 @@
 // rounding (reduction tolerance 1e-11), not bit for bit; iteration counts and terminations are the same
 // (tests/test_gpu_resident.py).
 //
-// Occupancy: two waves per SIMD.  <NW=4, PR=26, PL=18>: 256-thread workgroups, TWO problems resident per CU (73.7 KB
-// of LDS + 104 VGPRs of points each): while one problem's wave 0 runs the serial controller (~4 000 cycles on one
-// SIMD), the other problem's waves stream.  Capacity 256 lanes x 44 points.  <8, 26, 18>: one 512-thread workgroup per
-// CU for problems of up to 512 x 44 points.
+// Occupancy: two waves per SIMD.  The instantiations (abi_*.hip: kResPR256 / kResPL256 / kResPR512 / kResPL512):
+//   <NW=4, PR=23, PL=19>: 256-thread workgroups, TWO problems resident per CU (256 lanes x 19 points x 16 B = 77.8 KB of LDS +
+//     92 VGPRs of points each): while one problem's wave 0 runs the serial controller (~5 500 cycles on one SIMD), the other
+//     problem's waves stream.  Capacity 256 lanes x 42 points.  The batched default.
+//   <NW=8, PR=4, PL=18>: one 512-thread workgroup per CU (512 lanes x 18 x 16 B = 147.5 KB of LDS), capacity 512 lanes x 22
+//     points = 11 264: batches with more than 256 scans per problem (or flag 8192), and the single-problem solve of clc_solve.
+// CTRL selects the controller between passes: 0 = lm_advance_wave on the LDS state (clc_controller.hpp), 1 = the register-state
+// controller of the cooperative kernel (clc_lmuni.hpp; bit-identical decisions and results, tests/test_gpu_lmuni.py).
 #pragma once
 #include "clc_kernels.hpp"
 #include "clc_lmuni.hpp"

@@ -218,28 +218,25 @@ namespace clc_adapter {
 //     run.ClosedSolution(Tlc_initial);  Eigen::Matrix4d Tcl = Tlc_initial.inverse();  run.Calibration(Tcl, false);
 class Session {
  public:
-    explicit Session(const std::vector<Oberserve>& obs) : ok_(false), generation_(-1)
+    explicit Session(const std::vector<Oberserve>& obs) : obs_(obs), ok_(false), generation_(-1)
     {
         Handle H;  // locked first: flatten gathers into the process-wide pinned buffers
         if (!H.h) return;
-        const Flat f = flatten(obs);
-        const int P = (int)(f.pts_off.size() - 1);
-        if (clc_store_observations(H.h, P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts,
-                                   f.ptl_off.data(), f.ptl) != CLC_OK) {
-            std::cerr << "[clc] " << clc_last_error() << std::endl;
-            return;
-        }
-        generation_ = clc_store_generation(H.h);
-        ok_ = true;
+        ok_ = store(H.h);
     }
+
+    // false after a call that could not run (no device, a store / select / solve error — the message went to std::cerr): the
+    // reference's functions return void, so a caller that wants to know asks here.  Tlc / Tcl are left unchanged by such a call.
+    bool ok() const { return ok_; }
 
     // Closed-form initial guess of Tlc (camera -> laser).  Reference: src/LaseCamCalCeres.cpp:112-203.
     void ClosedSolution(Eigen::Matrix4d &Tlc)
     {
         Handle H;
-        if (!ok_ || !H.h || !mine(H.h)) return;
+        if (!H.h || !mine(H.h)) { ok_ = false; return; }
         if (clc_select_observations(H.h, /*linefit=*/1, /*boundary=*/0, NULL) != CLC_OK) {  // points_on_line only, :143
             std::cerr << "[clc] " << clc_last_error() << std::endl;
+            ok_ = false;
             return;
         }
         double T[16]; int unobservable = 0;
@@ -251,6 +248,7 @@ class Session {
         }
         if (rc != CLC_OK) {  // only a non-finite result (the pivoted LDLT / SVD back end is defined for singular input)
             std::cerr << "[clc] " << clc_last_error() << std::endl;
+            ok_ = false;
             return;
         }
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tlc(i, j) = T[4 * i + j];  // :198-200
@@ -261,10 +259,11 @@ class Session {
     void Calibration(Eigen::Matrix4d &Tcl, bool use_linefitting_data = true, bool use_boundary_constraint = false)
     {
         Handle H;
-        if (!ok_ || !H.h || !mine(H.h)) return;
+        if (!H.h || !mine(H.h)) { ok_ = false; return; }
         int64_t n_rec = 0;
         if (clc_select_observations(H.h, use_linefitting_data, use_boundary_constraint, &n_rec) != CLC_OK) {
             std::cerr << "[clc] " << clc_last_error() << std::endl;  // incl. the reference's std::out_of_range case, :278
+            ok_ = false;
             return;
         }
         double R[9], pose[7];
@@ -275,6 +274,7 @@ class Session {
         clc_summary sum;
         if (clc_solve(H.h, &opt, pose, &sum, NULL, 0) != CLC_OK) {
             std::cerr << "[clc] " << clc_last_error() << std::endl;
+            ok_ = false;
             return;
         }
         static const char* term[] = {"RUNNING", "CONVERGENCE (gradient)", "CONVERGENCE (parameter)", "CONVERGENCE (function)",
@@ -314,16 +314,27 @@ class Session {
     }
 
  private:
-    // The stored scans belong to the process-wide handle: a later Session (or one of the free functions below, which are
-    // one-call sessions) replaces them.  This Session does not keep a copy of `obs`, so it refuses to go on — loudly —
-    // rather than solve somebody else's observations.
-    bool mine(clc_handle* h) const
+    bool store(clc_handle* h)
     {
-        if (clc_store_generation(h) == generation_) return true;
-        std::cerr << "[clc] Session: another Session / CamLaserCal* call has replaced the scans stored on the shared context; "
-                     "create a new Session for these observations" << std::endl;
-        return false;
+        const Flat f = flatten(obs_);
+        const int P = (int)(f.pts_off.size() - 1);
+        if (clc_store_observations(h, P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts,
+                                   f.ptl_off.data(), f.ptl) != CLC_OK) {
+            std::cerr << "[clc] " << clc_last_error() << std::endl;
+            return false;
+        }
+        generation_ = clc_store_generation(h);
+        return true;
     }
+    // The stored scans belong to the process-wide handle: a later Session (or one of the free functions below, which are
+    // one-call sessions) replaces them.  This Session keeps its observations and stores them again when that happened (as
+    // calib.py's Session does), rather than solve somebody else's.
+    bool mine(clc_handle* h)
+    {
+        if (generation_ >= 0 && clc_store_generation(h) == generation_) return true;
+        return store(h);
+    }
+    const std::vector<Oberserve> obs_;
     bool ok_;
     int64_t generation_;
 };

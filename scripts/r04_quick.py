@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 4 quick timing on the GPU box: the cooperative C2 solve (wall + kernel), single-workgroup solves under both controllers
-(clc_set_auto_paths bit 4 = round-3 LDS controller), C3 and a C4 shard through the resident batched kernel.  One JSON line each."""
+(clc_set_auto_paths bit 4 = the cooperative kernel's register-state controller instead of the LDS-state one), C3 and a C4 shard through the resident batched kernel.  One JSON line each."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -40,7 +40,7 @@ for name, S in (("c1", sd.GenerateSimData(1, noise_sigma=0.01)), ("20x500", sd.s
     sv.set_launch(0, -1)
     sv.upload(rec)
     row = {"observations": int(rec.shape[0])}
-    for label, mask in (("regs", 0), ("lds", 4), ("regs", 0), ("lds", 4)):
+    for label, mask in (("default_controller", 0), ("coop_controller", 4), ("default_controller", 0), ("coop_controller", 4)):
         sv.set_auto_paths(mask)
         for _ in range(20):
             r = sv.solve(x0, trace_cap=0)

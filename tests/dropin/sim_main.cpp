@@ -119,7 +119,30 @@ static int session_flow(size_t n_poses, size_t n_rays) {
     return 0;
 }
 
+// Two Sessions alive at once: the second one's store replaces the scans on the shared context; the first one notices (store
+// generation), stores its own observations again and solves ITS problem — and says through ok() that it could run.
+static int replaced_flow() {
+    std::vector<Oberserve> obs_a, obs_b;
+    GenerateSimData(obs_a, 7u, 0.0, 50, 180);
+    GenerateSimData(obs_b, 8u, 0.05, 30, 60);
+    clc_adapter::Session a(obs_a);
+    clc_adapter::Session b(obs_b);  // replaces a's scans on the device
+    Eigen::Matrix4d Tlc = Eigen::Matrix4d::Identity();
+    a.ClosedSolution(Tlc);
+    Eigen::Matrix4d Tcl = invert(Tlc);
+    a.Calibration(Tcl, false);
+    Eigen::Matrix4d Tb = Eigen::Matrix4d::Identity();
+    b.ClosedSolution(Tb);  // (and back again)
+    Tlc = invert(Tcl);
+    const double Rgt[3][3] = {{0, 0, 1}, {-1, 0, 0}, {0, -1, 0}}, tgt[3] = {0.1, 0.2, 0.3};
+    double eR = 0, et = 0;
+    for (int i = 0; i < 3; ++i) { et = std::fmax(et, std::fabs(Tlc(i, 3) - tgt[i])); for (int j = 0; j < 3; ++j) eR = std::fmax(eR, std::fabs(Tlc(i, j) - Rgt[i][j])); }
+    std::printf("REPLACED ok_a=%d ok_b=%d %.3e %.3e\n", a.ok() ? 1 : 0, b.ok() ? 1 : 0, et, eR);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "replaced") return replaced_flow();
     if (argc > 1 && std::string(argv[1]) == "session")
         return session_flow(argc > 2 ? (size_t)std::atol(argv[2]) : 2000, argc > 3 ? (size_t)std::atol(argv[3]) : 900);
     const bool offline_flow = argc > 1 && std::string(argv[1]) == "offline";

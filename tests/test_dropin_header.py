@@ -69,3 +69,15 @@ def test_dropin_session_flow_at_c2_size():
     t = re.search(r"TIMING session flow: total (\S+) ms", p.stdout)
     assert t and float(t.group(1)) < 50.0
     print(re.search(r"TIMING.*", p.stdout).group(0))
+
+
+@pytest.mark.gpu
+def test_dropin_session_whose_scans_were_replaced_stores_them_again():
+    """Two clc_adapter::Session objects alive at once: the second store replaces the first one's scans on the shared context; the
+    first Session stores its own observations again (as calib.py's Session does) and recovers ITS noise-free ground truth; ok()
+    reports that the calls ran."""
+    p = subprocess.run([_build_exe(), "replaced"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"REPLACED ok_a=(\d) ok_b=(\d) (\S+) (\S+)", p.stdout)
+    assert m and m.group(1) == "1" and m.group(2) == "1", p.stdout[-600:]
+    assert float(m.group(3)) < 1e-7 and float(m.group(4)) < 1e-7, p.stdout[-600:]
