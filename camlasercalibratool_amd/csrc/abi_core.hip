@@ -226,7 +226,7 @@ void clc_destroy(clc_handle* h) {
   void* ptrs[] = {h->d_tiles, h->d_partials, h->d_block, h->d_trace, h->d_small, h->d_btiles,
                   h->d_tile_off, h->d_nobs, h->d_queue, h->d_states,
                   h->d_bpartials, h->d_ticket, h->d_ctiles, h->d_groups, h->d_bctiles, h->d_bgroups, h->d_results,
-                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->bres.d_xy, h->bres.d_desc, h->bres.d_row, h->sres.d_xy, h->sres.d_desc, h->sres.d_row, h->cres.d_xy, h->cres.d_desc, h->cres.d_row, h->d_board, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
+                  h->d_rxy, h->d_rdesc, h->d_brxy, h->d_brdesc, h->bres.d_xy, h->bres.d_desc, h->bres.d_row, h->sres.d_xy, h->sres.d_desc, h->sres.d_row, h->cres.d_xy, h->cres.d_desc, h->cres.d_row, h->cres.d_z, h->sres.d_z, h->bres.d_z, h->d_board, h->d_prob_row, h->d_sq, h->d_st, h->d_spts, h->d_sptl, h->d_soff};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->pool.clear();
@@ -265,6 +265,7 @@ int clc_get_path_info(const clc_handle* h, clc_path_info* out) {
   out->single_points_per_lane = h->sres.ok ? h->sres.max_ppl : 0;
   out->coop_resident = h->cres.ok ? 1 : 0;
   out->coop_points_per_lane = h->cres.ok ? h->cres.max_ppl : 0;
+  out->coop_points_carry_z = h->cres.ok && h->cres.with_z ? 1 : 0;
   out->coop_resting = h->coop_eligible < h->coop_retry_at ? 1 : 0;
   out->coop_timeouts = h->coop_aborts;
   out->batched_resident = h->bres.ok ? 1 : 0;

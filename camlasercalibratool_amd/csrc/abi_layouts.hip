@@ -51,8 +51,10 @@ int device_scan(clc_handle* h, const TIn* d_in, long long n, unsigned int minus_
 // (points per lane of every problem, on the device), offsets (O(P) on the host), lane descriptors + j-major point rows.
 // Leaves L.ok false — and the streaming layouts in charge — when some problem does not fit a workgroup.
 int build_resident(clc_handle* h, ResLayout& L, int first_try, const double* d_aos, long long n, size_t P, size_t G,
-                   const long long* d_rec_off, const unsigned int* d_gid, const long long* d_starts, int max_ppl_override = 0) {
+                   const long long* d_rec_off, const unsigned int* d_gid, const long long* d_starts, int max_ppl_override = 0,
+                   bool with_z = false) {
   L.ok = false;
+  L.with_z = false;
   L.lanes = 0;
   L.max_ppl = 0;
   L.rows = 0;
@@ -96,20 +98,27 @@ int build_resident(clc_handle* h, ResLayout& L, int first_try, const double* d_a
   if (rc != CLC_OK) return rc;
   CLC_HIP(hipMemcpyAsync(L.d_row, row.data(), (P + 1) * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
   CLC_HIP(hipMemsetAsync(L.d_xy + (size_t)total * (size_t)lanes * 2, 0, (size_t)lanes * 2 * sizeof(double), h->stream));
+  if (with_z) {
+    rc = ensure_bytes(&L.d_z, &L.z_cap, ((size_t)total + 1) * (size_t)lanes * sizeof(double));
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(hipMemsetAsync(L.d_z + (size_t)total * (size_t)lanes, 0, (size_t)lanes * sizeof(double), h->stream));
+  }
+  double* d_zl = with_z ? L.d_z : nullptr;
   const unsigned int* d_row = reinterpret_cast<const unsigned int*>(L.d_row);
   clc::ResLane* d_desc = reinterpret_cast<clc::ResLane*>(L.d_desc);
   if (lanes == 256)
     hipLaunchKernelGGL((clc::res_build_kernel<256>), dim3((unsigned)P), dim3(256), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
-                       (long long)G, d_row, d_desc, L.d_xy);
+                       (long long)G, d_row, d_desc, L.d_xy, d_zl);
   else
     hipLaunchKernelGGL((clc::res_build_kernel<512>), dim3((unsigned)P), dim3(512), 0, h->stream, d_aos, d_rec_off, d_gid, d_starts, n,
-                       (long long)G, d_row, d_desc, L.d_xy);
+                       (long long)G, d_row, d_desc, L.d_xy, d_zl);
   CLC_HIP(hipGetLastError());
   CLC_HIP(hipStreamSynchronize(h->stream));  // `row` is a host temporary
   L.lanes = lanes;
   L.max_ppl = (int)max_ppl;
   L.uni_ppl = uniform && P > 0 ? (int)ppl[0] : -1;
   L.rows = (long long)total;
+  L.with_z = with_z;
   L.ok = true;
   return CLC_OK;
 }
@@ -239,7 +248,8 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   }
   if (T.coop != nullptr) {
     T.coop->ok = false;
-    if (!any_z && P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && !(T.res != nullptr && T.res->ok)) {
+    // (records with p.z != 0: the cooperative kernel's WITH_Z form holds 24-byte slots — the only on-chip form that does)
+    if (P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && !(T.res != nullptr && T.res->ok)) {
       // the one problem in COOP_WGS chunks of equal record counts (a chunk may begin and end inside a scan: res_scan_extent)
       std::vector<long long> chunk(clc::COOP_WGS + 1);
       for (int c = 0; c <= clc::COOP_WGS; ++c) chunk[c] = (long long)((__int128)n * c / clc::COOP_WGS);
@@ -247,7 +257,8 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
       CLC_HIP(bchunk.alloc(chunk.size()));
       CLC_HIP(hipMemcpyAsync(bchunk.p, chunk.data(), chunk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
       CLC_HIP(hipStreamSynchronize(h->stream));
-      rc = build_resident(h, *T.coop, clc::COOP_NL, d_aos, n, (size_t)clc::COOP_WGS, G, bchunk.p, bgid.p, bstarts.p, clc::COOP_PR + clc::COOP_PL);
+      rc = build_resident(h, *T.coop, clc::COOP_NL, d_aos, n, (size_t)clc::COOP_WGS, G, bchunk.p, bgid.p, bstarts.p,
+                          any_z ? clc::COOP_PR_Z + clc::COOP_PL_Z : clc::COOP_PR + clc::COOP_PL, any_z != 0);
       if (rc != CLC_OK) return rc;
     }
   }

@@ -371,6 +371,10 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
     int a = 0, b = 0;
     const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, clc::coop_solve_kernel<true, false>, clc::COOP_THREADS, 0);
     const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, clc::coop_solve_kernel<false, false>, clc::COOP_THREADS, 0);
+    int c = 0, d = 0;
+    const hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, clc::coop_solve_kernel<true, false, true>, clc::COOP_THREADS, 0);
+    const hipError_t e4 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, clc::coop_solve_kernel<false, false, true>, clc::COOP_THREADS, 0);
+    if (e3 != hipSuccess || e4 != hipSuccess || c < 1 || d < 1) a = 0;
     h->coop_checked = (e1 == hipSuccess && e2 == hipSuccess && a >= 1 && b >= 1 && h->num_cus >= clc::COOP_WGS) ? 1 : -1;
     (void)hipGetLastError();
   }
@@ -419,12 +423,12 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
   const unsigned int wgs = (unsigned int)(clc::COOP_WGS - h->coop_test_drop);
   h->coop_test_drop = 0;
   if (timed) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
-  if (opt.use_loss)
-    hipLaunchKernelGGL((clc::coop_solve_kernel<true, false>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, d_row, d_desc,
-                       h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
-  else
-    hipLaunchKernelGGL((clc::coop_solve_kernel<false, false>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, d_row, d_desc,
-                       h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done);
+#define CLC_LAUNCH_COOP(LOSS, Z)                                                                                                              \
+  hipLaunchKernelGGL((clc::coop_solve_kernel<LOSS, false, Z>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, h->cres.d_z, d_row, \
+                     d_desc, h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done)
+  if (h->cres.with_z) { if (opt.use_loss) CLC_LAUNCH_COOP(true, true); else CLC_LAUNCH_COOP(false, true); }  // 24-byte slots: p.z != 0
+  else { if (opt.use_loss) CLC_LAUNCH_COOP(true, false); else CLC_LAUNCH_COOP(false, false); }
+#undef CLC_LAUNCH_COOP
   CLC_HIP(hipGetLastError());
   if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
   {  // the kernel raises the flag (system-scope release) after the outcome is written; bounded like solve_resident_single

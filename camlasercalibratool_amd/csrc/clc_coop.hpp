@@ -52,6 +52,9 @@ constexpr int COOP_NW = 4, COOP_NL = 64 * COOP_NW;  // the point waves / lanes o
 constexpr int COOP_THREADS = COOP_NL + 64;           // ... + the controller wave
 constexpr int COOP_STATUS_ABORT = -1;                // published instead of an LM status when the launch gives up
 constexpr int COOP_PR = 16, COOP_PL = 24;
+// points that carry z (p.z != 0 in some record: 24 bytes per slot instead of 16): the same registers and the same 98 KB of LDS hold
+// 10 + 16 points per lane — 65 536 lanes x 26 = 1.7e6 observations
+constexpr int COOP_PR_Z = 10, COOP_PL_Z = 16;
 constexpr unsigned long long COOP_CENSUS_TICKS = 20000ull;    // first pass: 200 us of the 100 MHz wall clock per poll
 constexpr unsigned long long COOP_TIMEOUT_TICKS = 100000ull;  // later passes: 1 ms
 constexpr int COOP_DONE_OK = 1, COOP_DONE_ABORT = 2;
@@ -144,16 +147,18 @@ __device__ __forceinline__ void wave_reduce_to_rows(double (&acc)[NACC], double 
   }
 }
 
-template <bool WITH_LOSS, bool NT>
+template <bool WITH_LOSS, bool NT, bool WITH_Z = false>
 __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
-    const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
+    const double* __restrict__ xyl, const double* __restrict__ zl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, const Pose7 pose0, clc_iteration* __restrict__ trace,
     const int trace_cap, CoopBoard* __restrict__ board, const unsigned int tag0, double* __restrict__ pose_out,
     clc_summary* __restrict__ summary_out, double* __restrict__ results, int32_t* __restrict__ host_done) {
-  constexpr int NW = COOP_NW, NL = COOP_NL, PR = COOP_PR, PL = COOP_PL, NP = PR + PL;
-  constexpr int CH = 6, NCH = (PL + CH - 1) / CH;
+  constexpr int NW = COOP_NW, NL = COOP_NL, PR = WITH_Z ? COOP_PR_Z : COOP_PR, PL = WITH_Z ? COOP_PL_Z : COOP_PL, NP = PR + PL;
+  constexpr int CH = WITH_Z ? 4 : 6, NCH = (PL + CH - 1) / CH;
   static_assert(NW == 4, "the row tail maps the four 16-lane rows of a wave onto the four point waves");
+  using Moments = typename std::conditional<WITH_Z, RowMoments3, RowMoments>::type;
   __shared__ v2d sh_pts[PL * NL];
+  __shared__ double sh_ptz[WITH_Z ? PL * NL : 1];  // the z of the LDS-held slots (points off the lidar plane)
   __shared__ double sh_state[LM_STATE_WORDS];
   __shared__ __attribute__((aligned(16))) double sh_tot[64];  // two buffers of 32: the totals of the passes alternate (clc_lmuni.hpp)
   __shared__ double sh_red[NW * 7 * 64];  // [wave][register 0..6][lane]: the partials of wave_reduce_to_rows
@@ -350,24 +355,33 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
   const int j_last = ppl > 0 ? ppl - 1 : 0;
   // (the LDS-bound rows only when the chunk has more points per lane than the registers hold — one wave-uniform branch around the
   // whole block, unconditional loads from clamped row indices inside it: at C2, 16 points per lane, there is nothing to load)
+  const double* __restrict__ srcz = WITH_Z ? zl + (size_t)row0 * NL + tid : nullptr;  // (z rows: j-major like the (x, y) rows, 8 bytes per slot)
   v2d lds_v[PL];
+  double lds_z[WITH_Z ? PL : 1];
   const bool use_lds = ppl > PR;
   if (use_lds) {
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
       const int j = PR + i;
       lds_v[i] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+      if (WITH_Z) lds_z[i] = srcz[(size_t)(j < j_last ? j : j_last) * NL];
     }
   }
   v2d reg[PR];
+  double regz[WITH_Z ? PR : 1];
 #pragma unroll
-  for (int j = 0; j < PR; ++j) reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+  for (int j = 0; j < PR; ++j) {
+    reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+    if (WITH_Z) regz[j] = srcz[(size_t)(j < j_last ? j : j_last) * NL];
+  }
   if (use_lds) {
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
       v2d v = lds_v[i];
-      if (PR + i >= ppl) { v[0] = 0.0; v[1] = 0.0; }
+      double vz = WITH_Z ? lds_z[i] : 0.0;
+      if (PR + i >= ppl) { v[0] = 0.0; v[1] = 0.0; vz = 0.0; }
       sh_pts[i * NL + tid] = v;
+      if (WITH_Z) sh_ptz[i * NL + tid] = vz;
     }
   }
   const double* __restrict__ gp = groups + (size_t)dl.gid * GROUP_DOUBLES;
@@ -397,7 +411,8 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
 #ifndef CLC_COOP_PAD_ANALYTIC
 #define CLC_COOP_PAD_ANALYTIC 0
 #endif
-  constexpr bool PAD_ANALYTIC = CLC_COOP_PAD_ANALYTIC != 0;  // (as clc_resident.hpp: the padding's contribution taken out analytically instead of masked slots)
+  constexpr bool PAD_ANALYTIC = CLC_COOP_PAD_ANALYTIC != 0;
+  static_assert(!(PAD_ANALYTIC && WITH_Z), "the analytic padding correction is written for (x, y) slots only");  // (as clc_resident.hpp: the padding's contribution taken out analytically instead of masked slots)
   const int cnt_m = cnt > 0 ? cnt : ppl_eff;
   int cmin = cnt_m;
 #pragma unroll
@@ -410,7 +425,7 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
   COOP_STAMP(COOP_STAMP_PER_PASS * COOP_STAMP_PASSES + 1);
 #pragma unroll
   for (int j = 0; j < PR; ++j)
-    if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; }
+    if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; if (WITH_Z) regz[j] = 0.0; }
 
   for (int k = 0;; ++k) {
     COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass);
@@ -432,17 +447,21 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
       q.c0 = fma(p5[1], pl_nz, fma(p5[0], pl_ny, fma(p4[1], pl_nx, pl_d)));
     }
     v2d buf[2][CH];
+    double bufz[2][WITH_Z ? CH : 1];
     if (ppl > PR) {
 #pragma unroll
       for (int u = 0; u < CH; ++u)
-        if (u < PL) buf[0][u] = sh_pts[u * NL + t];
+        if (u < PL) {
+          buf[0][u] = sh_pts[u * NL + t];
+          if (WITH_Z) bufz[0][u] = sh_ptz[u * NL + t];
+        }
     }
 #ifdef CLC_STAMPS
     asm volatile("" :: "v"(q.mx), "v"(q.c0));
     COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 8);
 #endif
-    RowMoments M;
-    rows_moments_reset<WITH_LOSS>(M);
+    Moments M;
+    lane_moments_reset<WITH_LOSS>(M);
 #pragma unroll
     for (int j0 = 0; j0 < NP; j0 += GRP) {
       if (j0 < ppl) {  // wave-uniform
@@ -453,10 +472,14 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
               const int c1 = (j - PR) / CH + 1;
 #pragma unroll
               for (int u = 0; u < CH; ++u)
-                if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                if (c1 * CH + u < PL) {
+                  buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                  if (WITH_Z) bufz[c1 & 1][u] = sh_ptz[(c1 * CH + u) * NL + t];
+                }
             }
             const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
-            rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);
+            const double vz = !WITH_Z ? 0.0 : (j < PR ? regz[j < PR ? j : 0] : bufz[((j - PR) / CH) & 1][(j - PR) % CH]);
+            lane_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], vz, M, /*renorm=*/j == j0 + GRP - 1);
           }
         } else {
 #pragma unroll
@@ -465,10 +488,14 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
               const int c1 = (j - PR) / CH + 1;
 #pragma unroll
               for (int u = 0; u < CH; ++u)
-                if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                if (c1 * CH + u < PL) {
+                  buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                  if (WITH_Z) bufz[c1 & 1][u] = sh_ptz[(c1 * CH + u) * NL + t];
+                }
             }
             const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
-            rows_point_masked<WITH_LOSS>(q, j < cnt_m, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);
+            const double vz = !WITH_Z ? 0.0 : (j < PR ? regz[j < PR ? j : 0] : bufz[((j - PR) / CH) & 1][(j - PR) % CH]);
+            lane_point_masked<WITH_LOSS>(q, j < cnt_m, inv_lf2, v[0], v[1], vz, M, /*renorm=*/j == j0 + GRP - 1);
           }
         }
       }
@@ -494,7 +521,7 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
         M.prod = fma(-cs * c0, c0, M.prod);
       }
     } else {
-      rows_pad_correction<WITH_LOSS>(M, (double)(ppl_eff - cnt_m));
+      lane_pad_correction<WITH_LOSS>(M, (double)(ppl_eff - cnt_m));
     }
 #ifdef CLC_STAMPS
     asm volatile("" :: "v"(M.S0), "v"(M.Tx), "v"(M.prod));
@@ -503,7 +530,7 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-    rows_flush<WITH_LOSS>(q, M, acc);
+    lane_flush<WITH_LOSS>(q, M, acc);
     if (PAD_ANALYTIC && WITH_LOSS) acc[27] = fma(-q.s2, lp, acc[27]);
 #ifdef CLC_STAMPS
     asm volatile("" :: "v"(acc[0]), "v"(acc[20]), "v"(acc[27]));

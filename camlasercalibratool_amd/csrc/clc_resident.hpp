@@ -97,7 +97,7 @@ template <int NL>
 __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict__ aos, const long long* __restrict__ rec_off,
                                                        const unsigned int* __restrict__ gid, const long long* __restrict__ starts,
                                                        long long n, long long n_groups, const unsigned int* __restrict__ res_row,
-                                                       ResLane* __restrict__ desc, double* __restrict__ xyl) {
+                                                       ResLane* __restrict__ desc, double* __restrict__ xyl, double* __restrict__ zl = nullptr) {
   __shared__ int lane_first[NL + 1];
   const long long p = blockIdx.x;
   const int t = threadIdx.x;
@@ -152,6 +152,10 @@ __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict_
       v = rec[2];  // p.x, p.y
     }
     out[(size_t)j * NL] = v;
+  }
+  if (zl != nullptr) {  // points off the lidar plane: their z in a j-major array of its own, 8 bytes per slot (clc_coop.hpp, WITH_Z)
+    double* outz = zl + (size_t)row0 * NL + t;
+    for (int j = 0; j < ppl; ++j) outz[(size_t)j * NL] = j < dl.cnt ? aos[8 * (k0 + j) + 6] : 0.0;
   }
 }
 

@@ -374,4 +374,59 @@ CLC_HD void rows3_flush(const RowPlane& q, const RowMoments3& M, double* acc) {
     acc[27] = fma(s2, M.prod, acc[27]);
 }
 
+// The same for a slot of the on-chip lane layout that may be padding (see rows_point_masked).
+template <bool WITH_LOSS>
+CLC_HD void rows3_point_masked(const RowPlane& q, const bool valid, const double inv_lf2, const double x, const double y, const double z,
+                               RowMoments3& M, const bool renorm = true) {
+  const double r1 = fma(q.mz, z, fma(q.my, y, fma(q.mx, x, q.c0)));
+  const double r0 = valid ? r1 : 0.0;
+  double w = 1.0;
+  if (WITH_LOSS) {
+    const double sum = fma(r0 * r0, inv_lf2, 1.0);
+    w = rcp_ge1_weight(sum);
+    const double pr = M.prod * sum;
+    if (renorm) {
+      int e;
+      M.prod = frexp_pos(pr, e);
+      M.expo += e;
+    } else {
+      M.prod = pr;
+    }
+  } else {
+    M.prod = fma(r0, r0, M.prod);
+  }
+  if (WITH_LOSS) w = valid ? w : 0.0;
+  const double wx = w * x, wy = w * y, wz = w * z, wr = w * r0;
+  M.S0 += w;
+  M.Sx += wx;
+  M.Sy += wy;
+  M.Sz += wz;
+  M.Sxx = fma(wx, x, M.Sxx);
+  M.Sxy = fma(wx, y, M.Sxy);
+  M.Sxz = fma(wx, z, M.Sxz);
+  M.Syy = fma(wy, y, M.Syy);
+  M.Syz = fma(wy, z, M.Syz);
+  M.Szz = fma(wz, z, M.Szz);
+  M.T0 += wr;
+  M.Tx = fma(wr, x, M.Tx);
+  M.Ty = fma(wr, y, M.Ty);
+  M.Tz = fma(wr, z, M.Tz);
+}
+
+// One spelling for both point forms (overloaded on the moment type): what a kernel templated on "the points carry z" calls.
+template <bool L> CLC_HD void lane_moments_reset(RowMoments& M) { rows_moments_reset<L>(M); }
+template <bool L> CLC_HD void lane_moments_reset(RowMoments3& M) { rows3_moments_reset<L>(M); }
+template <bool L> CLC_HD void lane_point(const RowPlane& q, double inv_lf2, double x, double y, double, RowMoments& M, bool renorm) { rows_point<L>(q, inv_lf2, x, y, M, renorm); }
+template <bool L> CLC_HD void lane_point(const RowPlane& q, double inv_lf2, double x, double y, double z, RowMoments3& M, bool renorm) { rows3_point<L>(q, inv_lf2, x, y, z, M, renorm); }
+template <bool L> CLC_HD void lane_point_masked(const RowPlane& q, bool valid, double inv_lf2, double x, double y, double, RowMoments& M, bool renorm) {
+  rows_point_masked<L>(q, valid, inv_lf2, x, y, M, renorm);
+}
+template <bool L> CLC_HD void lane_point_masked(const RowPlane& q, bool valid, double inv_lf2, double x, double y, double z, RowMoments3& M, bool renorm) {
+  rows3_point_masked<L>(q, valid, inv_lf2, x, y, z, M, renorm);
+}
+template <bool L> CLC_HD void lane_pad_correction(RowMoments& M, double n_padded_slots) { rows_pad_correction<L>(M, n_padded_slots); }
+template <bool L> CLC_HD void lane_pad_correction(RowMoments3& M, double n_padded_slots) { if (!L) M.S0 -= n_padded_slots; }
+template <bool L> CLC_HD void lane_flush(const RowPlane& q, const RowMoments& M, double* acc) { rows_flush<L>(q, M, acc); }
+template <bool L> CLC_HD void lane_flush(const RowPlane& q, const RowMoments3& M, double* acc) { rows3_flush<L>(q, M, acc); }
+
 }  // namespace clc

@@ -90,8 +90,8 @@ def test_cooperative_solve_is_repeatable_bit_for_bit(sv):
 
 
 def test_cooperative_solve_options_and_limits(sv, oracle_mod):
-    """Solver options reach the in-kernel controller; flag 4096 at upload, p.z != 0, or a size outside (11 264, 2 097 152] leave
-    the problem to the other paths; profile_events = 1 asks for per-pass events and gets the launch pair, 2 times the one launch."""
+    """Solver options reach the in-kernel controller; flag 4096 at upload or a problem one workgroup holds leave
+    the problem to the other paths (p.z != 0: the kernel's 24-byte-slot form); profile_events = 1 asks for per-pass events and gets the launch pair, 2 times the one launch."""
     rec = clc.flatten_observations(sd.sim_fixed_count(11, 100, 500, noise_sigma=0.01), False)
     sv.set_launch(0, -1)
     sv.upload(rec)
@@ -116,9 +116,9 @@ def test_cooperative_solve_options_and_limits(sv, oracle_mod):
     r = sv.solve(X0, o)
     assert sv.debug_coop()[2] == n0 + 1 and r.summary.eval_kernel_launches == 1 and 0 < r.summary.eval_kernel_ms < r.summary.solve_ms + 1.0
     recz = rec.copy()
-    recz[7, 6] = 1e-3
+    recz[7, 6] = 1e-3  # one point off the lidar plane: the 24-byte-slot form of the kernel (tests/test_gpu_rows_z.py)
     sv.upload(recz)
-    assert not sv.debug_coop()[0]
+    assert sv.debug_coop()[0] and sv.path_info().coop_points_carry_z == 1
     sv.set_launch(0, STEP_CHAIN | 4096)
     sv.upload(rec)
     assert not sv.debug_coop()[0]

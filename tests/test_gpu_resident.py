@@ -247,7 +247,7 @@ def test_single_problem_resident_solve(sv, oracle_mod, seed, noise):
 
 def test_single_problem_resident_options_and_limits(sv, oracle_mod):
     """Solver options reach the in-kernel controller (no loss, iteration cap); a problem beyond 512 x 22 points, or with
-    p.z != 0, keeps the step chain; profile_events = 1 asks for per-pass events and gets the launch pair."""
+    p.z != 0, is not held by one workgroup (the cooperative kernel takes it); profile_events = 1 asks for per-pass events and gets the launch pair."""
     S = sd.sim_fixed_count(5, 20, 500, noise_sigma=0.01)  # 10 000 points: fits
     rec = clc.flatten_observations(S, False)
     sv.set_launch(0, -1)

@@ -1,4 +1,5 @@
-"""GPU tests of the row layout for scan points OFF the lidar plane (p.z != 0).
+"""GPU tests of scan points OFF the lidar plane (p.z != 0): the row layout that carries z (streaming paths) and the 24-byte-slot form of
+the cooperative on-chip kernel (csrc/clc_coop.hpp, WITH_Z — the default for a single problem of up to 65 536 lanes x 26 points).
 
 Oberserve::points is std::vector<Eigen::Vector3d> (include/LaseCamCalCeres.h:22); the reference's own scan conversion writes
 z = 0 (src/utilities.cpp:198-215), a caller of the Vector3d interface need not.  Such arrays keep the row layout with a
@@ -93,7 +94,7 @@ def test_rows_with_z_differ_from_the_flat_answer(sv, oracle_mod):
 
 @pytest.mark.parametrize("use_loss", [1, 0])
 def test_solve_on_rows_with_z(sv, oracle_mod, use_loss):
-    """clc_solve as the step chain on rows that carry z (forced below 2e5 observations, the default above)."""
+    """clc_solve as the step chain on rows that carry z (forced), and with the default flags (-1: the cooperative kernel's z form)."""
     S = sd.sim_fixed_count(6, 60, 500, noise_sigma=0.01)
     rec = _off_plane(clc.flatten_observations(S, False), 4, sigma=0.02)
     o, oo = clc.default_options(), oracle_mod.default_options()
@@ -113,7 +114,7 @@ def test_solve_on_rows_with_z(sv, oracle_mod, use_loss):
 
 
 def test_solve_default_path_beyond_2e5_observations_with_z(sv, oracle_mod):
-    """2.5e5 observations with z: the default flags stream the rows (24 B per point) through the step chain."""
+    """2.5e5 observations with z: rows that carry z are built (the streaming paths' layout) and the default solve runs on chip."""
     S = sd.sim_fixed_count(7, 500, 500, noise_sigma=0.01)
     rec = _off_plane(clc.flatten_observations(S, False), 5, sigma=0.01)
     sv.set_launch(0, -1)
@@ -169,3 +170,68 @@ def test_batched_problems_with_z(sv, oracle_mod):
     rec0, off0, x00, _ = sd.sim_shard_records(32, 0, P, 12, 97, 0.01)
     sv.upload_batched(rec0, off0)
     assert not sv.rows_carry_z()[1] and sv.debug_resident()[0]
+
+
+def _on_chip(sv):
+    pi = sv.path_info()
+    return pi.coop_resident == 1 and pi.coop_points_carry_z == 1 and pi.single_resident == 0
+
+
+@pytest.mark.parametrize("use_loss", [1, 0])
+def test_cooperative_kernel_holds_points_with_z(sv, oracle_mod, use_loss):
+    """The default clc_solve of a single problem whose points carry z: ONE launch of coop_solve_kernel<loss, nt, WITH_Z> (10 points
+    per lane in registers + 16 in LDS, 24 bytes per slot) — C1 size (which without z one workgroup would hold), ragged scans,
+    chunks that cut scans, z in every point and in one point only.  Same termination and iteration count as the oracle's DENSE_QR solve
+    and as the step chain on the rows that carry z, T_cl / cost within the gates, bit-repeatable."""
+    cases = [("C1 size", _off_plane(clc.flatten_observations(sd.GenerateSimData(2, noise_sigma=0.01), False), 1, sigma=0.03)),
+             ("ragged scans", _off_plane(clc.flatten_observations(sd.GenerateSimData(4, n_poses=400, noise_sigma=0.02), False), 2, sigma=0.02, every=3)),
+             ("24 scans x 5000: chunks cut scans", _off_plane(clc.flatten_observations(sd.sim_fixed_count(5, 24, 5000, noise_sigma=0.01), False), 3)),
+             ("one point off the plane", clc.flatten_observations(sd.sim_fixed_count(7, 300, 400, noise_sigma=0.01), False))]
+    cases[3][1][12345, 6] = 0.2
+    o, oo = clc.default_options(), oracle_mod.default_options()
+    o.use_loss = oo.use_loss = use_loss
+    sv.set_launch(0, -1)
+    for label, rec in cases:
+        sv.upload(rec)
+        assert _on_chip(sv), label
+        n0 = sv.path_info().coop_solves
+        r = sv.solve(X0, o)
+        assert sv.path_info().coop_solves == n0 + 1 and sv.path_info().coop_timeouts == 0, label
+        ref = oracle_mod.solve(rec, X0, options=oo, linear_solver="qr")
+        assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations, label
+        assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL, label
+        assert len(r.trace) == len(ref.trace)
+        r2 = sv.solve(X0, o)
+        assert np.array_equal(r.pose, r2.pose) and r.summary.final_cost == r2.summary.final_cost, label
+        sv.set_launch(0, BASE)  # the step chain on the rows that carry z: another summation order, the same decisions
+        c = sv.solve(X0, o)
+        sv.set_launch(0, -1)
+        assert (c.summary.termination, c.summary.num_iterations, c.summary.num_evaluations) == (r.summary.termination, r.summary.num_iterations, r.summary.num_evaluations), label
+        assert np.abs(c.pose - r.pose).max() <= 1e-9, label
+
+
+def test_cooperative_kernel_z_capacity_edge(sv, oracle_mod):
+    """65 536 lanes x 26 points with z is the last problem the kernel holds (scans of 13 full lanes); one observation more keeps the
+    step chain on the rows that carry z.  Both agree with the oracle."""
+    ppl = 26
+    K = 16 * ppl      # 416 points per scan = 16 full lanes; a workgroup's chunk = 16 scans = 256 lanes
+    n_scans = 256 * 16
+    S = sd.sim_fixed_count(21, n_scans + 1, K, noise_sigma=0.01)
+    full = _off_plane(clc.flatten_observations(S, False), 9, sigma=0.02)
+    rec = np.ascontiguousarray(full[: n_scans * K])
+    assert rec.shape[0] == 256 * 256 * ppl
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    assert _on_chip(sv) and sv.path_info().coop_points_per_lane == ppl
+    x0 = sv.pose_plus(sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))[None, :], np.array([[0.02, -0.01, 0.02, 0.01, -0.02, 0.01]]))[0]
+    r = sv.solve(x0, trace_cap=0)
+    ref = oracle_mod.solve(rec, x0, linear_solver="qr", threads=oracle_mod.max_threads())
+    assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations
+    assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    # one observation more needs a 27th slot in some lane: not held — the step chain on the rows that carry z
+    more = np.ascontiguousarray(full[: n_scans * K + 1])
+    sv.upload(more)
+    assert sv.path_info().coop_resident == 0 and sv.rows_carry_z()[0]
+    r = sv.solve(x0, trace_cap=0)
+    ref = oracle_mod.solve(more, x0, linear_solver="qr", threads=oracle_mod.max_threads())
+    assert r.summary.num_iterations == ref.summary.num_iterations and _dT(r.pose, ref.pose) <= T_TOL

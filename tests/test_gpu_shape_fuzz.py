@@ -6,6 +6,8 @@ shapes sit on the edges of the on-chip paths' capacity logic —
   * the cooperative kernel (csrc/clc_coop.hpp) takes over at 11 265 — or earlier, when the scans' lengths leave too many half-filled
     lanes or there are more than 512 scans — and holds 65 536 lanes x 40 points: 16 / 17 points per
     lane (the register part / the first LDS slot) and 40 / 41 (the last problem it holds / the first one the step chain keeps);
+  * about one problem in seven has points off the lidar plane (p.z != 0): never one workgroup's layout, always the cooperative kernel's
+    24-byte-slot form;
   * scans: one scan only, 511 / 512 / 513 scans (a scan per lane of the single workgroup, +- 1), scans of 1-3 points, scans
     longer than a lane's chunk (chunks cut scans), ragged mixtures.
 
@@ -132,9 +134,15 @@ def test_shape_fuzz_200_single_problems_around_the_capacity_edges(sv, oracle_mod
     paths = {"single": 0, "coop": 0, "chain": 0}
     shapes = _shapes(rng)
     assert len(shapes) == 196
+    n_z = 0
     for label, lens in shapes:
         rec = pool.take(lens, rng)
         n = rec.shape[0]
+        with_z = bool(rng.random() < 0.15)  # points off the lidar plane: never one workgroup's layout, the cooperative kernel's z form
+        if with_z:
+            idx = np.arange(0, n, int(rng.integers(1, 4)))
+            rec[idx, 6] = rng.normal(size=idx.shape[0]) * 0.02
+            n_z += 1
         x0 = sv.pose_plus(pool.gt[None, :], rng.normal(size=(1, 6)) * (0.03 if len(lens) > 2 else 0.005))[0]
         _, _, solves0, aborts0, off = sv.debug_coop()
         assert not off
@@ -145,8 +153,8 @@ def test_shape_fuzz_200_single_problems_around_the_capacity_edges(sv, oracle_mod
         # exactly one of the two on-chip layouts exists: the single workgroup's when the problem fits it (a lane holds points of ONE
         # scan: n <= 11 264 is necessary, not sufficient), the cooperative kernel's otherwise — never the step chain at these sizes
         assert single_ok != built, (label, n)
-        if n > SINGLE_CAP or len(lens) > 512:
-            assert built, (label, n)
+        if n > SINGLE_CAP or len(lens) > 512 or with_z:
+            assert built and sv.path_info().coop_points_carry_z == int(with_z), (label, n)
         if single_ok:
             assert solves1 == solves0, (label, n)
             paths["single"] += 1
@@ -176,6 +184,7 @@ def test_shape_fuzz_200_single_problems_around_the_capacity_edges(sv, oracle_mod
             assert built and ppl_built == ppl + dn and solves1 == solves0 + 1, (ppl, dn, built, ppl_built)
             paths["coop"] += 1
     dt = time.perf_counter() - t0
-    print(f"shape fuzz: {paths}, {dt:.1f} s")
-    assert paths["single"] >= 80 and paths["coop"] >= 40 and paths["chain"] == 1
+    print(f"shape fuzz: {paths}, {n_z} with z, {dt:.1f} s")
+    assert n_z >= 15
+    assert paths["single"] >= 60 and paths["coop"] >= 40 and paths["chain"] == 1
     assert dt < 60.0, dt
