@@ -270,10 +270,11 @@ int clc_eval(clc_handle* h, const double pose[7], int with_loss, double loss_sca
  * on the uploaded observations, SE(3) local parameterisation, Cauchy loss; runs entirely
  * on the device.  pose is in/out = [tx,ty,tz,qx,qy,qz,qw] (:219, :311-314).
  * trace (nullable) receives up to trace_cap iteration records.
- * With the library's default launch flags the whole solve is ONE launch when the problem fits on chip
- * (p.z == 0): up to 11 264 observations in one workgroup, up to ~2.6e6 across 256 co-resident workgroups
- * (csrc/clc_coop.hpp; needs a 256-CU device, falls back by itself otherwise or when its exchange times
- * out); beyond that — or with explicit clc_set_launch flags — one launch per LM iteration.  Same LM
+ * With the library's default launch flags the whole solve is ONE launch when the problem fits on chip:
+ * up to 11 264 observations in one workgroup (all p.z == 0, every lane's points from one scan), up to ~2.6e6
+ * across 256 co-resident workgroups (~1.7e6 when some p.z != 0: 24-byte slots) (csrc/clc_coop.hpp; needs a
+ * 256-CU device, falls back by itself otherwise or when its exchange times out — see clc_set_auto_paths);
+ * beyond that — or with explicit clc_set_launch flags — one launch per LM iteration.  Same LM
  * decisions on every path; sums are taken in different orders (results agree to rounding). */
 int clc_solve(clc_handle* h, const clc_options* opt, double pose[7], clc_summary* summary,
               clc_iteration* trace, int trace_cap);
