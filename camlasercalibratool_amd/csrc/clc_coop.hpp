@@ -45,6 +45,16 @@
 namespace clc {
 
 constexpr int COOP_WGS = 256, COOP_GROUPS = 8, COOP_PER_GROUP = COOP_WGS / COOP_GROUPS, COOP_ROW_WORDS = 64;
+// Row strides of the two boards in 8-byte words (>= COOP_ROW_WORDS: a row is 28 elements x 16 bytes = 448 bytes).  Everybody polls the
+// 8 group rows at once; whether rows 512 bytes apart queue behind each other in one memory channel was measured with 1 KB and 4 KB
+// strides (group rows alone, and both boards): no difference (C2 kernel 82.5-83.9 us each way) — the hops are latency, not a hot spot.
+#ifndef CLC_COOP_A_STRIDE
+#define CLC_COOP_A_STRIDE 64
+#endif
+#ifndef CLC_COOP_B_STRIDE
+#define CLC_COOP_B_STRIDE 64
+#endif
+constexpr int COOP_A_STRIDE = CLC_COOP_A_STRIDE, COOP_B_STRIDE = CLC_COOP_B_STRIDE;
 // Four waves per workgroup = ONE wave per SIMD: a pass is ~400 instructions per wave of which only 22 per point, so half the
 // lanes with twice the points each issue ~30 % fewer instructions per SIMD than two waves per SIMD; the LDS part (98 KB) also
 // keeps a second workgroup off the CU.  Points per lane in registers + in LDS.
@@ -76,8 +86,8 @@ constexpr int COOP_DONE_OK = 1, COOP_DONE_ABORT = 2;
 constexpr int COOP_REPLICAS = CLC_COOP_REPLICAS;
 constexpr unsigned long long COOP_ABORT_CHECK_TICKS = 2000ull;  // a waiting workgroup starts reading the abort word after 20 us
 struct CoopBoard {
-  unsigned long long a[2][COOP_WGS][COOP_ROW_WORDS];                    // [pass parity][workgroup][2 x 28 words, padded]
-  unsigned long long b[2][COOP_REPLICAS][COOP_GROUPS][COOP_ROW_WORDS];  // [pass parity][copy][group]
+  unsigned long long a[2][COOP_WGS][COOP_A_STRIDE];                    // [pass parity][workgroup][2 x 28 words, padded]
+  unsigned long long b[2][COOP_REPLICAS][COOP_GROUPS][COOP_B_STRIDE];  // [pass parity][copy][group]
   unsigned long long ctl[8];  // [0]: tag0 of a launch that aborted (read by workgroups that have waited 20 us); [1], [2]: tuning hook
 };
 
@@ -103,10 +113,10 @@ __device__ __forceinline__ v4u coop_get(__amdgpu_buffer_rsrc_t rs, const unsigne
 __device__ __forceinline__ bool coop_valid(const v4u w, const unsigned int tag) { return w[0] == tag && w[2] == tag; }
 __device__ __forceinline__ double coop_value(const v4u w) { return __hiloint2double((int)w[1], (int)w[3]); }
 __device__ __forceinline__ unsigned int coop_row_a(const int par, const int wg) {
-  return (unsigned int)(offsetof(CoopBoard, a) + ((size_t)(par * COOP_WGS + wg) * COOP_ROW_WORDS) * 8);
+  return (unsigned int)(offsetof(CoopBoard, a) + ((size_t)(par * COOP_WGS + wg) * COOP_A_STRIDE) * 8);
 }
 __device__ __forceinline__ unsigned int coop_row_b(const int par, const int copy, const int grp) {
-  return (unsigned int)(offsetof(CoopBoard, b) + ((size_t)((par * COOP_REPLICAS + copy) * COOP_GROUPS + grp) * COOP_ROW_WORDS) * 8);
+  return (unsigned int)(offsetof(CoopBoard, b) + ((size_t)((par * COOP_REPLICAS + copy) * COOP_GROUPS + grp) * COOP_B_STRIDE) * 8);
 }
 // sleep (no issue slots, no memory traffic) until the shader clock reaches t
 __device__ __forceinline__ void coop_wait_until(const long long t) {
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
           unsigned int bo = base;
           asm volatile("" : "+v"(bo));  // (a fresh sample every iteration)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) w[i] = coop_get(rs, bo + (unsigned int)(COOP_GROUPS * i * COOP_ROW_WORDS * 8));
+          for (int i = 0; i < 16; ++i) w[i] = coop_get(rs, bo + (unsigned int)(COOP_GROUPS * i * COOP_A_STRIDE * 8));
 #pragma unroll
           for (int i = 0; i < 16; ++i) ok = ok && coop_valid(w[i], tag);
           if (__all(ok)) break;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
           unsigned int bo = base;
           asm volatile("" : "+v"(bo));  // (a fresh sample every iteration)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) w[i] = coop_get(rs, bo + (unsigned int)(i * COOP_ROW_WORDS * 8));
+          for (int i = 0; i < 4; ++i) w[i] = coop_get(rs, bo + (unsigned int)(i * COOP_B_STRIDE * 8));
           if (pre_due) {  // (wave-uniform; the loads above stay in flight: nothing below touches their registers)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
