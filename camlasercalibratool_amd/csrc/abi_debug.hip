@@ -70,6 +70,23 @@ int clc_debug_wave_reduce(clc_handle* h, const double* in, double* out, int redu
   return CLC_OK;
 }
 
+// op 0 rsqrt_pos, 1 rcp_pos, 2 rcp_pos_safe, 3 sqrt_pos, 4 rcp_ge1, 5 rcp_ge1_weight, 6 log via frexp_pos + log_mant_exp: out[i] = f(in[i])
+// computed on the device.
+int clc_debug_math(clc_handle* h, int op, const double* in, double* out, long long n) {
+  if (!h || !in || !out || n < 0 || op < 0 || op > 6) return fail(CLC_ERR_INVALID_ARG, "clc_debug_math: bad argument");
+  if (n == 0) return CLC_OK;
+  CLC_HIP(hipSetDevice(h->device));
+  DevBuf<double> bi(&h->pool), bo(&h->pool);
+  CLC_HIP(bi.alloc((size_t)n));
+  CLC_HIP(bo.alloc((size_t)n));
+  CLC_HIP(hipMemcpy(bi.p, in, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(clc::math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, op, bi.p, bo.p, n);
+  CLC_HIP(hipGetLastError());
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  CLC_HIP(hipMemcpy(out, bo.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return CLC_OK;
+}
+
 // Per-workgroup timeline of one compact-layout evaluation launch: stamps[grid*8] =
 // {wall_start, wall_end (10 ns ticks), cycles prologue, loop, epilogue, 0, 0, 0}; returns grid.
 int clc_debug_eval_timeline(clc_handle* h, const double pose[7], double lf, long long* stamps, int cap_waves,

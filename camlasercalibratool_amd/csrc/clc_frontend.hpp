@@ -56,6 +56,28 @@ static __global__ void plus_kernel(const double* __restrict__ x, const double* _
   for (int i = 0; i < 7; ++i) out[7 * k + i] = o[i];
 }
 
+// Debug/test entry: the DEVICE branches of the scalar helpers (clc_math.hpp, clc_rows.hpp: v_rcp / v_rsq seeds + Newton steps,
+// frexp + the polynomial logarithm), element-wise on caller-provided values — the host unit shims compile their plain-expression
+// branches, so only a kernel can pin these (tests/test_gpu_device_math.py).
+static __global__ void math_probe_kernel(const int op, const double* __restrict__ in, double* __restrict__ out, const long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = in[i];
+  double y = 0.0;
+  if (op == 0) y = rsqrt_pos(x);
+  else if (op == 1) y = rcp_pos(x);
+  else if (op == 2) y = rcp_pos_safe(x);
+  else if (op == 3) y = sqrt_pos(x);
+  else if (op == 4) y = rcp_ge1(x);
+  else if (op == 5) y = rcp_ge1_weight(x);
+  else if (op == 6) {
+    int e;
+    const double m = frexp_pos(x, e);
+    y = log_mant_exp(m, e);
+  }
+  out[i] = y;
+}
+
 // Debug/test entry: run only the wave reduction on caller-provided lane values
 // in[64][28] -> out[28].
 static __global__ void wave_reduce_test_kernel(const double* __restrict__ in, double* __restrict__ out,

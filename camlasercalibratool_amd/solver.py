@@ -334,6 +334,16 @@ class Solver:
         return pts
 
     # ---- test / profiling hooks ----
+    def debug_math(self, op: int, x: np.ndarray) -> np.ndarray:
+        """Device branch of a scalar helper, element-wise (hooks build): 0 rsqrt_pos, 1 rcp_pos, 2 rcp_pos_safe, 3 sqrt_pos, 4 rcp_ge1,
+        5 rcp_ge1_weight, 6 log via frexp_pos + log_mant_exp."""
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        out = np.empty_like(x)
+        f = self._hook("clc_debug_math")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong]
+        check(f(self._h, op, x.ctypes.data, out.ctypes.data, x.shape[0]), "clc_debug_math")
+        return out
+
     def debug_wave_reduce(self, lanes: np.ndarray, reduce_mode: int) -> np.ndarray:
         lanes = np.ascontiguousarray(lanes, dtype=np.float64).reshape(64, 28)
         out = np.empty(28)
