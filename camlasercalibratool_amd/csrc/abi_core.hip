@@ -162,7 +162,7 @@ int clc_create(clc_handle** out, int device) {
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = std::getenv("CLC_AUTO_PATHS_DISABLE")) {
     const int m = std::atoi(e);
-    if (m >= 0 && m <= 7) h->auto_disable = m;
+    if (m >= 0 && m <= 15) h->auto_disable = m;
   }
   CLC_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
@@ -252,7 +252,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_auto_paths(clc_handle* h, int disable_mask) {
-  if (!h || disable_mask < 0 || disable_mask > 7) return fail(CLC_ERR_INVALID_ARG, "clc_set_auto_paths: bad argument");
+  if (!h || disable_mask < 0 || disable_mask > 15) return fail(CLC_ERR_INVALID_ARG, "clc_set_auto_paths: bad argument");
   h->auto_disable = disable_mask;
   return CLC_OK;
 }
@@ -266,6 +266,7 @@ int clc_get_path_info(const clc_handle* h, clc_path_info* out) {
   out->coop_resident = h->cres.ok ? 1 : 0;
   out->coop_points_per_lane = h->cres.ok ? h->cres.max_ppl : 0;
   out->coop_points_carry_z = h->cres.ok && h->cres.with_z ? 1 : 0;
+  out->coop_workgroups = h->cres.ok ? h->cres.wgs : 0;
   out->coop_resting = h->coop_eligible < h->coop_retry_at ? 1 : 0;
   out->coop_timeouts = h->coop_aborts;
   out->batched_resident = h->bres.ok ? 1 : 0;

@@ -250,16 +250,24 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
     T.coop->ok = false;
     // (records with p.z != 0: the cooperative kernel's WITH_Z form holds 24-byte slots — the only on-chip form that does)
     if (P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && !(T.res != nullptr && T.res->ok)) {
-      // the one problem in COOP_WGS chunks of equal record counts (a chunk may begin and end inside a scan: res_scan_extent)
-      std::vector<long long> chunk(clc::COOP_WGS + 1);
-      for (int c = 0; c <= clc::COOP_WGS; ++c) chunk[c] = (long long)((__int128)n * c / clc::COOP_WGS);
-      DevBuf<long long> bchunk(&h->pool);
-      CLC_HIP(bchunk.alloc(chunk.size()));
-      CLC_HIP(hipMemcpyAsync(bchunk.p, chunk.data(), chunk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
-      CLC_HIP(hipStreamSynchronize(h->stream));
-      rc = build_resident(h, *T.coop, clc::COOP_NL, d_aos, n, (size_t)clc::COOP_WGS, G, bchunk.p, bgid.p, bstarts.p,
-                          any_z ? clc::COOP_PR_Z + clc::COOP_PL_Z : clc::COOP_PR + clc::COOP_PL, any_z != 0);
-      if (rc != CLC_OK) return rc;
+      // the one problem in chunks of equal record counts, one per workgroup (a chunk may begin and end inside a scan: res_scan_extent):
+      // COOP_WGS of them, or COOP_SMALL_WGS where that leaves a lane at most COOP_SMALL_MAX_PPL points (the one-hop form of the kernel)
+      const int cap_ppl = any_z ? clc::COOP_PR_Z + clc::COOP_PL_Z : clc::COOP_PR + clc::COOP_PL;
+      const int small_ppl = std::min(clc::COOP_SMALL_MAX_PPL, cap_ppl);
+      const bool small_ok = !any_z && n <= (long long)clc::COOP_SMALL_WGS * clc::COOP_NL * small_ppl && (h->auto_disable & 8) == 0;
+      for (int attempt = small_ok ? 0 : 1; attempt < 2 && !T.coop->ok; ++attempt) {
+        const int wgs = attempt == 0 ? clc::COOP_SMALL_WGS : clc::COOP_WGS;
+        std::vector<long long> chunk((size_t)wgs + 1);
+        for (int c = 0; c <= wgs; ++c) chunk[c] = (long long)((__int128)n * c / wgs);
+        DevBuf<long long> bchunk(&h->pool);
+        CLC_HIP(bchunk.alloc(chunk.size()));
+        CLC_HIP(hipMemcpyAsync(bchunk.p, chunk.data(), chunk.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+        CLC_HIP(hipStreamSynchronize(h->stream));
+        rc = build_resident(h, *T.coop, clc::COOP_NL, d_aos, n, (size_t)wgs, G, bchunk.p, bgid.p, bstarts.p,
+                            attempt == 0 ? small_ppl : cap_ppl, any_z != 0);
+        if (rc != CLC_OK) return rc;
+        T.coop->wgs = wgs;
+      }  // (the small form's layout did not fit — scans that leave half-filled lanes: the 256-workgroup form is tried next)
     }
   }
   CLC_HIP(hipStreamSynchronize(h->stream));  // the temporaries above are freed on return

@@ -420,14 +420,17 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
   const int d_cap = want_trace ? h->trace_cap : 0;
   const unsigned int tag0 = h->coop_tag;
   h->coop_tag += passes;
-  const unsigned int wgs = (unsigned int)(clc::COOP_WGS - h->coop_test_drop);
+  const int n_wgs = h->cres.wgs > 0 ? h->cres.wgs : clc::COOP_WGS;  // COOP_WGS, or COOP_SMALL_WGS: the one-hop form
+  const unsigned int wgs = (unsigned int)std::max(1, n_wgs - h->coop_test_drop);
   h->coop_test_drop = 0;
   if (timed) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
-#define CLC_LAUNCH_COOP(LOSS, Z)                                                                                                              \
-  hipLaunchKernelGGL((clc::coop_solve_kernel<LOSS, false, Z>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, h->cres.d_z, d_row, \
-                     d_desc, h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done)
-  if (h->cres.with_z) { if (opt.use_loss) CLC_LAUNCH_COOP(true, true); else CLC_LAUNCH_COOP(false, true); }  // 24-byte slots: p.z != 0
-  else { if (opt.use_loss) CLC_LAUNCH_COOP(true, false); else CLC_LAUNCH_COOP(false, false); }
+#define CLC_LAUNCH_COOP(LOSS, Z, ONE)                                                                                                         \
+  hipLaunchKernelGGL((clc::coop_solve_kernel<LOSS, false, Z, ONE>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, h->cres.d_z, d_row, \
+                     d_desc, h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done, \
+                     n_wgs)
+  if (h->cres.with_z) { if (opt.use_loss) CLC_LAUNCH_COOP(true, true, false); else CLC_LAUNCH_COOP(false, true, false); }  // 24-byte slots: p.z != 0
+  else if (n_wgs == clc::COOP_SMALL_WGS) { if (opt.use_loss) CLC_LAUNCH_COOP(true, false, true); else CLC_LAUNCH_COOP(false, false, true); }  // one hop
+  else { if (opt.use_loss) CLC_LAUNCH_COOP(true, false, false); else CLC_LAUNCH_COOP(false, false, false); }
 #undef CLC_LAUNCH_COOP
   CLC_HIP(hipGetLastError());
   if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));

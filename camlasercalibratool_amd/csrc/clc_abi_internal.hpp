@@ -116,6 +116,7 @@ struct ResLayout {
   double* d_z = nullptr;     // with_z: the slots' z, j-major like d_xy, 8 bytes per slot
   size_t z_cap = 0;
   bool with_z = false;       // some record has p.z != 0 (cooperative layout only)
+  int wgs = 0;               // cooperative layout only: the workgroups the problem is dealt to (COOP_WGS, or COOP_SMALL_WGS: one-hop form)
   int lanes = 0;             // lanes per problem of the built layout (256 / 512)
   int max_ppl = 0;           // largest points-per-lane over the problems
   int uni_ppl = -1;          // >= 0: every problem has this many points per lane

@@ -45,6 +45,9 @@
 namespace clc {
 
 constexpr int COOP_WGS = 256, COOP_GROUPS = 8, COOP_PER_GROUP = COOP_WGS / COOP_GROUPS, COOP_ROW_WORDS = 64;
+// The small form: problems of at most COOP_SMALL_MAX_PPL points per lane of 32 workgroups run on 32 workgroups with a ONE-hop exchange
+// (every workgroup reads all 32 rows): a pass of ~4-5 us instead of ~5.8 where the 256-workgroup form has 1-2 points per lane.
+constexpr int COOP_SMALL_WGS = 32, COOP_SMALL_MAX_PPL = 10;
 // Row strides of the two boards in 8-byte words (>= COOP_ROW_WORDS: a row is 28 elements x 16 bytes = 448 bytes).  Everybody polls the
 // 8 group rows at once; whether rows 512 bytes apart queue behind each other in one memory channel was measured with 1 KB and 4 KB
 // strides (group rows alone, and both boards): no difference (C2 kernel 82.5-83.9 us each way) — the hops are latency, not a hot spot.
@@ -157,12 +160,12 @@ __device__ __forceinline__ void wave_reduce_to_rows(double (&acc)[NACC], double 
   }
 }
 
-template <bool WITH_LOSS, bool NT, bool WITH_Z = false>
+template <bool WITH_LOSS, bool NT, bool WITH_Z = false, bool ONE_HOP = false>
 __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     const double* __restrict__ xyl, const double* __restrict__ zl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, const Pose7 pose0, clc_iteration* __restrict__ trace,
     const int trace_cap, CoopBoard* __restrict__ board, const unsigned int tag0, double* __restrict__ pose_out,
-    clc_summary* __restrict__ summary_out, double* __restrict__ results, int32_t* __restrict__ host_done) {
+    clc_summary* __restrict__ summary_out, double* __restrict__ results, int32_t* __restrict__ host_done, const int n_wgs) {
   constexpr int NW = COOP_NW, NL = COOP_NL, PR = WITH_Z ? COOP_PR_Z : COOP_PR, PL = WITH_Z ? COOP_PL_Z : COOP_PL, NP = PR + PL;
   constexpr int CH = WITH_Z ? 4 : 6, NCH = (PL + CH - 1) / CH;
   static_assert(NW == 4, "the row tail maps the four 16-lane rows of a wave onto the four point waves");
@@ -186,8 +189,13 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     // partials are in LDS] -> (leaders: gather the group's rows, publish the group row) -> lmu_pre while the rows travel -> the 8
     // group rows -> totals -> lmu_post -> [barrier B: pose + status published].
     // =====================================================================================================================
-    const int grp = wg % COOP_GROUPS;            // the XCD the dispatcher places this workgroup on (round-robin)
-    const bool leader = wg < COOP_GROUPS;
+    // ONE_HOP = false: COOP_WGS workgroups, two hops (8 groups of 32).  ONE_HOP = true: COOP_SMALL_WGS (32) workgroups — the problem is
+    // small enough for them —, every one of them gathers all 32 rows itself (what a group leader does) and nobody publishes a group
+    // row.  (A compile-time switch: as a run-time one it cost the 256-workgroup form 4 % at C2.)
+    constexpr bool one_hop = ONE_HOP;
+    constexpr int groups = ONE_HOP ? 1 : COOP_GROUPS;
+    const int grp = ONE_HOP ? 0 : wg % COOP_GROUPS;  // (the XCD the dispatcher places this workgroup on: round-robin)
+    const bool leader = ONE_HOP || wg < COOP_GROUPS;
     clc_iteration* const tr = wg == 0 ? trace : nullptr;
     const int tr_cap = wg == 0 ? trace_cap : 0;
     LmState& st = *reinterpret_cast<LmState*>(sh_state);
@@ -209,7 +217,9 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     // cycles), so the first polls go out at fixed offsets from it (measured flat within 1 % for 500-1 000 / 2 000-4 500 cycles;
     // an adaptive offset taken from the previous pass ran away: a poll that succeeds at once says nothing about how early it could
     // have gone).
-    const long long d1 = board->ctl[1] ? (long long)board->ctl[1] : CLC_COOP_D1, d2 = board->ctl[2] ? (long long)board->ctl[2] : CLC_COOP_D2;
+    // (one-hop form: lmu_pre runs first, ~1 100 cycles; the rows are published ~950 cycles after barrier A and take a hop to become
+    // visible — first look at 1 900, measured 800...2 200: 4.6-4.9 us per pass, the minimum here)
+    const long long d1 = board->ctl[1] ? (long long)board->ctl[1] : (ONE_HOP ? 1900 : CLC_COOP_D1), d2 = board->ctl[2] ? (long long)board->ctl[2] : CLC_COOP_D2;
     for (int k = 0;; ++k) {
       __syncthreads();  // barrier A
       // ---- the 28 totals of pass `k` over all workgroups -> sh_tot[1 - S.hx]; fixed order: group members 0-15 + 16-31, groups
@@ -221,18 +231,26 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
       const unsigned long long limit = k == 0 ? COOP_CENSUS_TICKS : COOP_TIMEOUT_TICKS;
       bool fine = true;
       const long long t_a = clock64();
+      // What does not need the totals (lmu_pre), while the rows travel: a follower has the whole of hop 1 for it (and looks at the group
+      // rows afterwards); in the one-hop form it takes the place of the wait for the rows' publication.  (The leaders of the two-hop
+      // form: behind their first look at the group rows, below.)
+      if (ONE_HOP) {
+        if (k > 0) lmu_pre(S, st, opt, sh_tot, tr, tr_cap, lane);
+        COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 11);
+      }
       if (leader) {
         coop_wait_until(t_a + d1);
         // rows of this group: workgroups grp + 8 m, m = 16 h .. 16 h + 15
         v4u w[16];
-        const unsigned int base = coop_row_a(par, grp + COOP_GROUPS * 16 * h) + 16u * (unsigned int)e;
+        const unsigned int base = coop_row_a(par, grp + groups * 16 * h) + 16u * (unsigned int)e;
+        constexpr unsigned int row_step = (unsigned int)(groups * COOP_A_STRIDE * 8);
         const unsigned long long t0 = wall_clock64();
         for (;;) {
           bool ok = true;
           unsigned int bo = base;
           asm volatile("" : "+v"(bo));  // (a fresh sample every iteration)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) w[i] = coop_get(rs, bo + (unsigned int)(COOP_GROUPS * i * COOP_A_STRIDE * 8));
+          for (int i = 0; i < 16; ++i) w[i] = coop_get(rs, bo + (unsigned int)i * row_step);
 #pragma unroll
           for (int i = 0; i < 16; ++i) ok = ok && coop_valid(w[i], tag);
           if (__all(ok)) break;
@@ -250,19 +268,24 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
         for (int i = 1; i < 16; ++i) s += coop_value(w[i]);
         double s_lo = s, s_hi = s;
         swap_halves(s_lo, s_hi);  // lanes < 32: own half (members 0-15) + the other half's (16-31)
-        if (mine && fine) {
+        if (one_hop) {  // the group IS the problem: these are the totals
+          if (mine) sh_tot[32 * (1 - S.hx) + lane] = s_lo + s_hi;
+        } else if (mine && fine) {
+          int so = lane;
+          asm volatile("" : "+v"(so));  // (the store's lane offset computed HERE: hoisted out of the pass loop it was spilled, and its reload sat in front of the store)
 #pragma unroll
-          for (int r = 0; r < COOP_REPLICAS; ++r) coop_put(rs, coop_row_b(par, (r + grp) % COOP_REPLICAS, grp), lane, s_lo + s_hi, tag);
+          for (int r = 0; r < COOP_REPLICAS; ++r) coop_put(rs, coop_row_b(par, (r + grp) % COOP_REPLICAS, grp), so, s_lo + s_hi, tag);
         }
         COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 4);
       }
-      // What does not need the totals (lmu_pre), while the (group) rows travel.  A follower has the whole of hop 1 for it and looks at
-      // the group rows afterwards; a leader has just published its group row — its first look at the 8 group rows goes out BEFORE its
-      // lmu_pre and is evaluated behind it (lmu_pre is about as long as the hop: issued after it, that poll cost the leaders, and with
-      // them every workgroup's next pass, ~700 cycles).
-      if (k > 0 && !leader) lmu_pre(S, st, opt, sh_tot, tr, tr_cap, lane);
-      if (!leader) COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 11);
-      if (fine) {
+      // A leader of the two-hop form has just published its group row: its first look at the 8 group rows goes out BEFORE its lmu_pre
+      // and is evaluated behind it (lmu_pre is about as long as the hop: issued after it, that poll cost the leaders, and with them
+      // every workgroup's next pass, ~700 cycles).
+      if (!ONE_HOP) {
+        if (k > 0 && !leader) lmu_pre(S, st, opt, sh_tot, tr, tr_cap, lane);
+        if (!leader) COOP_STAMP(COOP_STAMP_PER_PASS * stamp_pass + 11);
+      }
+      if (fine && !one_hop) {
         // the 8 group rows: groups 4 h .. 4 h + 3
         coop_wait_until(t_a + d2);
         const unsigned int base = coop_row_b(par, wg % COOP_REPLICAS, 4 * h) + 16u * (unsigned int)e;

@@ -167,6 +167,8 @@ int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
  * 4 = the single-workgroup solve runs the LM controller of the cooperative kernel (wave-uniform arithmetic, state in registers)
  *     instead of its own (state in LDS) — same arithmetic, bit-identical results, slower there; how the cooperative kernel's
  *     controller is compared with the serial one on identical totals (tests/test_gpu_lmuni.py).
+ * 8 = (at upload) not the 32-workgroup one-hop form of the cooperative solve for problems of at most 81 920 observations
+ *     (every workgroup reads all 32 rows itself: one store-to-load hop per pass instead of two) — the 256-workgroup form then.
  * 0 = library default.  The environment variable CLC_AUTO_PATHS_DISABLE sets the initial mask of every handle. */
 int clc_set_auto_paths(clc_handle* h, int disable_mask);
 
@@ -188,7 +190,7 @@ typedef struct clc_path_info {
   int32_t batched_points_per_lane;
   int32_t rows_layout;             /* single problem's streaming row layout: 0 none, 1 (x, y) rows, 2 rows that carry z */
   int32_t batched_rows_layout;
-  int32_t reserved_;
+  int32_t coop_workgroups;         /* 256, or 32: the one-hop form for problems of at most 32 x 256 x 10 points */
   int64_t coop_solves;             /* solves that ran on the cooperative kernel */
   int64_t batched_lane_rows;       /* point rows of the batched lane layout (x lanes x 16 bytes = its size) */
   int64_t n_rows;                  /* rows of 64 points of the streaming row layouts */
