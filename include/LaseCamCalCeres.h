@@ -218,7 +218,10 @@ namespace clc_adapter {
 //     run.ClosedSolution(Tlc_initial);  Eigen::Matrix4d Tcl = Tlc_initial.inverse();  run.Calibration(Tcl, false);
 class Session {
  public:
-    explicit Session(const std::vector<Oberserve>& obs) : obs_(obs), ok_(false), generation_(-1)
+    // `obs` is read here; it is read AGAIN only if another Session (or one of the free functions) has replaced the stored scans
+    // on the shared context before a later call of this one — keep it alive for as long as the Session (no copy is made: the
+    // reference-size inputs are small, a C2-size one is 53 MB).
+    explicit Session(const std::vector<Oberserve>& obs) : obs_(&obs), ok_(false), generation_(-1)
     {
         Handle H;  // locked first: flatten gathers into the process-wide pinned buffers
         if (!H.h) return;
@@ -316,7 +319,7 @@ class Session {
  private:
     bool store(clc_handle* h)
     {
-        const Flat f = flatten(obs_);
+        const Flat f = flatten(*obs_);
         const int P = (int)(f.pts_off.size() - 1);
         if (clc_store_observations(h, P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts,
                                    f.ptl_off.data(), f.ptl) != CLC_OK) {
@@ -327,14 +330,14 @@ class Session {
         return true;
     }
     // The stored scans belong to the process-wide handle: a later Session (or one of the free functions below, which are
-    // one-call sessions) replaces them.  This Session keeps its observations and stores them again when that happened (as
-    // calib.py's Session does), rather than solve somebody else's.
+    // one-call sessions) replaces them.  This Session then stores its caller's observations again (as calib.py's Session does),
+    // rather than solve somebody else's.
     bool mine(clc_handle* h)
     {
         if (generation_ >= 0 && clc_store_generation(h) == generation_) return true;
         return store(h);
     }
-    const std::vector<Oberserve> obs_;
+    const std::vector<Oberserve>* obs_;  // the caller's observations (not owned)
     bool ok_;
     int64_t generation_;
 };
