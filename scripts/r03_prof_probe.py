@@ -30,8 +30,10 @@ if what == "resident":
         out[name + "_ms"] = 1e3 * float(np.median(ts))
         out["passes_total"] = int(sum(q.num_evaluations for q in s))
     sv.pose_plus(x0[None, :], np.zeros((1, 6)))
-elif what == "coop":
+elif what in ("coop", "coopz"):
     rec = clc.flatten_observations(sd.sim_fixed_count(1000, n // 500, 500, noise_sigma=0.01), False)
+    if what == "coopz":  # points off the lidar plane: the 24-byte-slot form of the kernel
+        rec[:, 6] = np.random.default_rng(3).normal(size=rec.shape[0]) * 0.02
     sv.upload(rec)
     built, ppl, _, _, _ = sv.debug_coop()
     o = clc.default_options()
@@ -40,7 +42,7 @@ elif what == "coop":
     for _ in range(5):
         r = sv.solve(x0, o, trace_cap=0)
     _, _, solves, aborts, off = sv.debug_coop()
-    out.update(coop_built=built, points_per_lane=ppl, coop_solves=solves, aborts=aborts, passes=int(r.summary.num_evaluations), solve_ms=r.summary.solve_ms,
+    out.update(workgroups=sv.path_info().coop_workgroups, z=sv.path_info().coop_points_carry_z, coop_built=built, points_per_lane=ppl, coop_solves=solves, aborts=aborts, passes=int(r.summary.num_evaluations), solve_ms=r.summary.solve_ms,
                lane_layout_bytes=256 * ppl * 256 * 16 + 256 * 256 * 8 + (n // 500) * 48)
 elif what == "step":
     rec = clc.flatten_observations(sd.sim_fixed_count(1000, n // 500, 500, noise_sigma=0.01), False)
