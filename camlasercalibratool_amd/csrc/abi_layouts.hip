@@ -254,7 +254,7 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
       // COOP_WGS of them, or COOP_SMALL_WGS where that leaves a lane at most COOP_SMALL_MAX_PPL points (the one-hop form of the kernel)
       const int cap_ppl = any_z ? clc::COOP_PR_Z + clc::COOP_PL_Z : clc::COOP_PR + clc::COOP_PL;
       const int small_ppl = std::min(clc::COOP_SMALL_MAX_PPL, cap_ppl);
-      const bool small_ok = !any_z && n <= (long long)clc::COOP_SMALL_WGS * clc::COOP_NL * small_ppl && (h->auto_disable & 8) == 0;
+      const bool small_ok = n <= (long long)clc::COOP_SMALL_WGS * clc::COOP_NL * small_ppl && (h->auto_disable & 8) == 0;
       for (int attempt = small_ok ? 0 : 1; attempt < 2 && !T.coop->ok; ++attempt) {
         const int wgs = attempt == 0 ? clc::COOP_SMALL_WGS : clc::COOP_WGS;
         std::vector<long long> chunk((size_t)wgs + 1);

@@ -428,8 +428,11 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
   hipLaunchKernelGGL((clc::coop_solve_kernel<LOSS, false, Z, ONE>), dim3(wgs), dim3(clc::COOP_THREADS), 0, h->stream, h->cres.d_xy, h->cres.d_z, d_row, \
                      d_desc, h->d_groups, h->cres.uni_ppl, opt, p0, d_trace, d_cap, h->d_board, tag0, h->d_spose, h->d_ssummary, h->d_small, d_done, \
                      n_wgs)
-  if (h->cres.with_z) { if (opt.use_loss) CLC_LAUNCH_COOP(true, true, false); else CLC_LAUNCH_COOP(false, true, false); }  // 24-byte slots: p.z != 0
-  else if (n_wgs == clc::COOP_SMALL_WGS) { if (opt.use_loss) CLC_LAUNCH_COOP(true, false, true); else CLC_LAUNCH_COOP(false, false, true); }  // one hop
+  const bool one = n_wgs == clc::COOP_SMALL_WGS;  // the one-hop form on 32 workgroups
+  if (h->cres.with_z) {  // 24-byte slots: p.z != 0
+    if (one) { if (opt.use_loss) CLC_LAUNCH_COOP(true, true, true); else CLC_LAUNCH_COOP(false, true, true); }
+    else { if (opt.use_loss) CLC_LAUNCH_COOP(true, true, false); else CLC_LAUNCH_COOP(false, true, false); }
+  } else if (one) { if (opt.use_loss) CLC_LAUNCH_COOP(true, false, true); else CLC_LAUNCH_COOP(false, false, true); }
   else { if (opt.use_loss) CLC_LAUNCH_COOP(true, false, false); else CLC_LAUNCH_COOP(false, false, false); }
 #undef CLC_LAUNCH_COOP
   CLC_HIP(hipGetLastError());
