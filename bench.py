@@ -52,16 +52,31 @@ MIN_BYTES_PER_POINT = 16     # what the reference's own container holds per obse
 MIN_BYTES_PER_SCAN = 40      # ... plus one plane (4 doubles) and one scale per Oberserve (include/LaseCamCalCeres.h:11-24)
 INFINITY_CACHE_BYTES = 256 * 2**20
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: FP64 (and any other) VALU issue peak
-# VALU wave-instructions of resident_solve_kernel<loss, nt, 4 waves, 23 + 19 points> per wave and evaluation pass at 42 points per
-# lane, the controller's share (wave 0, between passes) included: the pass's instruction stream does not depend on the data, so
-# the count per pass is a constant of the build — PMC SQ_INSTS_VALU / (passes x 4 waves) of profiles/r04_resident.md (1 478; the
-# static count of the pass alone in the ISA, scripts/isa_hist.py, is 1 310)
-RESIDENT_VALU_PER_WAVE_PASS_42 = 1478
-# coop_solve_kernel<loss> at 16 points per lane (C2): VALU wave-instructions one WORKGROUP (4 point waves + the controller wave)
-# issues per evaluation pass, and once per launch outside the passes — the difference of a 13-pass and a 5-pass launch under
-# --pmc SQ_INSTS_VALU, profiles/r04_coop.md (the pass's instruction stream does not depend on the data)
-COOP_VALU_PER_WG_PASS = {16: 3298}
-COOP_VALU_PER_WG_ONCE = {16: 1041}
+# The whole-solve kernels are priced against FP64 VALU issue with instruction counts that are constants of a BUILD (the pass's
+# instruction stream does not depend on the data): PMC SQ_INSTS_VALU of the profile scripts (scripts/profile_r05.sh ->
+# scripts/summarize_r05.py), kept in profiles/valu_counts.json together with the identity of the sources they were measured on
+# (`csrc_sha16` = camlasercalibratool_amd/_build.csrc_sha16(), `head`).  When the sources in the tree differ from that identity the
+# counts are NOT used: `roofline.frac` is null and `valu_issue.current` false, until the profile is regenerated.
+VALU_COUNTS_FILE = os.path.join(ROOT, "profiles", "valu_counts.json")
+
+
+def valu_counts(path=None, sha=None):
+    """(counts, info): the measured instruction counts when they belong to the sources in the tree, else (None, info) —
+    info = {source, source_head, csrc_sha16, current} rides on the line as roofline.valu_issue."""
+    from camlasercalibratool_amd import _build
+    sha = sha or _build.csrc_sha16()
+    try:
+        d = json.load(open(path or VALU_COUNTS_FILE))
+    except (OSError, ValueError) as e:
+        return None, {"source": "profiles/valu_counts.json", "current": False, "csrc_sha16": sha, "error": repr(e)}
+    info = {"source": "profiles/valu_counts.json (rocprofv3 --pmc SQ_INSTS_VALU)", "source_head": d.get("head"), "csrc_sha16": d.get("csrc_sha16"),
+            "current": d.get("csrc_sha16") == sha}
+    if not info["current"]:
+        info["tree_csrc_sha16"] = sha
+        print(f"bench.py: profiles/valu_counts.json was measured on sources {d.get('csrc_sha16')} but the tree is {sha}: VALU counts "
+              "not used (roofline.frac = null); regenerate with scripts/profile_r05.sh + scripts/summarize_r05.py", file=sys.stderr)
+        return None, info
+    return d, info
 
 
 def hbm_figures(moved_bytes, contract_bytes, sec):
@@ -116,6 +131,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process group for N>1 (nccl = RCCL; gloo only for dry runs: the result records are then gathered "
                          "with torch.distributed instead of clc_gather_results)")
+    ap.add_argument("--detail-file", default=None, help="where the full result goes (default: bench_detail.json beside bench.py)")
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="the K-step timed region is repeated this many times (each bracketed by barrier + synchronize, max over ranks); "
+                         "ms_per_step is the median block")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: map ranks onto the visible GPUs modulo their count (with --backend gloo)")
     return ap.parse_args()
@@ -168,24 +187,28 @@ def resident_kernel_report(clc, solver, x_start, n_problems, n_obs_total, n_scan
            "note": "the data crosses HBM once per SOLVE, not once per pass (`frac_moved`, bounded by 1); the launch is bound by FP64 VALU issue: "
                    "`frac` = VALU lane-instructions / kernel time / issue peak.  `contract_64B_frac` prices the launch at the contract's 64 algorithmic "
                    "bytes per evaluation x all passes and is not a bandwidth"}
-    tfile = os.path.join(ROOT, "profiles", "r04_resident_traffic.json")
-    if os.path.exists(tfile) and n_problems == 8192:
-        try:
-            rep["traffic"] = json.load(open(tfile)).get("pmc_read_bytes_per_batch")
-            rep["traffic_source"] = "profiles/r04_resident.md (rocprofv3 --pmc FETCH_SIZE of the builder's run; 1.009 x one pass over the lane layout)"
-        except Exception:
-            pass
-    # per wave and pass: 21.5 VALU instructions per point + what does not depend on the points; exact at 42 points per lane (PMC), an
-    # estimate elsewhere
-    per_wave_pass = RESIDENT_VALU_PER_WAVE_PASS_42 + 21.5 * (ppl - 42)
-    lane_instr = passes * (lanes / 64.0) * per_wave_pass * 64
-    rep["achieved"] = lane_instr / sec / 1e12
-    rep["frac"] = lane_instr / sec / VALU_PEAK_LANE_INSTR
-    rep["valu_issue"] = {"valu_instructions_per_wave_and_pass": per_wave_pass, "exact": bool(lanes == 256 and ppl == 42), "lane_instructions": lane_instr,
-                         "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR, "frac": lane_instr / sec / VALU_PEAK_LANE_INSTR,
-                         "note": "VALU wave-instructions per wave and pass (a constant of the build at 42 points per lane: 21.5 per point + the per-pass moment "
-                                 "expansion, padding correction, wave reduction and the controller's share; profiles/r04_resident.md) x waves x this "
-                                 "run's passes x 64 lanes, over this run's kernel time, against 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz"}
+    counts, vinfo = valu_counts()
+    table = (counts or {}).get("resident") or {}
+    rc, exact = table.get(str(ppl)), True
+    if rc is None and table:  # another problem size: the nearest measured count, moved along its per-point slope (an estimate, flagged)
+        near = min(table, key=lambda k: abs(int(k) - ppl))
+        rc, exact = dict(table[near]), False
+        rc["valu_per_wave_pass"] = float(rc["valu_per_wave_pass"]) + float(rc.get("valu_per_point", 21.5)) * (ppl - int(near))
+    rep["valu_issue"] = dict(vinfo, exact=exact)
+    if rc is not None and lanes == rc.get("lanes", 256):
+        if exact and n_problems == rc.get("problems"):
+            rep["traffic"] = rc.get("pmc_read_bytes_per_batch")
+            rep["traffic_source"] = "profiles/valu_counts.json (rocprofv3 --pmc FETCH_SIZE of the builder's run on the same sources)"
+        per_wave_pass = float(rc["valu_per_wave_pass"])
+        lane_instr = passes * (lanes / 64.0) * per_wave_pass * 64
+        rep["achieved"] = lane_instr / sec / 1e12
+        rep["frac"] = lane_instr / sec / VALU_PEAK_LANE_INSTR
+        rep["valu_issue"].update({"per_pass": per_wave_pass, "lane_instructions": lane_instr, "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR,
+                                  "note": "VALU wave-instructions per wave and pass (controller's share included) x waves x this run's passes x 64 lanes, "
+                                          "over this run's kernel time, against 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz"})
+    elif counts is not None:
+        rep["valu_issue"]["current"] = False
+        rep["valu_issue"]["error"] = f"no count for {ppl} points per lane x {lanes} lanes in profiles/valu_counts.json"
     return rep
 
 
@@ -215,7 +238,11 @@ def coop_kernel_report(clc, solver, x0, n_obs, n_scans):
     # lane layout (16 B per point slot, zero-padded to ppl per lane) + lane descriptors + plane table, read once; + the exchange words
     moved = COOP_WGS * ppl * COOP_LANES * 16 + COOP_WGS * COOP_LANES * 8 + n_scans * 48
     exchange = passes * (COOP_WGS * 448 * 2 + 8 * 448 * (1 + COOP_WGS))  # rows written + read by the 8 leaders, group rows written + read by all
-    vp, vo = COOP_VALU_PER_WG_PASS.get(ppl), COOP_VALU_PER_WG_ONCE.get(ppl, 0)
+    counts, vinfo = valu_counts()
+    cc = ((counts or {}).get("coop") or {}).get(str(ppl)) or {}
+    vp, vo = cc.get("valu_per_workgroup_pass"), cc.get("valu_per_workgroup_once", 0)
+    if counts is not None and not cc:
+        vinfo = dict(vinfo, current=False, error=f"no count for {ppl} points per lane in profiles/valu_counts.json")
     lane_instr = 64.0 * COOP_WGS * (passes * vp + vo) if vp else None
     rep = {"bound": "valu_f64", "peak": VALU_PEAK_LANE_INSTR / 1e12, "unit": "T VALU lane-instructions/s",
            "achieved": lane_instr / sec / 1e12 if vp else None, "frac": lane_instr / sec / VALU_PEAK_LANE_INSTR if vp else None,
@@ -223,10 +250,10 @@ def coop_kernel_report(clc, solver, x0, n_obs, n_scans):
                      "per lane in registers + LDS, + one controller wave); per pass: lane moments -> two-level exchange of the 28 totals through tagged words -> "
                      "LM controller (csrc/clc_lmuni.hpp) on the controller wave of every workgroup)",
            "launches_per_solve": 1, "avg_kernel_ms": best, "evaluation_passes": passes, "us_per_pass": 1e3 * best / passes,
-           "valu_issue": {"valu_wave_instructions_per_workgroup_and_pass": vp, "valu_wave_instructions_per_workgroup_once": vo,
+           "valu_issue": {**vinfo, "per_pass": vp, "once": vo,
                           "lane_instructions_per_launch": lane_instr, "peak_lane_instructions_per_s": VALU_PEAK_LANE_INSTR,
-                          "note": "instruction counts are constants of the build at this many points per lane (profiles/r04_coop.md: --pmc SQ_INSTS_VALU of a 13-pass and "
-                                  "a 5-pass launch); x 256 workgroups x this run's passes x 64 lanes, over this run's kernel time, against 256 CUs x 4 SIMDs x "
+                          "note": "VALU wave-instructions per WORKGROUP and pass / once per launch (difference of a 13-pass and a shorter launch under --pmc "
+                                  "SQ_INSTS_VALU); x 256 workgroups x this run's passes x 64 lanes, over this run's kernel time, against 256 CUs x 4 SIMDs x "
                                   "16 lanes/clk x 2.4 GHz.  A fifth of the issue peak: the launch waits more than it computes, see `limited_by`"},
            "limited_by": "latency: a pass is the serial chain [pose + lane moments + expansion + wave reduction, FP64 issue on one wave per SIMD, ~2.3 us at 16 points "
                          "per lane] -> [exchange: 32 rows -> 8 group leaders -> everyone, two store-to-load hops through device memory of ~1.1 us each] -> "
@@ -236,7 +263,9 @@ def coop_kernel_report(clc, solver, x0, n_obs, n_scans):
            "moved_bytes_per_launch": int(moved + exchange), "achieved_moved_GBps": (moved + exchange) / sec / 1e9,
            "frac_moved": (moved + exchange) / sec / 1e9 / HBM_PEAK_GBS,
            "hbm_passes_over_the_data_per_solve": 1, "exchange_bytes_per_launch": int(exchange),
-           "served_from": "infinity_cache" if moved <= INFINITY_CACHE_BYTES else "hbm", "traffic_measured_in_run": False, "traffic": None,
+           "served_from": "infinity_cache" if moved <= INFINITY_CACHE_BYTES else "hbm", "traffic_measured_in_run": False,
+           "traffic": cc.get("hbm_bytes_per_launch") if cc.get("passes") == passes else None,
+           "traffic_source": "profiles/valu_counts.json (rocprofv3 --pmc FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 of the builder's run on the same sources)",
            "pricings": pricings(evals, n_scans * passes, moved + exchange, sec),
            "timing": "hipEvent pair around the launch on the solver's stream (profile_events = 2), best of 7",
            "cooperative_launch_timeouts": aborts,
@@ -280,24 +309,29 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
 
     for _ in range(warmup):
         ss.solve(x0, ordered=False, copy=False, inplace=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        # start poses into the handle's pinned buffer, solve this shard in place, all-gather of all ranks' records
-        out = ss.solve(x0, ordered=False, copy=False, inplace=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # the timed region: `steps` steps bracketed by barrier + synchronize on both sides, `blocks` times over; every block's time is
+    # the MAX over ranks, ms_per_step the median block
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            # start poses into the handle's pinned buffer, solve this shard in place, all-gather of all ranks' records
+            out = ss.solve(x0, ordered=False, copy=False, inplace=True)
+        barrier()
+        block_s.append(time.perf_counter() - t0)
     sms = ss.last_summaries
     per = args.shard_poses * args.shard_pts
     evals_step = float(sum(sms[k].num_evaluations for k in range(len(sms)))) * per
     iters_step = float(sum(sms[k].num_iterations for k in range(len(sms))))
     if dist is not None:
         cdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed, evals_step, iters_step], dtype=torch.float64, device=cdev)
-        tmax = t.clone()
+        tmax = torch.tensor(block_s, dtype=torch.float64, device=cdev)
+        t = torch.tensor([evals_step, iters_step], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, evals_step, iters_step = float(tmax[0]), float(t[1]), float(t[2])
+        block_s, evals_step, iters_step = [float(v) for v in tmax], float(t[0]), float(t[1])
+    elapsed = float(np.median(block_s))
     res = None
     if rank == 0:
         raw = np.array(out).reshape(-1, 12)
@@ -311,7 +345,8 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
                         f"x{world} GPUs = {n_total} problems; step = clc_solve_batched + RCCL all-gather of all {n_total} result records",
             "problems": n_total, "problems_per_gpu": args.problems_per_gpu, "observations_per_gpu": n_obs_local,
             "record_bytes_per_gpu": 64 * n_obs_local,
-            "ms_per_step": 1e3 * dt, "problems_per_s": n_total / dt, "evals_per_s": evals_step / dt,
+            "ms_per_step": 1e3 * dt, "ms_per_step_blocks": [1e3 * b / steps for b in block_s],
+            "problems_per_s": n_total / dt, "evals_per_s": evals_step / dt,
             "lm_iters_per_s": iters_step / dt,
             "lm_iterations_min_max": [int(its.min()), int(its.max())],
             "terminations": {clc.TERMINATION.get(int(c), str(int(c))): int((full[:, 10] == c).sum()) for c in np.unique(full[:, 10])},
@@ -374,24 +409,180 @@ def _claim_stdout():
     os.dup2(2, 1)
 
 
-def _emit(out):
+LINE_LIMIT = 4096  # bytes: the driver keeps a bounded tail of stdout; the r04 line (21.6 KB) was not parsed
+
+
+def _short(text, n=160):
+    text = str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def _num(v, digits=6):
+    """Numbers of the line: finite floats rounded to `digits` significant digits, everything non-finite -> None (strict JSON)."""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        if not np.isfinite(v):
+            return None
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def _pick(d, keys, digits=6, keep_none=False):
+    return {k: _num(d[k], digits) for k in keys if isinstance(d, dict) and k in d and (keep_none or d[k] is not None)}
+
+
+def compact_line(out, detail_file=None):
+    """The ONE stdout line of the contract, built from the full result dict: the headline fields, `config`, `roofline`, `cpu_baseline`,
+    `parity`, `scale_base` and one-number summaries of the side measurements — at most LINE_LIMIT bytes, strict JSON (no NaN / Infinity).
+    Everything else (sub-objects of the other kernels, pricings, notes, cold-start breakdown, gather bookkeeping) goes to the detail
+    file named in `detail_file` and to stderr.  tests/test_bench_line.py holds this to the limit."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step"), 9, keep_none=True)
+    for k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        line[k] = out.get(k)
+    cfg = out.get("config") or {}
+    line["config"] = {k: (_short(v, 240) if isinstance(v, str) else v) for k, v in cfg.items()
+                      if k in ("workload", "observations", "problems", "observations_per_gpu", "parallelism", "device", "compute_units")}
+    line.update(_pick(out, ("timed_blocks", "ms_per_step_min", "ms_per_step_max", "ms_per_step_first_block", "lm_iters_per_s", "problems_per_s",
+                            "per_gpu_value", "lm_iterations_per_solve", "evaluation_passes_per_solve", "final_cost"), 9))
+    if out.get("termination") is not None:
+        line["termination"] = out["termination"]
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        r = _pick(rf, ("bound", "peak", "unit", "achieved", "frac", "avg_kernel_ms", "frac_moved", "contract_64B_frac", "traffic",
+                       "evaluation_passes", "us_per_pass", "moved_bytes_per_launch", "algorithmic_bytes_per_launch",
+                       "traffic_measured_in_run", "served_from"))
+        r.setdefault("traffic", None)
+        r["kernel"] = _short(rf.get("kernel", ""), 120)
+        vi = rf.get("valu_issue")
+        if isinstance(vi, dict):
+            r["valu_issue"] = _pick(vi, ("source", "source_head", "csrc_sha16", "current", "per_pass", "once"))
+        line["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "host_cpus", "ms_per_solve"))
+        c["sample"] = _short(cb.get("sample", ""), 200)
+        line["cpu_baseline"] = c
+    pa = out.get("parity")
+    if isinstance(pa, dict):
+        line["parity"] = _pick(pa, ("T_cl_max_abs_err_vs_oracle", "final_cost_abs_err_vs_oracle", "iterations_gpu", "iterations_oracle"), 3)
+        line["parity"]["gates"] = pa.get("gates")
+    sb = out.get("scale_base")
+    if isinstance(sb, dict):
+        line["scale_base"] = _pick(sb, ("workload", "value", "unit", "ms_per_step"))
+    summ = {}
+    c3, c4, rl, cs = out.get("batched_c3"), out.get("batched_c4_shard"), out.get("roofline_large"), out.get("cold_start")
+    if isinstance(c3, dict) and "ms_per_batch" in c3:
+        summ["c3_ms_per_batch"] = _num(c3["ms_per_batch"], 5)
+        summ["c3_T_cl_err_vs_oracle"] = _num(c3.get("T_cl_max_abs_err_vs_oracle_sample"), 3)
+    if isinstance(c4, dict) and "ms_per_step" in c4:
+        summ["c4_shard_ms_per_step"] = _num(c4["ms_per_step"], 5)
+        summ["c4_T_cl_err_vs_oracle"] = _num(c4.get("T_cl_max_abs_err_vs_oracle_sample"), 3)
+        k4 = c4.get("roofline") or {}
+        summ["c4_kernel_ms"], summ["c4_kernel_frac"] = _num(k4.get("avg_kernel_ms"), 5), _num(k4.get("frac"), 4)
+        g = c4.get("gather") or {}
+        summ["c4_rccl_ranks"] = g.get("rccl_ranks")
+    elif isinstance(c4, dict) and "error" in c4:
+        summ["c4_error"] = _short(c4["error"], 120)
+    if isinstance(rl, dict):
+        summ["large"] = _pick(rl, ("frac", "frac_min", "frac_max", "avg_kernel_ms", "kernel_ms_min", "kernel_ms_max", "observations", "launches"), 5)
+        summ["large"]["stat"] = rl.get("stat")
+    if isinstance(cs, dict):
+        for shape in ("c1", "offline"):
+            d = cs.get(shape) or {}
+            if "first_call" in d:
+                summ[f"cold_{shape}_ms"] = [_num(d.get("clc_create_ms"), 4), _num(d["first_call"].get("total_ms"), 4),
+                                            _num((d.get("cpu_oracle") or {}).get("total_ms"), 4)]
+        summ["cold_fields"] = "[clc_create, first call, same calls on the CPU port]"
+    if summ:
+        line["side"] = summ
+    if detail_file:
+        line["detail_file"] = detail_file
+    # belt and braces: whatever a future field adds, the line never outgrows the limit
+    for victim in ("side", "parity", "scale_base", "detail_file"):
+        if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT - 64:
+            break
+        line.pop(victim, None)
+    return line
+
+
+def _jsonable(o):
+    if isinstance(o, dict):
+        return {str(k): _jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_jsonable(v) for v in o]
+    if isinstance(o, (np.floating, float)):
+        return float(o) if np.isfinite(o) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.bool_):
+        return bool(o)
+    if isinstance(o, np.ndarray):
+        return _jsonable(o.tolist())
+    return o
+
+
+def _emit(out, detail_path=None):
+    """stdout gets the compact line (compact_line); the full result goes to `detail_path` (default bench_detail.json beside this file,
+    and a copy under gpurun_out/ when that directory exists) and to stderr."""
     sys.stdout.flush()
-    os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
+    full = _jsonable(out)
+    paths = [detail_path] if detail_path else [os.path.join(ROOT, "bench_detail.json")]
+    if not detail_path and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                json.dump(full, f, indent=1, allow_nan=False)
+            written = written or pth
+        except OSError as e:
+            print(f"bench.py: could not write {pth}: {e}", file=sys.stderr)
+    print("bench.py detail: " + json.dumps(full, allow_nan=False), file=sys.stderr)
+    line = json.dumps(compact_line(full, os.path.relpath(written, ROOT) if written else None), allow_nan=False)
+    assert len(line) < LINE_LIMIT, len(line)
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, (line + "\n").encode())
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves — one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 — instead of quietly measuring one GPU.  Replaces this process."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)), file=sys.stderr)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args.gpus)  # does not return
     _claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:  # never measure a different number of GPUs than the line will claim
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or run `python bench.py --gpus {args.gpus}` "
+                         "without a launcher: it starts them itself)")
 
     import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    if torch.cuda.device_count() < world and not args.oversubscribe:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; "
+                         "--oversubscribe with --backend gloo is for dry runs)")
     if args.oversubscribe:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -422,8 +613,10 @@ def main():
                            "problems": c4["problems"], "observations_per_gpu": c4["observations_per_gpu"],
                            "parallelism": f"problem-sharded x{world} (contiguous shards, no data-path collective), clc_gather_results",
                            "device": c4["device"], "compute_units": c4["compute_units"]},
+                "timed_blocks": len(c4["ms_per_step_blocks"]), "ms_per_step_min": min(c4["ms_per_step_blocks"]),
+                "ms_per_step_max": max(c4["ms_per_step_blocks"]), "ms_per_step_first_block": c4["ms_per_step_blocks"][0],
                 "problems_per_s": c4["problems_per_s"], "lm_iters_per_s": c4["lm_iters_per_s"],
-                "roofline": c4.pop("roofline"),
+                "roofline": c4["roofline"],
                 "batched_c4_shard": c4,
                 # the N=1 line's `value` is C2 (the configuration the metric is quoted on, a single problem that does not shard); the base
                 # of THIS curve is the same line's top-level `scale_base.value` (= its batched_c4_shard.evals_per_s)
@@ -431,7 +624,7 @@ def main():
                 "scale_base_field": "scale_base.value of the `bench.py --gpus 1` line (this workload, one GPU's shard)",
                 "single_gpu_base": "run `bench.py --gpus 1`: its `batched_c4_shard` sub-object is this workload on one GPU",
             }
-            _emit(out)
+            _emit(out, args.detail_file)
         dist.destroy_process_group()
         return
 
@@ -454,32 +647,20 @@ def main():
 
     for _ in range(args.warmup):
         res = solver.solve(x0, opt, trace_cap=0)
-    barrier()
-    t0 = time.perf_counter()
-    evals = 0
-    iters = 0
-    k_ms = 0.0
-    k_launches = 0
-    for _ in range(args.steps):
-        res = solver.solve(x0, opt, trace_cap=0)  # no iteration trace: nothing forces a stream sync
-        evals += res.summary.num_evaluations * n_obs
-        iters += res.summary.num_iterations
-        k_ms += res.summary.eval_kernel_ms
-        k_launches += res.summary.eval_kernel_launches
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    elapsed_max, evals_total, iters_total = elapsed, float(evals), float(iters)  # one rank
-    # (outside the timed region) the same block of K solves five more times: the K-step region above is a few milliseconds
-    # long, and its median over blocks is the steadier figure from box to box
-    block_ms = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        tb0 = time.perf_counter()
+    # the timed region: K solves bracketed by barrier + synchronize on both sides, `blocks` times over (at the driver's --steps 20
+    # one block is under 2 ms of wall time: a single scheduler hiccup would move it by percent); ms_per_step = the median block
+    block_ms, evals, iters = [], 0, 0
+    for _ in range(max(1, args.blocks)):
+        barrier()
+        t0 = time.perf_counter()
+        evals = iters = 0
         for _ in range(args.steps):
-            solver.solve(x0, opt, trace_cap=0)
-        torch.cuda.synchronize()
-        block_ms.append(1e3 * (time.perf_counter() - tb0) / args.steps)
+            res = solver.solve(x0, opt, trace_cap=0)  # no iteration trace: nothing forces a stream sync
+            evals += res.summary.num_evaluations * n_obs
+            iters += res.summary.num_iterations
+        barrier()
+        block_ms.append(1e3 * (time.perf_counter() - t0) / args.steps)
+    elapsed_max, evals_total, iters_total = 1e-3 * float(np.median(block_ms)) * args.steps, float(evals), float(iters)  # one rank
 
     out = None
     hs = None
@@ -493,7 +674,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps,
-            "ms_per_step_median_of_5_more_blocks": float(np.median(block_ms)), "ms_per_step_blocks": block_ms,
+            "timed_blocks": len(block_ms), "ms_per_step_blocks": block_ms, "ms_per_step_min": min(block_ms), "ms_per_step_max": max(block_ms),
+            "ms_per_step_first_block": block_ms[0],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -580,14 +762,6 @@ def main():
         # its own object.
         coop = coop_kernel_report(clc, solver, x0, n_obs, args.poses)
         if coop is not None:
-            cfile = os.path.join(ROOT, "profiles", "r04_coop_traffic.json")
-            if os.path.exists(cfile):
-                try:
-                    cj = json.load(open(cfile))
-                    coop["traffic"] = cj.get("hbm_bytes_per_launch")
-                    coop["traffic_source"] = cj.get("source")
-                except Exception:
-                    pass
             coop["timed_region_wall_ms_per_solve"] = 1e3 * elapsed_max / args.steps
             out["roofline"] = coop
             if roof is not None:
@@ -605,7 +779,10 @@ def main():
         del big
         rows_ok_l, n_rows_l, _, _ = hs.debug_rows()
         streamed_l = (n_rows_l * ROW_BYTES) if rows_ok_l else COMPACT_BYTES_PER_EVAL * nb
-        ms = min(hs.time_eval(x0, reps=20) for _ in range(3))
+        # 15 groups of 10 back-to-back launches: the MEDIAN group is the figure (`frac`); min / max ride along — a best-of hid a
+        # spread in r04 (profiles/r05_large.md explains it)
+        groups = sorted(hs.time_eval(x0, reps=10) for _ in range(15))
+        ms, ms_lo, ms_hi = groups[len(groups) // 2], groups[0], groups[-1]
         hs.set_launch(0, 2 | 16 | 32)
         msc = min(hs.time_eval(x0, reps=10) for _ in range(3))
         hs.set_launch(0, 6)
@@ -616,7 +793,10 @@ def main():
             observations=nb, algorithmic_bytes=int(BYTES_PER_EVAL * nb), streamed_bytes=int(streamed_l),
             beyond_infinity_cache=bool(streamed_l > 256 * 2**20),
             kernel="clc::eval_rows_kernel<loss=1,nt=1,512,weighted=1>" if rows_ok_l else "clc::eval_kernel (compact, deep)",
-            avg_kernel_ms=ms, evals_per_s=nb / (ms * 1e-3),
+            avg_kernel_ms=ms, kernel_ms_min=ms_lo, kernel_ms_max=ms_hi, launches=150,
+            stat="median of 15 groups of 10 back-to-back launches (frac_min / frac_max: slowest / fastest group)",
+            frac_min=streamed_l / (ms_hi * 1e-3) / 1e9 / HBM_PEAK_GBS, frac_max=streamed_l / (ms_lo * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            kernel_ms_groups=groups, evals_per_s=nb / (ms * 1e-3),
             pricings=pricings(nb, (nb + args.pts - 1) // args.pts, streamed_l, ms * 1e-3),
             served_from="infinity_cache" if streamed_l <= INFINITY_CACHE_BYTES else "hbm", traffic_measured_in_run=False,
             note="`frac` (= `frac_moved`) = bytes the layout moves / time / 8 TB/s is the HBM fraction; `contract_64B_frac` prices the same launch at the "
@@ -774,7 +954,7 @@ def main():
 
         def _give_up():
             out["batched_c4_shard"] = {"error": "the C4-shard section did not finish within 300 s; everything else in this line was measured before it"}
-            _emit(out)
+            _emit(out, args.detail_file)
             os._exit(0)
 
         dog = threading.Timer(300.0, _give_up)
@@ -789,7 +969,7 @@ def main():
                                      "the N>1 lines report `per_gpu_value` = value / N to set against it"}
 
     if rank == 0:
-        _emit(out)
+        _emit(out, args.detail_file)
     if hs is not None:
         hs.close()
     solver.close()

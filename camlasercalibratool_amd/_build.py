@@ -34,6 +34,19 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
                "-mllvm", "-amdgpu-kernarg-preload-count=8"]
 
 
+def csrc_sha16() -> str:
+    """Identity of what the libraries are built from: sha256 over the bytes of every csrc source (in SOURCES order) and the compiler flags.
+    Constants that were measured on a build (the VALU instruction counts bench.py prices the whole-solve kernels with,
+    profiles/valu_counts.json) carry it, and bench.py refuses them when it differs from the sources in the tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in SOURCES:
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

@@ -81,6 +81,9 @@ constexpr int COOP_DONE_OK = 1, COOP_DONE_ABORT = 2;
 #define CLC_COOP_D2 3500        // ... at which everybody first looks at the 8 group rows
 #endif
 
+#ifndef CLC_COOP_GRP
+#define CLC_COOP_GRP 8          // points per basic block of a pass (see the point loop)
+#endif
 #ifndef CLC_COOP_REPLICAS
 #define CLC_COOP_REPLICAS 1
 #endif
@@ -391,7 +394,10 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
   const double* __restrict__ srcz = WITH_Z ? zl + (size_t)row0 * NL + tid : nullptr;  // (z rows: j-major like the (x, y) rows, 8 bytes per slot)
   v2d lds_v[PL];
   double lds_z[WITH_Z ? PL : 1];
-  const bool use_lds = ppl > PR;
+  // (keyed on the slots a pass TOUCHES, not on ppl: a pass walks whole blocks of CLC_COOP_GRP slots, and where PR is not a multiple of
+  // the block — the z form: 10 — the block that holds point 9 or 10 runs on into LDS slots; those must then hold zeros, not
+  // whatever the last launch left there)
+  const bool use_lds = (ppl + CLC_COOP_GRP - 1) / CLC_COOP_GRP * CLC_COOP_GRP > PR;
   if (use_lds) {
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
@@ -429,9 +435,6 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     pl_nx = a[0]; pl_ny = a[1]; pl_nz = b[0]; pl_d = b[1]; pl_s2 = s * s;
   }
   const double inv_lf2 = make_uniform(1.0 / (opt.loss_scale_factor * opt.loss_scale_factor));
-#ifndef CLC_COOP_GRP
-#define CLC_COOP_GRP 8
-#endif
   // Points per basic block = independent dependency chains: a wave alone on its SIMD needs them (C2 kernel: pairs 0.0986 ms, fours
   // 0.0942, eights 0.0909).  The running cost product is renormalised once per block: eight factors 1 + r0^2/lf^2 below 2^128 each
   // (|r0| / lf < 1.8e19) cannot overflow.
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     }
     v2d buf[2][CH];
     double bufz[2][WITH_Z ? CH : 1];
-    if (ppl > PR) {
+    if (use_lds) {
 #pragma unroll
       for (int u = 0; u < CH; ++u)
         if (u < PL) {

@@ -235,3 +235,38 @@ def test_cooperative_kernel_z_capacity_edge(sv, oracle_mod):
     r = sv.solve(x0, trace_cap=0)
     ref = oracle_mod.solve(more, x0, linear_solver="qr", threads=oracle_mod.max_threads())
     assert r.summary.num_iterations == ref.summary.num_iterations and _dT(r.pose, ref.pose) <= T_TOL
+
+
+@pytest.mark.parametrize("use_loss", [1, 0])
+@pytest.mark.parametrize("wgs", [32, 256])
+@pytest.mark.parametrize("ppl", [9, 10])
+def test_cooperative_kernel_z_with_9_and_10_points_per_lane(sv, oracle_mod, ppl, wgs, use_loss):
+    """The z form keeps 10 points per lane in registers, and a pass walks blocks of 8 slots: at 9 or 10 points per lane the block that
+    holds slots 8..15 runs on into LDS-held slots 10..15, which must hold zeros (round 4 left them unwritten: whatever the previous
+    launch had there — here a 26-points-per-lane problem with coordinates of hundreds of metres — entered the moments).  Both launch
+    forms (32 workgroups one-hop, 256 workgroups), loss on and off, against the oracle's DENSE_QR solve; idle lanes included (the
+    last scan is shorter)."""
+    o, oo = clc.default_options(), oracle_mod.default_options()
+    o.use_loss = oo.use_loss = use_loss
+    sv.set_launch(0, -1)
+    # a previous launch that fills every LDS slot with large non-zero points
+    dirty = _off_plane(clc.flatten_observations(sd.sim_fixed_count(33, 256 * 2, 26 * 128, noise_sigma=0.01), False), 11, sigma=0.5)
+    dirty[:, 4:7] *= 300.0
+    sv.upload(dirty)
+    assert _on_chip(sv) and sv.path_info().coop_points_per_lane == 26
+    sv.solve(X0, o, trace_cap=0)
+    K = 16 * ppl
+    n_scans = wgs * 16
+    S = sd.sim_fixed_count(40 + ppl, n_scans, K, noise_sigma=0.01)
+    rec = _off_plane(clc.flatten_observations(S, False), 12, sigma=0.02)
+    rec = np.ascontiguousarray(rec[: n_scans * K - 3 * ppl - 1])  # the last scan is short: lanes with fewer points, idle lanes
+    sv.upload(rec)
+    pi = sv.path_info()
+    assert _on_chip(sv) and pi.coop_points_per_lane == ppl and pi.coop_workgroups == wgs, (pi.coop_points_per_lane, pi.coop_workgroups)
+    x0 = sv.pose_plus(sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))[None, :], np.array([[0.03, -0.02, 0.02, 0.02, -0.02, 0.01]]))[0]
+    n0 = pi.coop_solves
+    r = sv.solve(x0, o, trace_cap=0)
+    assert sv.path_info().coop_solves == n0 + 1 and sv.path_info().coop_timeouts == 0
+    ref = oracle_mod.solve(rec, x0, options=oo, linear_solver="qr", threads=oracle_mod.max_threads())
+    assert r.summary.termination == ref.summary.termination and r.summary.num_iterations == ref.summary.num_iterations
+    assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
