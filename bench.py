@@ -135,6 +135,8 @@ def parse():
     ap.add_argument("--blocks", type=int, default=5,
                     help="the K-step timed region is repeated this many times (each bracketed by barrier + synchronize, max over ranks); "
                          "ms_per_step is the median block")
+    ap.add_argument("--two-call-step", action="store_true",
+                    help="C4 step as clc_solve_batched + clc_gather_results (the round-4 form) instead of the one-call clc_solve_batched_gather")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: map ranks onto the visible GPUs modulo their count (with --backend gloo)")
     return ap.parse_args()
@@ -307,8 +309,18 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The step: with the RCCL communicator ONE call, clc_solve_batched_gather (the kernel's epilogue writes the result records into the
+    # gather buffer; all-gather in place; one copy to the host); in the gloo dry runs the two calls + torch.distributed.
+    fused = ss.comm is not None and not args.two_call_step
+
+    def step():
+        if fused:
+            return ss.solve_gather(x0, ordered=False, copy=False)
+        # start poses into the handle's pinned buffer, solve this shard in place, all-gather of all ranks' records
+        return ss.solve(x0, ordered=False, copy=False, inplace=True)
+
     for _ in range(warmup):
-        ss.solve(x0, ordered=False, copy=False, inplace=True)
+        step()
     # the timed region: `steps` steps bracketed by barrier + synchronize on both sides, `blocks` times over; every block's time is
     # the MAX over ranks, ms_per_step the median block
     block_s = []
@@ -316,14 +328,17 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            # start poses into the handle's pinned buffer, solve this shard in place, all-gather of all ranks' records
-            out = ss.solve(x0, ordered=False, copy=False, inplace=True)
+            out = step()
         barrier()
         block_s.append(time.perf_counter() - t0)
-    sms = ss.last_summaries
     per = args.shard_poses * args.shard_pts
-    evals_step = float(sum(sms[k].num_evaluations for k in range(len(sms)))) * per
-    iters_step = float(sum(sms[k].num_iterations for k in range(len(sms))))
+    if fused:  # the shard's totals came back with the records (clc_batch_stats)
+        evals_step, iters_step = float(ss.last_stats.evaluations) * per, float(ss.last_stats.iterations)
+        assert ss.last_stats.problems == ss.hi - ss.lo, (ss.last_stats.problems, ss.hi - ss.lo)
+    else:
+        sms = ss.last_summaries
+        evals_step = float(sum(sms[k].num_evaluations for k in range(len(sms)))) * per
+        iters_step = float(sum(sms[k].num_iterations for k in range(len(sms))))
     if dist is not None:
         cdev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
         tmax = torch.tensor(block_s, dtype=torch.float64, device=cdev)
@@ -342,7 +357,7 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         res = {
             "workload": f"C4 shard: {args.problems_per_gpu} independent T_cl problems x {per} observations per GPU "
                         f"({args.shard_poses} poses x {args.shard_pts} pts, sigma=0.01 m, start 5 cm / 3 deg off the truth), "
-                        f"x{world} GPUs = {n_total} problems; step = clc_solve_batched + RCCL all-gather of all {n_total} result records",
+                        f"x{world} GPUs = {n_total} problems; step = solve of the shard + RCCL all-gather of all {n_total} result records",
             "problems": n_total, "problems_per_gpu": args.problems_per_gpu, "observations_per_gpu": n_obs_local,
             "record_bytes_per_gpu": 64 * n_obs_local,
             "ms_per_step": 1e3 * dt, "ms_per_step_blocks": [1e3 * b / steps for b in block_s],
@@ -350,7 +365,9 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
             "lm_iters_per_s": iters_step / dt,
             "lm_iterations_min_max": [int(its.min()), int(its.max())],
             "terminations": {clc.TERMINATION.get(int(c), str(int(c))): int((full[:, 10] == c).sum()) for c in np.unique(full[:, 10])},
-            "gather": {"collective": "ncclAllGather via clc_gather_results" if use_rccl else "torch.distributed all_gather (dry run)",
+            "step_call": ("clc_solve_batched_gather (one launch whose epilogue writes the records into the gather buffer + in-place ncclAllGather + one D2H copy, "
+                          f"fused={int(ss.last_stats.fused)})" if fused else "clc_solve_batched + clc_gather_results" if use_rccl else "clc_solve_batched + torch.distributed all_gather"),
+            "gather": {"collective": ("ncclAllGather (in place) via clc_solve_batched_gather" if fused else "ncclAllGather via clc_gather_results") if use_rccl else "torch.distributed all_gather (dry run)",
                        "library": ss.comm.library if ss.comm is not None else None, "rccl_ranks": rccl_ranks,
                        "bytes_per_rank": 96 * ss.cap, "bytes_total": 96 * ss.cap * world,
                        "records_per_rank": ss.cap, "padding_records": int((raw[:, 11] < 0).sum()),
@@ -455,7 +472,8 @@ def compact_line(out, detail_file=None):
         r = _pick(rf, ("bound", "peak", "unit", "achieved", "frac", "avg_kernel_ms", "frac_moved", "contract_64B_frac", "traffic",
                        "evaluation_passes", "us_per_pass", "moved_bytes_per_launch", "algorithmic_bytes_per_launch",
                        "traffic_measured_in_run", "served_from"))
-        r.setdefault("traffic", None)
+        for k in ("achieved", "frac", "traffic"):  # null = not measured (e.g. VALU counts that belong to other sources), never absent
+            r.setdefault(k, None)
         r["kernel"] = _short(rf.get("kernel", ""), 120)
         vi = rf.get("valu_issue")
         if isinstance(vi, dict):

@@ -29,7 +29,7 @@ EXPORTED = [
     "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
     "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",
     "clc_comm_unique_id", "clc_comm_create", "clc_comm_destroy", "clc_comm_rank", "clc_comm_world",
-    "clc_gather_results", "clc_comm_records",
+    "clc_gather_results", "clc_comm_records", "clc_solve_batched_gather",
     "clc_store_observations", "clc_select_observations", "clc_upload_batched_device", "clc_line_fit_batched_device",
     "clc_scan_to_points_device", "clc_pinned_alloc", "clc_pinned_free", "clc_store_generation", "clc_batched_host_buffers",
     "clc_get_path_info", "clc_device_info", "clc_comm_library",
@@ -92,6 +92,12 @@ class Summary(C.Structure):
         ("eval_kernel_ms", C.c_double),
         ("eval_kernel_launches", C.c_int64),
     ]
+
+
+class BatchStats(C.Structure):
+    """clc_batch_stats (include/clc.h): the local shard's totals of one clc_solve_batched_gather."""
+    _fields_ = [("problems", C.c_int64), ("evaluations", C.c_int64), ("iterations", C.c_int64), ("not_converged", C.c_int64),
+                ("fused", C.c_int32), ("pad_", C.c_int32), ("kernel_ms", C.c_double), ("solve_ms", C.c_double)]
 
 
 class PathInfo(C.Structure):
@@ -166,6 +172,8 @@ def load(path: str):
         L.clc_comm_rank.argtypes = [C.c_void_p]
         L.clc_comm_world.argtypes = [C.c_void_p]
         L.clc_comm_library.restype = C.c_char_p
+        L.clc_solve_batched_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.clc_solve_batched_gather.restype = C.c_int
         L.clc_comm_records.argtypes = [C.c_void_p]
         L.clc_comm_records.restype = C.POINTER(C.c_double)
         L.clc_get_path_info.argtypes = [C.c_void_p, C.c_void_p]

@@ -124,6 +124,41 @@ void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLau
 #undef CLC_LAUNCH_BD
 }
 
+void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl, clc_summary* d_summaries, double* d_results,
+                           double rec_base, unsigned long long* d_stats) {
+  // one workgroup per problem, the problem read from HBM once and kept in registers + LDS for its whole solve
+  const size_t P = h->n_problems;
+  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->bres.d_row);
+  const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->bres.d_desc);
+#define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
+  hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL, kResCtrl##NW>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream, \
+                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, d_summaries, d_results, nullptr, nullptr, \
+                     rec_base, d_stats)
+#define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
+  do {                                                                                                                        \
+    if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
+    else { if (bl.res_nt) CLC_LAUNCH_RES(false, true, NW, PR, PL); else CLC_LAUNCH_RES(false, false, NW, PR, PL); }            \
+  } while (0)
+  if (h->bres.lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
+  else CLC_LAUNCH_RES_V(8, kResPR512, kResPL512);
+#undef CLC_LAUNCH_RES_V
+#undef CLC_LAUNCH_RES
+}
+
+int batched_check_inputs(const char* who, const clc_options& opt, const double* poses, size_t P) {
+  if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, (std::string(who) + ": max_num_iterations < 0").c_str());
+  if (opt.use_loss && !(opt.loss_scale_factor > 0.0))
+    return fail(CLC_ERR_INVALID_ARG, (std::string(who) + ": loss_scale_factor must be > 0").c_str());
+  // all 7 P start-pose doubles finite: exponent field not all ones — an integer OR-reduction the compiler vectorises (57 344 values at C4)
+  unsigned long long bad = 0;
+  for (size_t i = 0; i < 7 * P; ++i) {
+    unsigned long long b;
+    std::memcpy(&b, &poses[i], sizeof(b));
+    bad |= (unsigned long long)(((b >> 52) & 0x7FFull) == 0x7FFull);
+  }
+  if (bad) return fail(CLC_ERR_NONFINITE, (std::string(who) + ": non-finite initial pose").c_str());
+  return CLC_OK;
+}
 
 }  // namespace clc_abi
 
@@ -146,18 +181,10 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
     return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: pass both of the handle's host buffers or neither");
   clc_options opt;
   if (opt_in) opt = *opt_in; else clc_options_default(&opt);
-  if (opt.max_num_iterations < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: max_num_iterations < 0");
-  if (opt.use_loss && !(opt.loss_scale_factor > 0.0))
-    return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched: loss_scale_factor must be > 0");
   const size_t P = h->n_problems;
-  {  // all 7 P start-pose doubles finite: exponent field not all ones — an integer OR-reduction the compiler vectorises (57 344 values at C4)
-    unsigned long long bad = 0;
-    for (size_t i = 0; i < 7 * P; ++i) {
-      unsigned long long b;
-      std::memcpy(&b, &poses[i], sizeof(b));
-      bad |= (unsigned long long)(((b >> 52) & 0x7FFull) == 0x7FFull);
-    }
-    if (bad) return fail(CLC_ERR_NONFINITE, "clc_solve_batched: non-finite initial pose");
+  {
+    const int rc = batched_check_inputs("clc_solve_batched", opt, poses, P);
+    if (rc != CLC_OK) return rc;
   }
   CLC_HIP(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
@@ -170,17 +197,6 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   // (the previous batch ended with a stream synchronisation: nothing still reads or writes the staging buffers)
   if (!in_place) std::memcpy(h->h_poses, poses, sizeof(double) * 7 * P);
   if (bl.resident) {
-    // one workgroup per problem, the problem read from HBM once and kept in registers + LDS for its whole solve
-    const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->bres.d_row);
-    const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->bres.d_desc);
-#define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
-  hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL, kResCtrl##NW>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream, \
-                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, h->d_summaries, h->d_results, nullptr, nullptr)
-#define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
-  do {                                                                                                                        \
-    if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
-    else { if (bl.res_nt) CLC_LAUNCH_RES(false, true, NW, PR, PL); else CLC_LAUNCH_RES(false, false, NW, PR, PL); }            \
-  } while (0)
     // (A completion flag raised by the last workgroup to finish, polled by the host instead of this blocking synchronisation, was
     // measured: every workgroup then needs a system-scope release before it counts itself in, which on this part writes back L2 —
     // C4 shard 0.93 -> 1.28 ms, C3 0.150 -> 0.166.  The single-workgroup solve keeps its flag: one release per solve.)
@@ -190,10 +206,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
       if (rc != CLC_OK) return rc;
       CLC_HIP(hipEventRecord(h->ev[0], h->stream));
     }
-    if (h->bres.lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
-    else CLC_LAUNCH_RES_V(8, kResPR512, kResPL512);
-#undef CLC_LAUNCH_RES_V
-#undef CLC_LAUNCH_RES
+    launch_resident_batch(h, opt, bl, h->d_summaries, h->d_results, 0.0, nullptr);
     CLC_HIP(hipGetLastError());
     if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
     // (kernel completion makes the outcomes written over PCIe visible; polling the stream with hipStreamQuery instead of this

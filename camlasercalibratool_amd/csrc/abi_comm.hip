@@ -88,7 +88,37 @@ struct clc_comm {
   double* d_recv = nullptr;
   double* h_recv = nullptr;  // pinned
   size_t cap = 0;            // records per rank the buffers hold
+  // clc_solve_batched_gather: the kernel writes this rank's records into ITS segment of d_recv (the in-place form of the all-gather);
+  // d_recv / h_recv hold one record more than world x cap — the tail: 4 running totals (clc_batch_stats' counters, never reset)
+  unsigned long long stats_seen[4] = {0, 0, 0, 0};
+  long long pad_from = -1, pad_base = -1;  // own segment's padding records are in place for this many local problems
 };
+
+static __global__ void pad_records_kernel(double* __restrict__ seg, long long n_local, long long cap) {
+  const long long k = n_local + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cap) return;
+  double* o = seg + 12 * k;
+  for (int i = 0; i < 11; ++i) o[i] = 0.0;
+  o[11] = -1.0;
+}
+
+static int comm_ensure_buffers(clc_comm* c, size_t cap_per_rank) {
+  if (cap_per_rank <= c->cap) return CLC_OK;
+  if (c->d_send) CLC_HIP(hipFree(c->d_send));
+  if (c->d_recv) CLC_HIP(hipFree(c->d_recv));
+  if (c->h_recv) CLC_HIP(hipHostFree(c->h_recv));
+  c->d_send = c->d_recv = c->h_recv = nullptr;
+  c->cap = 0;
+  c->pad_from = c->pad_base = -1;
+  const size_t n_rec = cap_per_rank * (size_t)c->world + 1;  // + the totals' tail
+  CLC_HIP(hipMalloc(&c->d_send, sizeof(clc_result_record) * cap_per_rank));
+  CLC_HIP(hipMalloc(&c->d_recv, sizeof(clc_result_record) * n_rec));
+  CLC_HIP(hipMemset(c->d_recv, 0, sizeof(clc_result_record) * n_rec));
+  CLC_HIP(hipHostMalloc(&c->h_recv, sizeof(clc_result_record) * n_rec, hipHostMallocDefault));
+  std::memset(c->stats_seen, 0, sizeof(c->stats_seen));
+  c->cap = cap_per_rank;
+  return CLC_OK;
+}
 
 extern "C" {
 
@@ -162,17 +192,11 @@ int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_r
   if (n_local > cap_per_rank) { local_rc = CLC_ERR_INVALID_ARG; local_msg = "clc_gather_results: cap_per_rank < local problems (this rank contributed padding only)"; n_local = 0; }
   else if (n_local > 0 && !h->d_results) { local_rc = CLC_ERR_NO_DATA; local_msg = "clc_gather_results: no solved batch on the handle (this rank contributed padding only)"; n_local = 0; }
   CLC_HIP(hipSetDevice(h->device));
-  if (cap_per_rank > c->cap) {
-    if (c->d_send) CLC_HIP(hipFree(c->d_send));
-    if (c->d_recv) CLC_HIP(hipFree(c->d_recv));
-    if (c->h_recv) CLC_HIP(hipHostFree(c->h_recv));
-    c->d_send = c->d_recv = c->h_recv = nullptr;
-    c->cap = 0;
-    CLC_HIP(hipMalloc(&c->d_send, sizeof(clc_result_record) * cap_per_rank));
-    CLC_HIP(hipMalloc(&c->d_recv, sizeof(clc_result_record) * cap_per_rank * (size_t)c->world));
-    CLC_HIP(hipHostMalloc(&c->h_recv, sizeof(clc_result_record) * cap_per_rank * (size_t)c->world, hipHostMallocDefault));
-    c->cap = cap_per_rank;
+  {
+    const int rc = comm_ensure_buffers(c, cap_per_rank);
+    if (rc != CLC_OK) return rc;
   }
+  c->pad_from = c->pad_base = -1;  // (this all-gather rewrites the own segment of d_recv: the fused form pads it again)
   const int threads = 256;
   hipLaunchKernelGGL(clc::pack_results_kernel, dim3((unsigned)((cap_per_rank + threads - 1) / threads)), dim3(threads), 0,
                      h->stream, h->d_results, (long long)n_local, (long long)cap_per_rank, (double)first_global_index,
@@ -186,6 +210,112 @@ int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_r
   CLC_HIP(hipStreamSynchronize(h->stream));
   if (all_records) std::memcpy(all_records, c->h_recv, bytes);
   if (local_rc != CLC_OK) return fail(local_rc, local_msg);
+  return CLC_OK;
+}
+
+int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const double* poses0, int64_t first_global_index,
+                             size_t cap_per_rank, clc_result_record* all_records, clc_batch_stats* stats) {
+  if (!c || cap_per_rank == 0 || first_global_index < 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched_gather: bad argument");
+  clc_handle* h = c->h;
+  const size_t P = h->n_problems;
+  clc_options opt;
+  if (opt_in) opt = *opt_in; else clc_options_default(&opt);
+  // This is a collective (see clc_gather_results): a rank with a LOCAL problem still enters the all-gather, with padding only, and
+  // reports afterwards.
+  int local_rc = CLC_OK;
+  std::string local_msg;
+  auto local_fail = [&](int rc, const char* msg) { if (local_rc == CLC_OK) { local_rc = rc; local_msg = msg; } };
+  if (P > cap_per_rank) local_fail(CLC_ERR_INVALID_ARG, "clc_solve_batched_gather: cap_per_rank < local problems (this rank contributed padding only)");
+  if (P > 0 && !poses0) local_fail(CLC_ERR_INVALID_ARG, "clc_solve_batched_gather: NULL start poses (this rank contributed padding only)");
+  if (P > 0 && local_rc == CLC_OK && (!h->d_btiles || !h->h_poses)) local_fail(CLC_ERR_NO_DATA, "clc_solve_batched_gather: no problems uploaded");
+  if (P > 0 && local_rc == CLC_OK) {
+    const int rc = batched_check_inputs("clc_solve_batched_gather", opt, poses0, P);
+    if (rc != CLC_OK) local_fail(rc, clc_last_error());
+  }
+  CLC_HIP(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  BatchedLaunch bl;
+  if (P > 0 && local_rc == CLC_OK) {
+    const int rc = batched_launch_setup(h, opt, &bl);
+    if (rc != CLC_OK) local_fail(rc, clc_last_error());
+  }
+  if (P > 0 && local_rc == CLC_OK && !bl.resident) {
+    // The batch does not run as the one-launch on-chip solve (a problem too large for a workgroup, points with z, explicit flags): the
+    // two-call form — same records, poses and summaries cross PCIe as well.
+    std::memcpy(h->h_poses, poses0, sizeof(double) * 7 * P);
+    int rc = clc_solve_batched(h, &opt, h->h_poses, h->h_summaries);
+    if (rc != CLC_OK) { local_fail(rc, clc_last_error()); h->results_valid = 0; }
+    const int rc2 = clc_gather_results(c, first_global_index, cap_per_rank, all_records);
+    if (stats && rc == CLC_OK) {
+      std::memset(stats, 0, sizeof(*stats));
+      for (size_t k = 0; k < P; ++k) {
+        stats->evaluations += h->h_summaries[k].num_evaluations;
+        stats->iterations += h->h_summaries[k].num_iterations;
+        stats->not_converged += h->h_summaries[k].termination == CLC_NO_CONVERGENCE || h->h_summaries[k].termination == CLC_FAILURE;
+      }
+      stats->problems = (int64_t)P;
+      stats->fused = 0;
+      stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (local_rc != CLC_OK) return fail(local_rc, local_msg.c_str());
+    return rc2;
+  }
+  {
+    const int rc = comm_ensure_buffers(c, cap_per_rank);
+    if (rc != CLC_OK) return rc;
+  }
+  const size_t n_local = local_rc == CLC_OK ? P : 0;
+  double* seg = c->d_recv + 12 * (size_t)c->rank * cap_per_rank;                               // this rank's segment of the gathered array
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(c->d_recv + 12 * cap_per_rank * (size_t)c->world);  // the tail
+  if (c->pad_from != (long long)n_local || c->pad_base != (long long)cap_per_rank) {  // (first call, or the shape changed)
+    const long long n_pad = (long long)cap_per_rank - (long long)n_local;
+    if (n_pad > 0) {
+      hipLaunchKernelGGL(pad_records_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, h->stream, seg, (long long)n_local, (long long)cap_per_rank);
+      CLC_HIP(hipGetLastError());
+    }
+    c->pad_from = (long long)n_local;
+    c->pad_base = (long long)cap_per_rank;
+  }
+  const bool timed = opt.profile_events == 1;
+  if (timed) {
+    const int rc = ensure_events(h, 2);
+    if (rc != CLC_OK) return rc;
+  }
+  if (n_local > 0) {
+    // (the previous step ended with a stream synchronisation: nothing still reads the pinned start poses)
+    if (poses0 != h->h_poses) std::memcpy(h->h_poses, poses0, sizeof(double) * 7 * P);
+    if (timed) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
+    launch_resident_batch(h, opt, bl, nullptr, seg, (double)first_global_index, d_stats);
+    CLC_HIP(hipGetLastError());
+    if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
+  }
+  // the all-gather in place (send buffer = this rank's segment of the receive buffer), then everything — the world's records and the
+  // totals' tail — to the host in one copy, one synchronisation
+  const size_t count = cap_per_rank * (sizeof(clc_result_record) / sizeof(double));
+  ncclResult_t r = rccl().AllGather(seg, c->d_recv, count, ncclDouble, c->comm, h->stream);
+  if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+  const size_t bytes = sizeof(clc_result_record) * cap_per_rank * (size_t)c->world;
+  CLC_HIP(hipMemcpyAsync(c->h_recv, c->d_recv, bytes + sizeof(clc_result_record), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));
+  h->results_valid = 0;  // (the handle's own result buffer was not written: a later clc_gather_results has nothing to send)
+  if (all_records) std::memcpy(all_records, c->h_recv, bytes);
+  const unsigned long long* now = reinterpret_cast<const unsigned long long*>(c->h_recv + 12 * cap_per_rank * (size_t)c->world);
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->evaluations = (int64_t)(now[0] - c->stats_seen[0]);
+    stats->iterations = (int64_t)(now[1] - c->stats_seen[1]);
+    stats->not_converged = (int64_t)(now[2] - c->stats_seen[2]);
+    stats->problems = (int64_t)(now[3] - c->stats_seen[3]);
+    stats->fused = 1;
+    if (timed && n_local > 0) {
+      float ms = 0.f;
+      CLC_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+      stats->kernel_ms = (double)ms;
+    }
+    stats->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  for (int i = 0; i < 4; ++i) c->stats_seen[i] = now[i];
+  if (local_rc != CLC_OK) return fail(local_rc, local_msg.c_str());
   return CLC_OK;
 }
 

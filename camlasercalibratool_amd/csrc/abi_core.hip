@@ -146,6 +146,8 @@ void clc_options_default(clc_options* o) {
   o->profile_events = 0;
 }
 
+static int create_init(clc_handle* h);
+
 int clc_create(clc_handle** out, int device) {
   if (!out) return fail(CLC_ERR_INVALID_ARG, "clc_create: out is NULL");
   *out = nullptr;
@@ -160,6 +162,15 @@ int clc_create(clc_handle** out, int device) {
   clc_handle* h = new clc_handle();
   h->device = device;
   h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // (everything below can fail half-way — a busy or full device: the handle and what it already owns are released then)
+  const int rc = create_init(h);
+  if (rc != CLC_OK) { clc_destroy(h); return rc; }
+  *out = h;
+  return CLC_OK;
+}
+
+// The allocations, the stream and the warm-up of a new handle; on any error the caller (clc_create) destroys the handle.
+static int create_init(clc_handle* h) {
   if (const char* e = std::getenv("CLC_AUTO_PATHS_DISABLE")) {
     const int m = std::atoi(e);
     if (m >= 0 && m <= 15) h->auto_disable = m;
@@ -211,10 +222,9 @@ int clc_create(clc_handle** out, int device) {
     int rc = ensure_partials(h, h->num_cus);
     if (rc == CLC_OK) rc = ensure_trace(h, 128);
     if (rc == CLC_OK) rc = ensure_events(h, 2);
-    if (rc != CLC_OK) { clc_destroy(h); return rc; }
+    if (rc != CLC_OK) return rc;
     CLC_HIP(hipStreamSynchronize(h->stream));
   }
-  *out = h;
   return CLC_OK;
 }
 

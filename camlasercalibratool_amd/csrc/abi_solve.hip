@@ -368,17 +368,22 @@ constexpr int kCoopFallback = -1000;
 int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summary* summary, clc_iteration* trace, int trace_cap,
                std::chrono::steady_clock::time_point t0) {
   if (h->coop_checked == 0) {
-    int a = 0, b = 0;
-    const hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, clc::coop_solve_kernel<true, false>, clc::COOP_THREADS, 0);
-    const hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, clc::coop_solve_kernel<false, false>, clc::COOP_THREADS, 0);
-    int c = 0, d = 0;
-    const hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, clc::coop_solve_kernel<true, false, true>, clc::COOP_THREADS, 0);
-    const hipError_t e4 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, clc::coop_solve_kernel<false, false, true>, clc::COOP_THREADS, 0);
-    if (e3 != hipSuccess || e4 != hipSuccess || c < 1 || d < 1) a = 0;
-    h->coop_checked = (e1 == hipSuccess && e2 == hipSuccess && a >= 1 && b >= 1 && h->num_cus >= clc::COOP_WGS) ? 1 : -1;
+    // every instantiation that can be launched below must fit a CU (one workgroup each: co-residency is what makes the polling safe)
+    const void* forms[] = {
+        (const void*)clc::coop_solve_kernel<true, false, false, false>, (const void*)clc::coop_solve_kernel<false, false, false, false>,
+        (const void*)clc::coop_solve_kernel<true, false, true, false>,  (const void*)clc::coop_solve_kernel<false, false, true, false>,
+        (const void*)clc::coop_solve_kernel<true, false, false, true>,  (const void*)clc::coop_solve_kernel<false, false, false, true>,
+        (const void*)clc::coop_solve_kernel<true, false, true, true>,   (const void*)clc::coop_solve_kernel<false, false, true, true>};
+    bool fits = true;
+    for (const void* f : forms) {
+      int n = 0;
+      fits = fits && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, clc::COOP_THREADS, 0) == hipSuccess && n >= 1;
+    }
+    h->coop_checked = (fits && h->num_cus >= clc::COOP_SMALL_WGS) ? 1 : -1;
     (void)hipGetLastError();
   }
   if (h->coop_checked < 0) return kCoopFallback;
+  if (h->num_cus < (h->cres.wgs > 0 ? h->cres.wgs : clc::COOP_WGS)) return kCoopFallback;  // one workgroup per CU, or not at all
   if (!h->d_board) {
     CLC_HIP(hipMalloc(&h->d_board, sizeof(clc::CoopBoard)));
     // (ordered on the handle's stream AND waited for: the caller may switch streams, clc_set_stream, before the next solve)

@@ -443,6 +443,29 @@ __device__ __forceinline__ void batched_write_outcome(const LmState& s, int p, d
   r[11] = (double)p;
 }
 
+// The records-only outcome (clc_solve_batched_gather): the clc_result_record of problem p with its GLOBAL index, written where the
+// all-gather sends from, and the shard's running totals — stats[0] += evaluation passes, [1] += iterations, [2] += problems that did
+// not converge (NO_CONVERGENCE / FAILURE), [3] += 1; device-scope atomics, never reset: the host takes differences.
+__device__ __forceinline__ void batched_write_record(const LmState& s, int p, double* __restrict__ records, const double base_index,
+                                                     unsigned long long* __restrict__ stats) {
+  clc_summary sm;
+  lm_fill_summary(s, sm);
+  const int term = sm.termination == CLC_RUNNING ? CLC_FAILURE : sm.termination;
+  double* r = records + 12 * (size_t)p;
+  for (int i = 0; i < 7; ++i) r[i] = s.x_out[i];
+  r[7] = sm.final_cost;
+  r[8] = sm.initial_cost;
+  r[9] = (double)sm.num_iterations;
+  r[10] = (double)term;
+  r[11] = base_index + (double)p;
+  if (stats != nullptr) {
+    __hip_atomic_fetch_add(stats + 0, (unsigned long long)sm.num_evaluations, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(stats + 1, (unsigned long long)(sm.num_iterations > 0 ? sm.num_iterations : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (term == CLC_NO_CONVERGENCE || term == CLC_FAILURE) __hip_atomic_fetch_add(stats + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(stats + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // A problem writes its outcome in the launch in which it terminates (no separate finish launch).
 static __global__ __launch_bounds__(64) void batched_lm_kernel(const double* __restrict__ partials, const int blocks_per_problem,
                                   LmState* __restrict__ states, const clc_options opt,

@@ -151,6 +151,16 @@ class ShardSolver:
         out = self.comm.gather_results(self.lo, self.cap, copy=copy)
         return order_records(out, self.n_problems) if ordered else out
 
+    def solve_gather(self, poses0: np.ndarray, options=None, ordered: bool = True, copy: bool = True) -> np.ndarray:
+        """The same step as solve() through ONE call, clc_solve_batched_gather (include/clc.h): the kernel's epilogue writes the result
+        records into the gather buffer, all-gather in place, one copy to the host — no per-problem poses / summaries cross PCIe.
+        -> the records as solve(); the local shard's totals (evaluation passes, iterations, not converged) in `last_stats`.
+        Needs the RCCL communicator (use_rccl=True)."""
+        assert self.comm is not None, "solve_gather() needs the RCCL communicator; dry runs on a CPU process group use solve()"
+        self.last_poses, self.last_summaries = None, None
+        out, self.last_stats = self.comm.solve_gather(poses0 if self.hi > self.lo else None, self.lo, self.cap, options, copy=copy)
+        return order_records(out, self.n_problems) if ordered else out
+
     def close(self):
         if self.comm is not None:
             self.comm.close()

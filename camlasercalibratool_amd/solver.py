@@ -87,6 +87,31 @@ class Comm:
               "clc_gather_results")
         return np.ctypeslib.as_array(self._L.clc_comm_records(self._c), shape=(n, RESULT_RECORD))
 
+    def solve_gather(self, poses0: np.ndarray, first_global_index: int, cap_per_rank: int, options: Optional[Options] = None,
+                     copy: bool = True):
+        """clc_solve_batched_gather: the solver's uploaded shard solved by ONE launch whose epilogue writes the result records into
+        the gather buffer, all-gather in place, one copy to the host -> (records [world*cap_per_rank, 12], BatchStats of the local
+        shard).  poses0: [P_local, 7] start poses (None: the handle's pinned buffer, batched_buffers()[0], already filled).
+        copy=False: `records` is a view of the communicator's pinned host buffer (valid until the next gather)."""
+        n = self.world * cap_per_rank
+        st = _capi.BatchStats()
+        o = options or default_options()
+        if poses0 is None:
+            pp = C.POINTER(C.c_double)()
+            if self._solver.num_problems > 0:
+                check(self._L.clc_batched_host_buffers(self._solver._h, C.byref(pp), None), "clc_batched_host_buffers")
+            p_arg = C.cast(pp, C.c_void_p)
+        else:
+            poses = np.ascontiguousarray(poses0, dtype=np.float64)
+            assert poses.size == 7 * self._solver.num_problems, "one start pose per local problem"
+            p_arg = C.cast(dptr(poses), C.c_void_p)
+        out = np.empty((n, RESULT_RECORD)) if copy else None
+        check(self._L.clc_solve_batched_gather(self._c, C.byref(o), p_arg, C.c_int64(first_global_index), C.c_size_t(cap_per_rank),
+                                               dptr(out) if copy else None, C.byref(st)), "clc_solve_batched_gather")
+        if not copy:
+            out = np.ctypeslib.as_array(self._L.clc_comm_records(self._c), shape=(n, RESULT_RECORD))
+        return out, st
+
     def close(self):
         if getattr(self, "_c", None) is not None and self._c:
             self._L.clc_comm_destroy(self._c)

@@ -221,6 +221,8 @@ class Session {
     // `obs` is read here; it is read AGAIN only if another Session (or one of the free functions) has replaced the stored scans
     // on the shared context before a later call of this one — keep it alive for as long as the Session (no copy is made: the
     // reference-size inputs are small, a C2-size one is 53 MB).
+    // A temporary cannot be kept alive: `Session s(load_obs());` does not compile (the re-store would read freed memory).
+    explicit Session(std::vector<Oberserve>&&) = delete;
     explicit Session(const std::vector<Oberserve>& obs) : obs_(&obs), ok_(false), generation_(-1)
     {
         Handle H;  // locked first: flatten gathers into the process-wide pinned buffers
@@ -228,8 +230,10 @@ class Session {
         ok_ = store(H.h);
     }
 
-    // false after a call that could not run (no device, a store / select / solve error — the message went to std::cerr): the
-    // reference's functions return void, so a caller that wants to know asks here.  Tlc / Tcl are left unchanged by such a call.
+    // The outcome of the LAST call (constructor, ClosedSolution, Calibration): false when it could not run or finish (no device, a
+    // store / select / solve / analysis error — the message went to std::cerr), true again after the next call that succeeds.  The
+    // reference's functions return void, so a caller that wants to know asks here.  Tlc / Tcl are left unchanged by a call that
+    // failed before its result (a failure of the analysis pass alone leaves the refined Tcl in place).
     bool ok() const { return ok_; }
 
     // Closed-form initial guess of Tlc (camera -> laser).  Reference: src/LaseCamCalCeres.cpp:112-203.
@@ -256,6 +260,7 @@ class Session {
         }
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tlc(i, j) = T[4 * i + j];  // :198-200
         std::cout <<"------- Closed-form solution Tlc: -------\n" << Tlc <<std::endl;      // :202
+        ok_ = true;
     }
 
     // Nonlinear refinement of Tcl (laser -> camera).  Reference: src/LaseCamCalCeres.cpp:213-383.
@@ -286,7 +291,8 @@ class Session {
                   << "\n  Initial cost         " << sum.initial_cost << "\n  Final cost           " << sum.final_cost
                   << "\n  Iterations           " << sum.num_iterations << " (successful " << sum.num_successful_steps - 1
                   << ", unsuccessful " << sum.num_unsuccessful_steps << ")\n  Evaluation passes    " << sum.num_evaluations
-                  << "\n  Time (ms)            " << sum.solve_ms << "\n  Termination          " << term[sum.termination] << std::endl;  // :309
+                  << "\n  Time (ms)            " << sum.solve_ms << "\n  Termination          "
+                  << (sum.termination >= 0 && sum.termination < (int)(sizeof(term) / sizeof(term[0])) ? term[sum.termination] : "?") << std::endl;  // :309
 
         // write-back, :311-314 (Quaterniond::toRotationMatrix on the unit quaternion)
         {
@@ -302,10 +308,18 @@ class Session {
         /// =============================  analysis code (:316-381) ==============================
         // second pass without loss and without the board-edge terms: re-selected on the device, nothing crosses PCIe
         if (use_boundary_constraint && use_linefitting_data) {
-            if (clc_select_observations(H.h, use_linefitting_data, 0, NULL) != CLC_OK) return;
+            if (clc_select_observations(H.h, use_linefitting_data, 0, NULL) != CLC_OK) {
+                std::cerr << "[clc] analysis pass skipped: " << clc_last_error() << std::endl;
+                ok_ = false;
+                return;
+            }
         }
         double Hm[36], b[6], chi, sv[6], V[36]; int n = 0;
-        if (clc_information(H.h, pose, Hm, b, &chi, sv, V, &n) != CLC_OK) { std::cerr << "[clc] " << clc_last_error() << std::endl; return; }
+        if (clc_information(H.h, pose, Hm, b, &chi, sv, V, &n) != CLC_OK) {
+            std::cerr << "[clc] analysis pass failed: " << clc_last_error() << std::endl;
+            ok_ = false;
+            return;
+        }
         std::cout << "----- H singular values--------:\n";
         for (int i = 0; i < 6; ++i) std::cout << sv[i] << "\n";
         if (n > 0) {
@@ -314,6 +328,7 @@ class Session {
             for (int r = 0; r < 6; ++r) { for (int c = 6 - n; c < 6; ++c) std::cout << V[6 * r + c] << " "; std::cout << "\n"; }
         }
         std::cout <<"\nrecover chi2: " <<chi / 2. << std::endl;
+        ok_ = true;
     }
 
  private:

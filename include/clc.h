@@ -394,6 +394,29 @@ int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_r
                        clc_result_record* all_records);
 const clc_result_record* clc_comm_records(const clc_comm* c);
 
+/* clc_solve_batched + clc_gather_results as ONE enqueue — the step of a sharded batch (BASELINE.json configs[3]) when only the
+ * gathered records are wanted.  The on-chip batched kernel writes every local problem's result record, global index
+ * first_global_index + k, straight into this rank's segment of the communicator's gather buffer; the all-gather (in place) and ONE
+ * copy of the gathered records to the host follow on the same stream, and the host synchronises once.  No per-problem poses or
+ * summaries cross PCIe and nothing is packed or copied in between; what the two-call form returns per problem is in the records
+ * (pose, costs, iterations, termination), and the local shard's totals come back in `stats` (nullable).
+ * poses0: host, 7 doubles per LOCAL problem of the handle's uploaded batch (clc_upload_batched), or the handle's own pinned buffer
+ * (clc_batched_host_buffers) already filled.  all_records / clc_comm_records() as in clc_gather_results.  A batch that does not run as
+ * the one-launch on-chip solve falls back to the two calls (stats->fused = 0).  Collective call; same error convention as
+ * clc_gather_results (a rank with a local error still takes part, with padding records, and reports afterwards). */
+typedef struct clc_batch_stats {
+  int64_t problems;        /* local problems solved by this call */
+  int64_t evaluations;     /* sum of their evaluation passes (clc_summary.num_evaluations) */
+  int64_t iterations;      /* sum of their LM iterations */
+  int64_t not_converged;   /* of them: terminated with CLC_NO_CONVERGENCE or CLC_FAILURE */
+  int32_t fused;           /* 1: one launch + in-place all-gather + one copy; 0: the two-call fall-back ran */
+  int32_t pad_;
+  double kernel_ms;        /* profile_events = 1: HIP event pair around the solve launch (fused form) */
+  double solve_ms;         /* host wall time of the call */
+} clc_batch_stats;
+int clc_solve_batched_gather(clc_comm* c, const clc_options* opt, const double* poses0, int64_t first_global_index,
+                             size_t cap_per_rank, clc_result_record* all_records, clc_batch_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif
