@@ -125,7 +125,7 @@ void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLau
 }
 
 void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl, clc_summary* d_summaries, double* d_results,
-                           double rec_base, unsigned long long* d_stats) {
+                           double rec_base, double* rec_host, long long seg_off, unsigned long long goal) {
   // one workgroup per problem, the problem read from HBM once and kept in registers + LDS for its whole solve
   const size_t P = h->n_problems;
   const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->bres.d_row);
@@ -133,7 +133,7 @@ void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedL
 #define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL, kResCtrl##NW>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream, \
                      h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, d_summaries, d_results, nullptr, nullptr, \
-                     rec_base, d_stats)
+                     rec_base, rec_host, seg_off, goal)
 #define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
   do {                                                                                                                        \
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
@@ -206,7 +206,7 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
       if (rc != CLC_OK) return rc;
       CLC_HIP(hipEventRecord(h->ev[0], h->stream));
     }
-    launch_resident_batch(h, opt, bl, h->d_summaries, h->d_results, 0.0, nullptr);
+    launch_resident_batch(h, opt, bl, h->d_summaries, h->d_results, 0.0, nullptr, 0, 0);
     CLC_HIP(hipGetLastError());
     if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
     // (kernel completion makes the outcomes written over PCIe visible; polling the stream with hipStreamQuery instead of this

@@ -85,11 +85,14 @@ struct clc_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
   double* d_send = nullptr;
-  double* d_recv = nullptr;
-  double* h_recv = nullptr;  // pinned
+  double* d_recv = nullptr;  // = d_base + 12: the gathered records
+  double* h_recv = nullptr;  // = h_base + 12 (pinned)
+  double* d_base = nullptr;  // the allocations: ONE record in front of the gathered array holds the running totals of
+  double* h_base = nullptr;  // clc_solve_batched_gather.  h_base is mapped: the kernel writes this rank's records and the totals there itself
+  double* hd_base = nullptr; // device address of h_base
   size_t cap = 0;            // records per rank the buffers hold
   // clc_solve_batched_gather: the kernel writes this rank's records into ITS segment of d_recv (the in-place form of the all-gather);
-  // d_recv / h_recv hold one record more than world x cap — the tail: 4 running totals (clc_batch_stats' counters, never reset)
+  // the record in front of d_recv / h_recv: 4 running totals (clc_batch_stats' counters, never reset)
   unsigned long long stats_seen[4] = {0, 0, 0, 0};
   long long pad_from = -1, pad_base = -1;  // own segment's padding records are in place for this many local problems
 };
@@ -105,16 +108,20 @@ static __global__ void pad_records_kernel(double* __restrict__ seg, long long n_
 static int comm_ensure_buffers(clc_comm* c, size_t cap_per_rank) {
   if (cap_per_rank <= c->cap) return CLC_OK;
   if (c->d_send) CLC_HIP(hipFree(c->d_send));
-  if (c->d_recv) CLC_HIP(hipFree(c->d_recv));
-  if (c->h_recv) CLC_HIP(hipHostFree(c->h_recv));
-  c->d_send = c->d_recv = c->h_recv = nullptr;
+  if (c->d_base) CLC_HIP(hipFree(c->d_base));
+  if (c->h_base) CLC_HIP(hipHostFree(c->h_base));
+  c->d_send = c->d_recv = c->h_recv = c->d_base = c->h_base = c->hd_base = nullptr;
   c->cap = 0;
   c->pad_from = c->pad_base = -1;
-  const size_t n_rec = cap_per_rank * (size_t)c->world + 1;  // + the totals' tail
+  const size_t n_rec = cap_per_rank * (size_t)c->world + 1;  // the totals' record + the gathered array
   CLC_HIP(hipMalloc(&c->d_send, sizeof(clc_result_record) * cap_per_rank));
-  CLC_HIP(hipMalloc(&c->d_recv, sizeof(clc_result_record) * n_rec));
-  CLC_HIP(hipMemset(c->d_recv, 0, sizeof(clc_result_record) * n_rec));
-  CLC_HIP(hipHostMalloc(&c->h_recv, sizeof(clc_result_record) * n_rec, hipHostMallocDefault));
+  CLC_HIP(hipMalloc(&c->d_base, sizeof(clc_result_record) * n_rec));
+  CLC_HIP(hipMemset(c->d_base, 0, sizeof(clc_result_record) * n_rec));
+  CLC_HIP(hipHostMalloc(&c->h_base, sizeof(clc_result_record) * n_rec, hipHostMallocMapped));
+  CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_base), c->h_base, 0));
+  std::memset(c->h_base, 0, sizeof(clc_result_record));
+  c->d_recv = c->d_base + 12;
+  c->h_recv = c->h_base + 12;
   std::memset(c->stats_seen, 0, sizeof(c->stats_seen));
   c->cap = cap_per_rank;
   return CLC_OK;
@@ -168,8 +175,8 @@ void clc_comm_destroy(clc_comm* c) {
   }
   if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
   if (c->d_send) (void)hipFree(c->d_send);
-  if (c->d_recv) (void)hipFree(c->d_recv);
-  if (c->h_recv) (void)hipHostFree(c->h_recv);
+  if (c->d_base) (void)hipFree(c->d_base);
+  if (c->h_base) (void)hipHostFree(c->h_base);
   delete c;
 }
 
@@ -229,7 +236,23 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const doubl
   if (P > 0 && !poses0) local_fail(CLC_ERR_INVALID_ARG, "clc_solve_batched_gather: NULL start poses (this rank contributed padding only)");
   if (P > 0 && local_rc == CLC_OK && (!h->d_btiles || !h->h_poses)) local_fail(CLC_ERR_NO_DATA, "clc_solve_batched_gather: no problems uploaded");
   if (P > 0 && local_rc == CLC_OK) {
-    const int rc = batched_check_inputs("clc_solve_batched_gather", opt, poses0, P);
+    // options as clc_solve_batched checks them; the start poses go into the handle's pinned buffer (what the kernel reads) and are
+    // checked for non-finite values in the same pass over them.  (The previous step ended with a stream synchronisation: nothing
+    // still reads that buffer.)
+    int rc = batched_check_inputs("clc_solve_batched_gather", opt, poses0, 0);
+    if (rc == CLC_OK) {
+      unsigned long long bad = 0;
+      double* dst = h->h_poses;
+      const bool copy = poses0 != dst;
+      for (size_t i = 0; i < 7 * P; ++i) {
+        const double v = poses0[i];
+        unsigned long long b;
+        std::memcpy(&b, &v, sizeof(b));
+        bad |= (unsigned long long)(((b >> 52) & 0x7FFull) == 0x7FFull);
+        if (copy) dst[i] = v;
+      }
+      if (bad) rc = fail(CLC_ERR_NONFINITE, "clc_solve_batched_gather: non-finite initial pose");
+    }
     if (rc != CLC_OK) local_fail(rc, clc_last_error());
   }
   CLC_HIP(hipSetDevice(h->device));
@@ -242,8 +265,7 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const doubl
   if (P > 0 && local_rc == CLC_OK && !bl.resident) {
     // The batch does not run as the one-launch on-chip solve (a problem too large for a workgroup, points with z, explicit flags): the
     // two-call form — same records, poses and summaries cross PCIe as well.
-    std::memcpy(h->h_poses, poses0, sizeof(double) * 7 * P);
-    int rc = clc_solve_batched(h, &opt, h->h_poses, h->h_summaries);
+    int rc = clc_solve_batched(h, &opt, h->h_poses, h->h_summaries);  // (the start poses are in the pinned buffer already)
     if (rc != CLC_OK) { local_fail(rc, clc_last_error()); h->results_valid = 0; }
     const int rc2 = clc_gather_results(c, first_global_index, cap_per_rank, all_records);
     if (stats && rc == CLC_OK) {
@@ -265,13 +287,18 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const doubl
     if (rc != CLC_OK) return rc;
   }
   const size_t n_local = local_rc == CLC_OK ? P : 0;
-  double* seg = c->d_recv + 12 * (size_t)c->rank * cap_per_rank;                               // this rank's segment of the gathered array
-  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(c->d_recv + 12 * cap_per_rank * (size_t)c->world);  // the tail
+  const long long seg_off = 12ll * (long long)c->rank * (long long)cap_per_rank;  // this rank's segment of the gathered array (doubles)
+  double* seg = c->d_recv + seg_off;
   if (c->pad_from != (long long)n_local || c->pad_base != (long long)cap_per_rank) {  // (first call, or the shape changed)
     const long long n_pad = (long long)cap_per_rank - (long long)n_local;
-    if (n_pad > 0) {
+    if (n_pad > 0) {  // the padding records of this rank's segment: device (what the all-gather sends) and host
       hipLaunchKernelGGL(pad_records_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, h->stream, seg, (long long)n_local, (long long)cap_per_rank);
       CLC_HIP(hipGetLastError());
+      for (size_t k = n_local; k < cap_per_rank; ++k) {
+        double* o = c->h_recv + seg_off + 12 * k;
+        for (int i = 0; i < 11; ++i) o[i] = 0.0;
+        o[11] = -1.0;
+      }
     }
     c->pad_from = (long long)n_local;
     c->pad_base = (long long)cap_per_rank;
@@ -282,24 +309,30 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const doubl
     if (rc != CLC_OK) return rc;
   }
   if (n_local > 0) {
-    // (the previous step ended with a stream synchronisation: nothing still reads the pinned start poses)
-    if (poses0 != h->h_poses) std::memcpy(h->h_poses, poses0, sizeof(double) * 7 * P);
     if (timed) CLC_HIP(hipEventRecord(h->ev[0], h->stream));
-    launch_resident_batch(h, opt, bl, nullptr, seg, (double)first_global_index, d_stats);
+    // the last workgroup to finish (totals' arrival count == goal) copies the totals to the host twin
+    launch_resident_batch(h, opt, bl, nullptr, c->d_base, (double)first_global_index, c->hd_base, seg_off, c->stats_seen[3] + (unsigned long long)P);
     CLC_HIP(hipGetLastError());
     if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
   }
-  // the all-gather in place (send buffer = this rank's segment of the receive buffer), then everything — the world's records and the
-  // totals' tail — to the host in one copy, one synchronisation
+  // The all-gather in place (send buffer = this rank's segment of the receive buffer).  This rank's own records and the totals are in
+  // host memory already — the kernel wrote them there —, so only the OTHER ranks' segments are copied down (world size 1: nothing);
+  // one synchronisation.
   const size_t count = cap_per_rank * (sizeof(clc_result_record) / sizeof(double));
   ncclResult_t r = rccl().AllGather(seg, c->d_recv, count, ncclDouble, c->comm, h->stream);
   if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
-  const size_t bytes = sizeof(clc_result_record) * cap_per_rank * (size_t)c->world;
-  CLC_HIP(hipMemcpyAsync(c->h_recv, c->d_recv, bytes + sizeof(clc_result_record), hipMemcpyDeviceToHost, h->stream));
-  CLC_HIP(hipStreamSynchronize(h->stream));
+  const size_t seg_bytes = sizeof(clc_result_record) * cap_per_rank;
+  const size_t bytes = seg_bytes * (size_t)c->world;
+  if (c->rank > 0) CLC_HIP(hipMemcpyAsync(c->h_recv, c->d_recv, seg_bytes * (size_t)c->rank, hipMemcpyDeviceToHost, h->stream));
+  if (c->rank + 1 < c->world)
+    CLC_HIP(hipMemcpyAsync(c->h_recv + seg_off + 12 * cap_per_rank, c->d_recv + seg_off + 12 * cap_per_rank,
+                           seg_bytes * (size_t)(c->world - 1 - c->rank), hipMemcpyDeviceToHost, h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));  // (kernel completion makes what it wrote over PCIe visible)
   h->results_valid = 0;  // (the handle's own result buffer was not written: a later clc_gather_results has nothing to send)
   if (all_records) std::memcpy(all_records, c->h_recv, bytes);
-  const unsigned long long* now = reinterpret_cast<const unsigned long long*>(c->h_recv + 12 * cap_per_rank * (size_t)c->world);
+  unsigned long long now[4];
+  std::memcpy(now, c->h_base, sizeof(now));
+  if (n_local == 0) std::memcpy(now, c->stats_seen, sizeof(now));  // (no launch: the totals stand)
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->evaluations = (int64_t)(now[0] - c->stats_seen[0]);

@@ -312,10 +312,12 @@ struct BatchedLaunch {
 int batched_launch_setup(clc_handle* h, const clc_options& opt, BatchedLaunch* bl);
 void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl);
 // ONE launch of resident_solve_kernel over the handle's batch (bl.resident) on the handle's stream; start poses from the handle's pinned
-// buffer.  d_summaries != nullptr: outcomes into d_poses / d_summaries / d_results (clc_solve_batched); d_summaries == nullptr: the
-// records-only form — records with global index rec_base + k into d_results, totals into d_stats (clc_solve_batched_gather).
+// buffer.  d_summaries != nullptr: outcomes into d_poses / d_summaries / d_results (clc_solve_batched).  d_summaries == nullptr: the
+// records-only form (clc_solve_batched_gather) — d_results / rec_host = the communicator's gather buffer and its pinned host twin
+// ([totals record][gathered array]), this rank's segment seg_off doubles into the array, global index rec_base + k, `goal` = the
+// totals' arrival count at the end of this launch (batched_write_record, clc_kernels.hpp).
 void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl, clc_summary* d_summaries, double* d_results,
-                           double rec_base, unsigned long long* d_stats);
+                           double rec_base, double* rec_host, long long seg_off, unsigned long long goal);
 // the checks clc_solve_batched makes on its options and start poses (shared with clc_solve_batched_gather); CLC_OK or the error set
 int batched_check_inputs(const char* who, const clc_options& opt, const double* poses, size_t n_problems);
 

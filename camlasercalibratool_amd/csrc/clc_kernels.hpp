@@ -443,26 +443,38 @@ __device__ __forceinline__ void batched_write_outcome(const LmState& s, int p, d
   r[11] = (double)p;
 }
 
-// The records-only outcome (clc_solve_batched_gather): the clc_result_record of problem p with its GLOBAL index, written where the
-// all-gather sends from, and the shard's running totals — stats[0] += evaluation passes, [1] += iterations, [2] += problems that did
-// not converge (NO_CONVERGENCE / FAILURE), [3] += 1; device-scope atomics, never reset: the host takes differences.
-__device__ __forceinline__ void batched_write_record(const LmState& s, int p, double* __restrict__ records, const double base_index,
-                                                     unsigned long long* __restrict__ stats) {
+// The records-only outcome (clc_solve_batched_gather).  `base` / `host_base`: the communicator's gather buffer in device memory and
+// its pinned host twin, both laid out [one record of running totals][the gathered array]; this rank's segment of the array starts
+// seg_off doubles in.  The clc_result_record of problem p, GLOBAL index base_index + p, is written twice: into the device segment
+// (where the in-place all-gather sends from) and into the host segment (this rank's share of the result needs no copy afterwards).
+// Totals (64-bit, device-scope atomics, never reset: the host takes differences): [0] += evaluation passes, [1] += iterations,
+// [2] += problems that did not converge, [3] += 1.  The workgroup that brings [3] to `goal` is the last of its launch: everybody else's
+// atomics are complete by then (returning atomics, waited for before the count moves), and it copies the four totals to the host twin.
+__device__ __forceinline__ void batched_write_record(const LmState& s, int p, double* __restrict__ base, double* __restrict__ host_base,
+                                                     const long long seg_off, const double base_index, const unsigned long long goal) {
   clc_summary sm;
   lm_fill_summary(s, sm);
   const int term = sm.termination == CLC_RUNNING ? CLC_FAILURE : sm.termination;
-  double* r = records + 12 * (size_t)p;
-  for (int i = 0; i < 7; ++i) r[i] = s.x_out[i];
-  r[7] = sm.final_cost;
-  r[8] = sm.initial_cost;
-  r[9] = (double)sm.num_iterations;
-  r[10] = (double)term;
-  r[11] = base_index + (double)p;
-  if (stats != nullptr) {
-    __hip_atomic_fetch_add(stats + 0, (unsigned long long)sm.num_evaluations, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(stats + 1, (unsigned long long)(sm.num_iterations > 0 ? sm.num_iterations : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (term == CLC_NO_CONVERGENCE || term == CLC_FAILURE) __hip_atomic_fetch_add(stats + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(stats + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double v[12];
+  for (int i = 0; i < 7; ++i) v[i] = s.x_out[i];
+  v[7] = sm.final_cost;
+  v[8] = sm.initial_cost;
+  v[9] = (double)sm.num_iterations;
+  v[10] = (double)term;
+  v[11] = base_index + (double)p;
+  double* r = base + 12 + seg_off + 12 * (size_t)p;
+  double* rh = host_base + 12 + seg_off + 12 * (size_t)p;
+  for (int i = 0; i < 12; ++i) { r[i] = v[i]; rh[i] = v[i]; }
+  unsigned long long* stats = reinterpret_cast<unsigned long long*>(base);
+  const unsigned long long a0 = __hip_atomic_fetch_add(stats + 0, (unsigned long long)sm.num_evaluations, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long a1 = __hip_atomic_fetch_add(stats + 1, (unsigned long long)(sm.num_iterations > 0 ? sm.num_iterations : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long a2 = __hip_atomic_fetch_add(stats + 2, (term == CLC_NO_CONVERGENCE || term == CLC_FAILURE) ? 1ull : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" :: "v"(a0), "v"(a1), "v"(a2) : "memory");  // the three have been performed before the count moves
+  const unsigned long long arrived = __hip_atomic_fetch_add(stats + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  if (arrived == goal) {
+    unsigned long long* hs = reinterpret_cast<unsigned long long*>(host_base);
+    for (int i = 0; i < 3; ++i) hs[i] = __hip_atomic_load(stats + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hs[3] = arrived;
   }
 }
 

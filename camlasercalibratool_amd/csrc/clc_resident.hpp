@@ -189,7 +189,7 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
 // The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
 // uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read).
 // trace (nullable; single-problem launches only): the iteration records of clc_solve.
-// rec_base, stats: see batched_write_record (clc_kernels.hpp) — used when summaries == nullptr.
+// rec_base, rec_host, rec_seg_off, rec_goal: see batched_write_record (clc_kernels.hpp) — used when summaries == nullptr.
 // host_done (nullable): set to 1 in host memory, system-scope release, once the outcome of EVERY problem of the launch is written
 // (done_count: device counter of finished workgroups, zero between launches; nullable for a single-workgroup launch) — the host
 // polls it instead of blocking on the stream.
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, clc_iteration* __restrict__ trace,
     const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results,
     int32_t* __restrict__ host_done, unsigned int* __restrict__ done_count, const double rec_base = 0.0,
-    unsigned long long* __restrict__ stats = nullptr) {
+    double* __restrict__ rec_host = nullptr, const long long rec_seg_off = 0, const unsigned long long rec_goal = 0) {
   constexpr bool RES_LEAN = NW == 4;  // the controller next to 92 VGPRs of points: the small-footprint form (clc_controller.hpp)
   // How the pass gets its pose: CTRL 0 — x_eval from the LDS state, every wave turning the quaternion into a wave-uniform (SGPR)
   // rotation itself; CTRL 1 — as the cooperative kernel: rotation + translation + status published by the controller (six 16-byte
@@ -519,10 +519,11 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     }
     if (lane == 0) {
       if (st.status == CLC_RUNNING) st.status = CLC_FAILURE;  // unreachable: the controller stops at the iteration cap
-      // summaries == nullptr: the records-only form (clc_solve_batched_gather) — the problem's result record, global index rec_base +
-      // prob, goes straight into the communicator's gather buffer and nothing is written to host memory; the shard's totals in `stats`
+      // summaries == nullptr: the records-only form (clc_solve_batched_gather) — `results` / `rec_host` are the communicator's gather
+      // buffer and its pinned host twin: the problem's result record, global index rec_base + prob, goes straight into this rank's
+      // segment of both, the shard's totals into their leading record; no pose, no summary
       if (summaries != nullptr) batched_write_outcome(st, prob, poses, summaries, results);
-      else batched_write_record(st, prob, results, rec_base, stats);
+      else batched_write_record(st, prob, results, rec_host, rec_seg_off, rec_base, rec_goal);
       if (host_done != nullptr) {
         bool last = true;
         if (done_count != nullptr) {
