@@ -833,11 +833,14 @@ def main():
         xb = solver.pose_plus(np.stack([sd.pose7_from_T(g) for g in gts]), np.random.default_rng(1).normal(size=(Pb, 6)) * 0.05)
         solver.upload_batched(np.concatenate(recs), offb)
         tb = []
-        for _ in range(12):
+        pin_poses, _ = solver.batched_buffers()  # the handle's pinned arrays: start poses in, results out, no staging copies
+        for _ in range(25):
             t1 = time.perf_counter()
-            pb, smb = solver.solve_batched(xb)
+            pin_poses[:] = xb
+            pb, smb = solver.solve_batched_inplace()
             tb.append(time.perf_counter() - t1)
-        dtb = float(np.median(tb[2:]))
+        dtb = float(np.median(tb[5:]))
+        pb = pb.copy()
         evb = sum(smb[k].num_evaluations * int(offb[k + 1] - offb[k]) for k in range(Pb))
         out["batched_c3"] = {
             "workload": "C3: 1024 independent T_cl problems x 10000 observations (655 MB), start 5 cm / 3 deg off the truth",

@@ -470,10 +470,10 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
     // ---- the pose of this pass (rotation + translation) and whether there is one: 7 broadcast 16-byte reads ----
     RowPlane q;
     {
-      const v2d* pb = reinterpret_cast<const v2d*>(sh_pub);
-      asm volatile("" : "+v"(pb));
-      const v2d p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3], p4 = pb[4], p5 = pb[5];
-      const int status = reinterpret_cast<const int*>(pb + 6)[0];
+      // (ONE batch of ds_read_b128: the status word rides in the seventh; all seven are back before the branch)
+      const lds_cv2d* pb = lds_opaque(sh_pub);
+      const v2d p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3], p4 = pb[4], p5 = pb[5], p6 = pb[6];
+      const int status = __double2loint(p6[0]);
       if (status != CLC_RUNNING) break;  // (wave-uniform: terminated, or the launch aborted)
       // R row-major = p0[0] p0[1] p1[0] | p1[1] p2[0] p2[1] | p3[0] p3[1] p4[0];  t = p4[1] p5[0] p5[1]
       q.nx = pl_nx; q.ny = pl_ny; q.nz = pl_nz; q.s2 = pl_s2;

@@ -267,6 +267,25 @@ constexpr int FLAG_RESIDENT_WG512 = 8192;    // resident layout over 512 lanes p
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
+// Loads from LDS (or from device memory) that must stay INSIDE a loop, issued where they are written.  Passing the POINTER through an
+// empty asm does that, but a generic pointer that went through an asm has lost its address space: the loads become FLAT loads — in
+// round 4 the pose reads at the head of every on-chip pass and the 14 reads of the totals in the LM controller were flat loads of LDS
+// (vmcnt AND lgkmcnt, a longer round trip than ds_read, and their wait also waits for every global access in flight).  Here the
+// OFFSET is what the compiler cannot see through; the pointer keeps its address space: ds_read_b128 / global_load.
+typedef __attribute__((address_space(3))) const v2d lds_cv2d;
+typedef __attribute__((address_space(1))) const v2d glb_cv2d;
+typedef __attribute__((address_space(1))) const double glb_cdouble;
+__device__ __forceinline__ const lds_cv2d* lds_opaque(const void* shared_ptr) {
+  unsigned int off = 0;
+  asm volatile("" : "+v"(off));
+  return reinterpret_cast<const lds_cv2d*>(((__attribute__((address_space(3))) const char*)shared_ptr) + off);
+}
+__device__ __forceinline__ glb_cdouble* global_opaque(const double* device_ptr) {
+  unsigned int off = 0;
+  asm volatile("" : "+v"(off));
+  return reinterpret_cast<glb_cdouble*>(((__attribute__((address_space(1))) const char*)device_ptr) + off);
+}
+
 // compact layout (clc_stream.hpp): tiles of 128 points x[128], y[128], z[128] (FP64) + gid[128] (u32); one 48-byte group entry per scan
 constexpr int CTILE_DOUBLES = 3 * TILE + TILE / 2;  // 448 doubles = 3 584 B
 constexpr int GROUP_DOUBLES = 6;                    // {n.x, n.y, n.z, d, scale, 0}: 48 B, 16-B aligned

@@ -113,11 +113,10 @@ __device__ __forceinline__ void lmu_flush_xout(LmU& S, LmState& st, const int la
 
 // 28 wave-uniform totals from an LDS buffer: 14 broadcast 16-byte reads (~20 cycles each for a wave that runs alone).
 __device__ __forceinline__ void lmu_read_totals(const double* buf, double* T) {
-  const double* tp = buf;
-  asm volatile("" : "+v"(tp));  // (a per-lane address: the reads stay LDS reads issued HERE, in one batch)
+  const lds_cv2d* tp = lds_opaque(buf);  // (a per-lane address: the reads stay ds_read_b128 issued HERE, in one batch)
 #pragma unroll
   for (int i = 0; i < 14; ++i) {
-    const v2d v = reinterpret_cast<const v2d*>(tp)[i];
+    const v2d v = tp[i];
     T[2 * i] = v[0];
     T[2 * i + 1] = v[1];
   }

@@ -330,10 +330,9 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     // plane of the lane's scan (idle lanes: zeros, scale 0 — their moments are finite and expand to nothing)
     double nx, ny, nz, pd, ps;
     {
-      const double* g2 = gp;
-      asm volatile("" : "+v"(g2));  // (an address the compiler cannot prove loop-invariant: the loads stay in the pass)
-      const v2d a = *reinterpret_cast<const v2d*>(g2);
-      const v2d b = *reinterpret_cast<const v2d*>(g2 + 2);
+      glb_cdouble* g2 = global_opaque(gp);  // (an address the compiler cannot prove loop-invariant: the loads stay in the pass, as global loads)
+      const v2d a = *reinterpret_cast<glb_cv2d*>(g2);
+      const v2d b = *reinterpret_cast<glb_cv2d*>(g2 + 2);
       const double s5 = g2[4];
       const bool on = cnt > 0;
       nx = on ? a[0] : 0.0; ny = on ? a[1] : 0.0; nz = on ? b[0] : 0.0; pd = on ? b[1] : 0.0; ps = on ? s5 : 0.0;
@@ -346,8 +345,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     }
     RowPlane q;
     if (POSE_PUB) {
-      const v2d* pb = reinterpret_cast<const v2d*>(sh_pub);
-      asm volatile("" : "+v"(pb));
+      const lds_cv2d* pb = lds_opaque(sh_pub);
       const v2d p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3], p4 = pb[4], p5 = pb[5];  // 6 broadcast 16-byte reads
       const double Rm[9] = {p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1], p4[0]};
       const double tv[3] = {p4[1], p5[0], p5[1]};
