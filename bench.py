@@ -506,7 +506,7 @@ def compact_line(out, detail_file=None):
     elif isinstance(c4, dict) and "error" in c4:
         summ["c4_error"] = _short(c4["error"], 120)
     if isinstance(rl, dict):
-        summ["large"] = _pick(rl, ("frac", "frac_min", "frac_max", "avg_kernel_ms", "kernel_ms_min", "kernel_ms_max", "observations", "launches"), 5)
+        summ["large"] = _pick(rl, ("frac", "frac_min", "frac_max", "after_idle_worst_frac", "avg_kernel_ms", "kernel_ms_min", "kernel_ms_max", "observations", "launches"), 5)
         summ["large"]["stat"] = rl.get("stat")
     if isinstance(cs, dict):
         for shape in ("c1", "offline"):
@@ -797,10 +797,15 @@ def main():
         del big
         rows_ok_l, n_rows_l, _, _ = hs.debug_rows()
         streamed_l = (n_rows_l * ROW_BYTES) if rows_ok_l else COMPACT_BYTES_PER_EVAL * nb
-        # 15 groups of 10 back-to-back launches: the MEDIAN group is the figure (`frac`); min / max ride along — a best-of hid a
-        # spread in r04 (profiles/r05_large.md explains it)
+        # The same launch takes 85 us in steady state and up to ~125 us for a few milliseconds after an idle -> load transition (a
+        # power-management transient, profiles/r05_large.md: r04's best-of-3 right after the upload sat inside it).  So: 300 launches
+        # (~26 ms) of sustained streaming first, then 15 groups of 10 back-to-back launches — the MEDIAN group is the figure (`frac`),
+        # min / max ride along —, then the transient itself: 200 ms of idle and 8 more groups, the slowest of which is reported too.
+        hs.time_eval(x0, reps=300)
         groups = sorted(hs.time_eval(x0, reps=10) for _ in range(15))
         ms, ms_lo, ms_hi = groups[len(groups) // 2], groups[0], groups[-1]
+        time.sleep(0.2)
+        after_idle = [hs.time_eval(x0, reps=10) for _ in range(8)]
         hs.set_launch(0, 2 | 16 | 32)
         msc = min(hs.time_eval(x0, reps=10) for _ in range(3))
         hs.set_launch(0, 6)
@@ -812,7 +817,9 @@ def main():
             beyond_infinity_cache=bool(streamed_l > 256 * 2**20),
             kernel="clc::eval_rows_kernel<loss=1,nt=1,512,weighted=1>" if rows_ok_l else "clc::eval_kernel (compact, deep)",
             avg_kernel_ms=ms, kernel_ms_min=ms_lo, kernel_ms_max=ms_hi, launches=150,
-            stat="median of 15 groups of 10 back-to-back launches (frac_min / frac_max: slowest / fastest group)",
+            stat="median of 15 groups of 10 back-to-back launches after 300 warm ones (frac_min / frac_max: slowest / fastest group)",
+            after_idle_groups_ms=after_idle, after_idle_worst_frac=streamed_l / (max(after_idle) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            after_idle_note="8 groups of 10 launches right after 200 ms of idle: the clocks' transient under the new load (profiles/r05_large.md)",
             frac_min=streamed_l / (ms_hi * 1e-3) / 1e9 / HBM_PEAK_GBS, frac_max=streamed_l / (ms_lo * 1e-3) / 1e9 / HBM_PEAK_GBS,
             kernel_ms_groups=groups, evals_per_s=nb / (ms * 1e-3),
             pricings=pricings(nb, (nb + args.pts - 1) // args.pts, streamed_l, ms * 1e-3),

@@ -74,11 +74,13 @@ constexpr int COOP_DONE_OK = 1, COOP_DONE_ABORT = 2;
 #ifndef CLC_COOP_POLL_SLEEP
 #define CLC_COOP_POLL_SLEEP 1   // s_sleep units (64 cycles) between two polls of a board
 #endif
+// (round 5, after the pose / totals reads became ds_read again and lmu_pre ~400 cycles shorter: C2 kernel flat within noise, 76.0-77.7 us,
+// for D1 600-1100 x D2 1200-2800; D2 3500 +1 us, D1 300 +10 us — scripts/r05_coop_sweep.sh)
 #ifndef CLC_COOP_D1
-#define CLC_COOP_D1 800         // shader cycles after barrier A at which a leader first looks at its group's rows
+#define CLC_COOP_D1 900         // shader cycles after barrier A at which a leader first looks at its group's rows
 #endif
 #ifndef CLC_COOP_D2
-#define CLC_COOP_D2 3500        // ... at which everybody first looks at the 8 group rows
+#define CLC_COOP_D2 2200        // ... at which everybody first looks at the 8 group rows
 #endif
 
 #ifndef CLC_COOP_GRP
@@ -473,7 +475,10 @@ __global__ __launch_bounds__(COOP_THREADS) void coop_solve_kernel(
       // (ONE batch of ds_read_b128: the status word rides in the seventh; all seven are back before the branch)
       const lds_cv2d* pb = lds_opaque(sh_pub);
       const v2d p0 = pb[0], p1 = pb[1], p2 = pb[2], p3 = pb[3], p4 = pb[4], p5 = pb[5], p6 = pb[6];
-      const int status = __double2loint(p6[0]);
+      int status = __double2loint(p6[0]);
+      // (left alone the compiler reads the status word first, waits, branches and only then asks for the other six: two LDS round
+      // trips at the head of every pass; the status is made to depend on all of them)
+      asm volatile("" : "+v"(status) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5));
       if (status != CLC_RUNNING) break;  // (wave-uniform: terminated, or the launch aborted)
       // R row-major = p0[0] p0[1] p1[0] | p1[1] p2[0] p2[1] | p3[0] p3[1] p4[0];  t = p4[1] p5[0] p5[1]
       q.nx = pl_nx; q.ny = pl_ny; q.nz = pl_nz; q.s2 = pl_s2;
