@@ -104,7 +104,7 @@ class PathInfo(C.Structure):
     """clc_path_info (include/clc.h)."""
     _fields_ = [(n, C.c_int32) for n in ("single_resident", "single_lanes", "single_points_per_lane", "coop_resident", "coop_points_per_lane",
                                          "coop_points_carry_z", "coop_resting", "coop_timeouts", "batched_resident", "batched_lanes", "batched_points_per_lane",
-                                         "rows_layout", "batched_rows_layout", "coop_workgroups")] + \
+                                         "rows_layout", "batched_rows_layout", "coop_workgroups", "batched_points_carry_z", "reserved_")] + \
                [(n, C.c_int64) for n in ("coop_solves", "batched_lane_rows", "n_rows", "batched_n_rows")]
 
 

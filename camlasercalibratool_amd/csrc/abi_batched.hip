@@ -62,7 +62,7 @@ int batched_launch_setup(clc_handle* h, const clc_options& /*opt*/, BatchedLaunc
   // Problems that fit a workgroup's registers + LDS are read from HBM once and solved on chip (clc_resident.hpp).
   bl->resident = h->bres.ok && (h->launch_flags & (clc::FLAG_NO_RESIDENT | clc::FLAG_BATCHED_LOCKSTEP)) == 0;
   {
-    const size_t res_bytes = (size_t)h->bres.rows * (size_t)h->bres.lanes * 2 * sizeof(double);
+    const size_t res_bytes = (size_t)h->bres.rows * (size_t)h->bres.lanes * (h->bres.with_z ? 3 : 2) * sizeof(double);
     bl->res_nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0 || (h->launch_auto && res_bytes > kInfinityCacheBytes + kInfinityCacheBytes / 2);
   }
   return CLC_OK;
@@ -139,8 +139,16 @@ void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedL
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RES(true, true, NW, PR, PL); else CLC_LAUNCH_RES(true, false, NW, PR, PL); } \
     else { if (bl.res_nt) CLC_LAUNCH_RES(false, true, NW, PR, PL); else CLC_LAUNCH_RES(false, false, NW, PR, PL); }            \
   } while (0)
-  if (h->bres.lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
+#define CLC_LAUNCH_RESZ(LOSS, NT)                                                                                              \
+  hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, 8, kResPRz, kResPLz, kResCtrl8, true>), dim3((unsigned)P), dim3(512), 0, h->stream, \
+                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, d_summaries, d_results, nullptr, nullptr, \
+                     rec_base, rec_host, seg_off, goal, h->bres.d_z)
+  if (h->bres.with_z) {  // 24-byte slots (p.z != 0 in some record of the batch)
+    if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RESZ(true, true); else CLC_LAUNCH_RESZ(true, false); }
+    else { if (bl.res_nt) CLC_LAUNCH_RESZ(false, true); else CLC_LAUNCH_RESZ(false, false); }
+  } else if (h->bres.lanes == 256) CLC_LAUNCH_RES_V(4, kResPR256, kResPL256);
   else CLC_LAUNCH_RES_V(8, kResPR512, kResPL512);
+#undef CLC_LAUNCH_RESZ
 #undef CLC_LAUNCH_RES_V
 #undef CLC_LAUNCH_RES
 }

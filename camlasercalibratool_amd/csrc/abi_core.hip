@@ -282,6 +282,7 @@ int clc_get_path_info(const clc_handle* h, clc_path_info* out) {
   out->batched_resident = h->bres.ok ? 1 : 0;
   out->batched_lanes = h->bres.ok ? h->bres.lanes : 0;
   out->batched_points_per_lane = h->bres.ok ? h->bres.max_ppl : 0;
+  out->batched_points_carry_z = h->bres.ok && h->bres.with_z ? 1 : 0;
   out->rows_layout = h->rows_ok ? (h->rows_z ? 2 : 1) : 0;
   out->batched_rows_layout = h->brows_ok ? (h->brows_z ? 2 : 1) : 0;
   out->coop_solves = h->coop_solves;

@@ -244,6 +244,11 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
       const int first_try = (T.d_prob_row == nullptr || (h->launch_flags & clc::FLAG_RESIDENT_WG512) != 0) ? 512 : 256;
       rc = build_resident(h, *T.res, first_try, d_aos, n, P, G, broff.p, bgid.p, bstarts.p);
       if (rc != CLC_OK) return rc;
+    } else if (T.d_prob_row != nullptr) {
+      // a BATCH whose points carry z: the 512-lane form with 24-byte slots (one problem per CU; resident_solve_kernel<.., WITH_Z>) — the
+      // batch is still read from HBM once per solve.  (A single problem with z: the cooperative kernel's z form, below.)
+      rc = build_resident(h, *T.res, 512, d_aos, n, P, G, broff.p, bgid.p, bstarts.p, kResPRz + kResPLz, /*with_z=*/true);
+      if (rc != CLC_OK) return rc;
     }
   }
   if (T.coop != nullptr) {

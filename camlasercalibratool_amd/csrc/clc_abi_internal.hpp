@@ -115,7 +115,7 @@ struct ResLayout {
   size_t row_cap = 0;
   double* d_z = nullptr;     // with_z: the slots' z, j-major like d_xy, 8 bytes per slot
   size_t z_cap = 0;
-  bool with_z = false;       // some record has p.z != 0 (cooperative layout only)
+  bool with_z = false;       // some record has p.z != 0: 24-byte slots (cooperative layout; batched layout: the 512-lane z form)
   int wgs = 0;               // cooperative layout only: the workgroups the problem is dealt to (COOP_WGS, or COOP_SMALL_WGS: one-hop form)
   int lanes = 0;             // lanes per problem of the built layout (256 / 512)
   int max_ppl = 0;           // largest points-per-lane over the problems
@@ -272,6 +272,9 @@ inline void warm_kernel(const void* f) {
 // 256-lane form: 256-thread workgroups, two problems per CU; 512-lane form: one 512-thread workgroup per CU (problems with more
 // than 256 scans, or flag 8192).  Both hold 512 x 22 = 256 x 44 - 512 points at most.
 constexpr int kResPR256 = 23, kResPL256 = 19, kResPR512 = 4, kResPL512 = 18;
+// batches whose points carry z (p.z != 0 in some record): the 512-lane form with 24-byte slots — 10 points per lane in registers
+// (60 VGPRs) + 12 in LDS (512 x 12 x 24 B = 147.5 KB): 512 x 22 points, the same capacity as the (x, y) form
+constexpr int kResPRz = 10, kResPLz = 12;
 // controller of the batched launches (clc_resident.hpp CTRL): 4-wave form / 8-wave form
 constexpr int kResCtrl4 = 0, kResCtrl8 = 0;
 

@@ -195,14 +195,18 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
 // polls it instead of blocking on the stream.
 // CTRL: 1 = the wave-uniform controller with its state in the registers of wave 0 (clc_lmuni.hpp); 0 = lm_advance_wave on the LDS
 // state (the round-2/3 controller: what tests/test_gpu_lmuni.py compares the other against, bit for bit — same pass, same totals).
-template <bool WITH_LOSS, bool NT, int NW, int PR, int PL, int CTRL>
+// WITH_Z (8-wave form only): the points carry z (p.z != 0 somewhere in the batch) — 24-byte slots, a third register / LDS array per lane
+// (`zl`: the z rows, j-major like the (x, y) rows), 14 moments per lane (rows3_*, clc_rows.hpp), padded slots masked (as clc_coop.hpp).
+template <bool WITH_LOSS, bool NT, int NW, int PR, int PL, int CTRL, bool WITH_Z = false>
 __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     const double* __restrict__ xyl, const unsigned int* __restrict__ res_row, const ResLane* __restrict__ lane_desc,
     const double* __restrict__ groups, const int uni_ppl, const clc_options opt, clc_iteration* __restrict__ trace,
     const int trace_cap, double* __restrict__ poses, clc_summary* __restrict__ summaries, double* __restrict__ results,
     int32_t* __restrict__ host_done, unsigned int* __restrict__ done_count, const double rec_base = 0.0,
-    double* __restrict__ rec_host = nullptr, const long long rec_seg_off = 0, const unsigned long long rec_goal = 0) {
-  constexpr bool RES_LEAN = NW == 4;  // the controller next to 92 VGPRs of points: the small-footprint form (clc_controller.hpp)
+    double* __restrict__ rec_host = nullptr, const long long rec_seg_off = 0, const unsigned long long rec_goal = 0,
+    const double* __restrict__ zl = nullptr) {
+  static_assert(!WITH_Z || NW == 8, "points with z: the 8-wave form (one problem per CU)");
+  constexpr bool RES_LEAN = NW == 4 || WITH_Z;  // the controller next to 92 (60) VGPRs of points: the small-footprint form (clc_controller.hpp)
   // How the pass gets its pose: CTRL 0 — x_eval from the LDS state, every wave turning the quaternion into a wave-uniform (SGPR)
   // rotation itself; CTRL 1 — as the cooperative kernel: rotation + translation + status published by the controller (six 16-byte
   // LDS reads).  Same quat_to_rot on the same quaternion either way: the passes of the two forms are bit-identical.
@@ -214,12 +218,14 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   // out analytically once per pass (a logarithm + a reciprocal per lane).  The alternative of clc_coop.hpp (CLC_RES_PAD_ANALYTIC = 0:
   // masked slots in the groups that some lane has padding in) was measured here and lost: the wave-uniform branch per group and the
   // second copy of the point code cost the 4-wave form 12 % (C4 shard kernel 0.907 against 0.808 ms, C3 0.141 / 0.124, C1 0.143 / 0.134).
-  constexpr bool PAD_ANALYTIC = CLC_RES_PAD_ANALYTIC != 0;
+  constexpr bool PAD_ANALYTIC = CLC_RES_PAD_ANALYTIC != 0 && !WITH_Z;  // (the analytic correction is written for (x, y) slots)
+  using Moments = typename std::conditional<WITH_Z, RowMoments3, RowMoments>::type;
   constexpr int NL = NW * 64;
   constexpr int NP = PR + PL;  // points a lane can hold
   constexpr int CH = 6;        // LDS points are read in chunks of CH, one chunk ahead of the arithmetic
   constexpr int NCH = (PL + CH - 1) / CH;
   __shared__ v2d sh_pts[(PL > 0 ? PL : 1) * NL];
+  __shared__ double sh_ptz[WITH_Z ? PL * NL : 1];  // the z of the LDS-held slots
   __shared__ double sh_state[LM_STATE_WORDS];
   __shared__ __attribute__((aligned(16))) double sh_tot[64];  // CTRL 1: two buffers of 32, the totals of the passes alternate (clc_lmuni.hpp)
   __shared__ double sh_wsum[NW][NACC];
@@ -228,8 +234,8 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the iteration trace exists for the single-problem (8-wave) launches only: in the 4-wave form the controller shares the
   // register file with 92 VGPRs of points, and the trace record's code must not be there at all
-  clc_iteration* const tr = NW == 8 ? trace : nullptr;
-  const int tr_cap = NW == 8 ? trace_cap : 0;
+  clc_iteration* const tr = (NW == 8 && !WITH_Z) ? trace : nullptr;
+  const int tr_cap = (NW == 8 && !WITH_Z) ? trace_cap : 0;
   // The controller runs on wave 0.  (Picking wave 0 / wave 2 by the workgroup's LDS allocation base — s_getreg HW_REG_LDS_ALLOC — so
   // that the two workgroups of a CU never run their controllers on the same SIMD was measured: no gain, and the run-time wave
   // index cost a live SGPR in a kernel that already spills scalars — a -DCLC_STAMPS build of that form computed wrong steps.)
@@ -256,21 +262,30 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   // Order: the LDS-bound rows first, then the register rows — loads return in order, so the LDS part is written (and the
   // barrier in front of the first pass passed) while the register rows are still in flight; the first pass then consumes
   // them as they arrive.  (A lane reads back only its own LDS slots: no barrier is needed for sh_pts.)
+  const double* __restrict__ srcz = WITH_Z ? zl + (size_t)row0 * NL + tid : nullptr;
   v2d lds_v[PL > 0 ? PL : 1];
+  double lds_z[WITH_Z ? PL : 1];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     const int j = PR + i;
     lds_v[i] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+    if (WITH_Z) lds_z[i] = srcz[(size_t)(j < j_last ? j : j_last) * NL];
   }
   v2d reg[PR];
+  double regz[WITH_Z ? PR : 1];
 #pragma unroll
-  for (int j = 0; j < PR; ++j) reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+  for (int j = 0; j < PR; ++j) {
+    reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
+    if (WITH_Z) regz[j] = srcz[(size_t)(j < j_last ? j : j_last) * NL];
+  }
   const ResLane dl = lane_desc[(size_t)prob * NL + tid];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     v2d v = lds_v[i];
-    if (PR + i >= ppl) { v[0] = 0.0; v[1] = 0.0; }
+    double vz = WITH_Z ? lds_z[i] : 0.0;
+    if (PR + i >= ppl) { v[0] = 0.0; v[1] = 0.0; vz = 0.0; }
     sh_pts[i * NL + tid] = v;
+    if (WITH_Z) sh_ptz[i * NL + tid] = vz;
   }
   // The lane's plane is fetched again in every pass (48 bytes per lane out of L1/L2: a problem's group entries are ~1 KB)
   // rather than held in 10 VGPRs across the controller, which needs every register it can get.
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   RES_STAMP(3, clock64());
 #pragma unroll
   for (int j = 0; j < PR; ++j)
-    if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; }
+    if (j >= ppl) { reg[j][0] = 0.0; reg[j][1] = 0.0; if (WITH_Z) regz[j] = 0.0; }
   int pass_no = 0;  // (debug stamps)
 
   // one evaluation pass at the published pose: the wave's 28 totals -> sh_wsum[wave]
@@ -338,10 +353,14 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
       nx = on ? a[0] : 0.0; ny = on ? a[1] : 0.0; nz = on ? b[0] : 0.0; pd = on ? b[1] : 0.0; ps = on ? s5 : 0.0;
     }
     v2d buf[2][CH];  // LDS points, chunk c in buf[c & 1]; chunk 0 is read before the register points are consumed
+    double bufz[2][WITH_Z ? CH : 1];
     if (PL > 0) {
 #pragma unroll
       for (int u = 0; u < CH; ++u)
-        if (u < PL) buf[0][u] = sh_pts[u * NL + t];
+        if (u < PL) {
+          buf[0][u] = sh_pts[u * NL + t];
+          if (WITH_Z) bufz[0][u] = sh_ptz[u * NL + t];
+        }
     }
     RowPlane q;
     if (POSE_PUB) {
@@ -361,8 +380,8 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
 #ifdef CLC_STAMPS
     if (wave != cw) { asm volatile("" :: "v"(q.mx), "v"(q.c0)); RES_STAMP(8 + 6 * pass_no, clock64()); }  // plane + pose have arrived
 #endif
-    RowMoments M;
-    rows_moments_reset<WITH_LOSS>(M);
+    Moments M;
+    lane_moments_reset<WITH_LOSS>(M);
 #pragma unroll
     for (int j0 = 0; j0 < NP; j0 += GRP) {
       if (j0 < ppl) {  // wave-uniform; the points of a group in one basic block
@@ -373,10 +392,14 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
               const int c1 = (j - PR) / CH + 1;
 #pragma unroll
               for (int u = 0; u < CH; ++u)
-                if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                if (c1 * CH + u < PL) {
+                  buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                  if (WITH_Z) bufz[c1 & 1][u] = sh_ptz[(c1 * CH + u) * NL + t];
+                }
             }
             const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
-            rows_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);  // (rows_flush normalises an incomplete last group)
+            const double vz = !WITH_Z ? 0.0 : (j < PR ? regz[j < PR ? j : 0] : bufz[((j - PR) / CH) & 1][(j - PR) % CH]);
+            lane_point<WITH_LOSS>(q, inv_lf2, v[0], v[1], vz, M, /*renorm=*/j == j0 + GRP - 1);  // (rows_flush normalises an incomplete last group)
           }
         } else {
 #pragma unroll
@@ -385,10 +408,14 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
               const int c1 = (j - PR) / CH + 1;
 #pragma unroll
               for (int u = 0; u < CH; ++u)
-                if (c1 * CH + u < PL) buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                if (c1 * CH + u < PL) {
+                  buf[c1 & 1][u] = sh_pts[(c1 * CH + u) * NL + t];
+                  if (WITH_Z) bufz[c1 & 1][u] = sh_ptz[(c1 * CH + u) * NL + t];
+                }
             }
             const v2d v = j < PR ? reg[j < PR ? j : 0] : buf[((j - PR) / CH) & 1][(j - PR) % CH];
-            rows_point_masked<WITH_LOSS>(q, j < cnt_m, inv_lf2, v[0], v[1], M, /*renorm=*/j == j0 + GRP - 1);
+            const double vz = !WITH_Z ? 0.0 : (j < PR ? regz[j < PR ? j : 0] : bufz[((j - PR) / CH) & 1][(j - PR) % CH]);
+            lane_point_masked<WITH_LOSS>(q, j < cnt_m, inv_lf2, v[0], v[1], vz, M, /*renorm=*/j == j0 + GRP - 1);
           }
         }
       }
@@ -414,13 +441,13 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
         M.prod = fma(-cs * c0, c0, M.prod);
       }
     } else {
-      rows_pad_correction<WITH_LOSS>(M, (double)(ppl_eff - cnt_m));
+      lane_pad_correction<WITH_LOSS>(M, (double)(ppl_eff - cnt_m));
     }
     RES_STAMP(5 + 6 * pass_no, clock64());
     double acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-    rows_flush<WITH_LOSS>(q, M, acc);
+    lane_flush<WITH_LOSS>(q, M, acc);
     if (PAD_ANALYTIC && WITH_LOSS) acc[27] = fma(-q.s2, lp, acc[27]);
     wave_reduce_butterfly(acc, sh_wsum[wave], lane);
     RES_STAMP(6 + 6 * pass_no, clock64());

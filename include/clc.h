@@ -186,7 +186,7 @@ typedef struct clc_path_info {
   int32_t single_points_per_lane;
   int32_t coop_resident;           /* 1: the lane layout of the cooperative kernel is built: clc_solve = ONE launch of 256 workgroups */
   int32_t coop_points_per_lane;    /* <= 40 (<= 26 when the points carry z) */
-  int32_t coop_points_carry_z;     /* 1: some record has p.z != 0: 24-byte slots (the only on-chip form that holds such points) */
+  int32_t coop_points_carry_z;     /* 1: some record has p.z != 0: 24-byte slots */
   int32_t coop_resting;            /* 1: after a launch that timed out the path rests (the step chain runs) until its back-off expires */
   int32_t coop_timeouts;           /* cooperative launches that timed out on this handle */
   int32_t batched_resident;        /* 1: clc_solve_batched = ONE launch of the resident kernel */
@@ -195,6 +195,8 @@ typedef struct clc_path_info {
   int32_t rows_layout;             /* single problem's streaming row layout: 0 none, 1 (x, y) rows, 2 rows that carry z */
   int32_t batched_rows_layout;
   int32_t coop_workgroups;         /* 256, or 32: the one-hop form for problems of at most 32 x 256 x 10 points */
+  int32_t batched_points_carry_z;  /* 1: the batch has p.z != 0 somewhere and is held on chip in 24-byte slots (512 lanes x <= 22 points per problem) */
+  int32_t reserved_;
   int64_t coop_solves;             /* solves that ran on the cooperative kernel */
   int64_t batched_lane_rows;       /* point rows of the batched lane layout (x lanes x 16 bytes = its size) */
   int64_t n_rows;                  /* rows of 64 points of the streaming row layouts */

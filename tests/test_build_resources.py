@@ -66,7 +66,9 @@ def test_hot_kernels_do_not_spill(usage):
             # LEAN controller).
             # (the 8-wave form with the cooperative kernel's controller on wave 0 — CTRL = 1, the bit-identity test's vehicle, not a
             # default path — holds that controller's ~115 VGPRs of state next to the pass and parks ~35 of them)
-            assert usage[k]["ScratchSize"] <= (160 if "Li8ELi4ELi18ELi1E" in k else 128), (k, usage[k])
+            # (the z form — 512 lanes, 24-byte slots, 60 VGPRs of points — parks controller state as well: a path for callers whose points
+            # leave the lidar plane, measured against the lockstep launches it replaces in tests/test_gpu_rows_z.py)
+            assert usage[k]["ScratchSize"] <= (160 if ("Li8ELi4ELi18ELi1E" in k or "Li8ELi10ELi12ELi0ELb1E" in k) else 128), (k, usage[k])
         else:
             assert usage[k]["ScratchSize"] == 0, (k, usage[k])
         assert usage[k]["VGPRs"] <= 256, (k, usage[k])

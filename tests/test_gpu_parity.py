@@ -946,16 +946,27 @@ def test_solve_batched_gather_one_call_equals_the_two_calls(oracle_mod):
         with pytest.raises(clc.ClcError, match="non-finite"):
             ss.comm.solve_gather(bad, 0, P)
         assert np.array_equal(ss.solve_gather(x0, ordered=False), two)  # and the next call is whole again
-        # a batch that does not run as the on-chip solve (points off the lidar plane): the two-call fall-back, same contract
+        # points off the lidar plane: still one launch (the 24-byte-slot form of the on-chip kernel), still the one-call form
         recz = rec.copy()
         recz[::5, 6] = 0.01
         ss.upload(recz, off)
-        assert ss.solver.path_info().batched_resident == 0
+        assert ss.solver.path_info().batched_resident == 1 and ss.solver.path_info().batched_points_carry_z == 1
         twoz = ss.solve(x0, ordered=False)
         evz = sum(ss.last_summaries[k].num_evaluations for k in range(P))
         onez = ss.solve_gather(x0, ordered=False)
-        assert np.array_equal(onez, twoz) and ss.last_stats.fused == 0 and ss.last_stats.problems == P
-        assert ss.last_stats.evaluations == evz
+        assert np.array_equal(onez, twoz) and ss.last_stats.fused == 1 and ss.last_stats.evaluations == evz
+    # a batch that does not run as the on-chip solve (problems of 15 000 observations: more than a workgroup holds): the two-call
+    # fall-back, same contract
+    P3 = 5
+    rec3, off3, x03, _ = sd.sim_shard_records(29, 0, P3, 30, 500, 0.01)
+    with cdist.ShardSolver(P3, device_index=0, rank=0, world=1) as ss:
+        ss.upload(rec3, off3)
+        assert ss.solver.path_info().batched_resident == 0
+        two3 = ss.solve(x03, ordered=False)
+        ev3 = sum(ss.last_summaries[k].num_evaluations for k in range(P3))
+        one3 = ss.solve_gather(x03, ordered=False)
+        assert np.array_equal(one3, two3) and ss.last_stats.fused == 0 and ss.last_stats.problems == P3
+        assert ss.last_stats.evaluations == ev3
     k = 17
     ref = oracle_mod.solve(rec[off[k]:off[k + 1]], x0[k], linear_solver="qr")
     assert _dT(two[k, :7], ref.pose) <= T_TOL and two[k, 9] == ref.summary.num_iterations

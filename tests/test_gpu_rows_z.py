@@ -147,29 +147,96 @@ def test_closed_form_ignores_z_like_the_reference(sv, oracle_mod):
 
 
 def test_batched_problems_with_z(sv, oracle_mod):
-    """A batch with points off the lidar plane: no lane layout, no whole-solve kernel; the lockstep launches run on rows that
-    carry z (one wave per problem and 256-thread workgroups) and agree with the per-point layouts and with the oracle."""
+    """A batch with points off the lidar plane runs ON CHIP: the 512-lane form of resident_solve_kernel with 24-byte slots (10 points per
+    lane in registers + 12 in LDS), one launch, the batch read from HBM once.  It agrees with the lockstep launches on the rows that carry
+    z (one wave per problem and 256-thread workgroups), with the per-point layout, and with the oracle; ragged scans and a problem with
+    one scan only included; loss on and off."""
     P = 12
     rec, off, x0, gt = sd.sim_shard_records(31, 0, P, 12, 97, 0.01)
     rec = _off_plane(rec, 8, sigma=0.02)
     sv.set_launch(0, -1)
     sv.upload_batched(rec, off)
-    assert sv.debug_rows()[2] and sv.rows_carry_z()[1] and not sv.debug_resident()[0]
-    p1, s1 = sv.solve_batched(x0)
-    sv.set_launch(0, BASE | 2048 | 1024)  # lockstep, 256-thread workgroups, serial controller
-    p2, s2 = sv.solve_batched(x0)
-    sv.set_launch(0, 2 | 16 | 32)         # compact per-point layout
-    p3, s3 = sv.solve_batched(x0)
-    sv.set_launch(0, -1)
-    for k in range(P):
-        ref = oracle_mod.solve(rec[off[k]:off[k + 1]], x0[k], linear_solver="qr")
-        for p, s in ((p1, s1), (p2, s2), (p3, s3)):
-            assert s[k].termination == ref.summary.termination and s[k].num_iterations == ref.summary.num_iterations, k
-            assert _dT(p[k], ref.pose) <= T_TOL and abs(s[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
-    # a later flat batch on the same handle goes back on chip
+    pi = sv.path_info()
+    assert sv.debug_rows()[2] and sv.rows_carry_z()[1]
+    assert pi.batched_resident == 1 and pi.batched_points_carry_z == 1 and pi.batched_lanes == 512 and pi.batched_points_per_lane <= 22
+    for use_loss in (1, 0):
+        o, oo = clc.default_options(), oracle_mod.default_options()
+        o.use_loss = oo.use_loss = use_loss
+        sv.set_launch(0, -1)
+        p1, s1 = sv.solve_batched(x0, o)
+        sv.set_launch(0, BASE | 2048 | 1024)  # lockstep, 256-thread workgroups, serial controller (rows that carry z)
+        p2, s2 = sv.solve_batched(x0, o)
+        sv.set_launch(0, BASE | 4096)         # not the on-chip kernel: lockstep, one wave per problem
+        p4, s4 = sv.solve_batched(x0, o)
+        sv.set_launch(0, 2 | 16 | 32)         # compact per-point layout
+        p3, s3 = sv.solve_batched(x0, o)
+        sv.set_launch(0, -1)
+        for k in range(P):
+            ref = oracle_mod.solve(rec[off[k]:off[k + 1]], x0[k], options=oo, linear_solver="qr")
+            for p, s in ((p1, s1), (p2, s2), (p3, s3), (p4, s4)):
+                assert s[k].termination == ref.summary.termination and s[k].num_iterations == ref.summary.num_iterations, (k, use_loss)
+                assert _dT(p[k], ref.pose) <= T_TOL and abs(s[k].final_cost - ref.summary.final_cost) <= COST_TOL, (k, use_loss)
+        pr, sr = sv.solve_batched(x0, o)
+        assert np.array_equal(pr, p1) and all(sr[k].final_cost == s1[k].final_cost for k in range(P))  # bit-repeatable
+    # a later flat batch on the same handle goes back to the (x, y) form, two problems per CU
     rec0, off0, x00, _ = sd.sim_shard_records(32, 0, P, 12, 97, 0.01)
     sv.upload_batched(rec0, off0)
-    assert not sv.rows_carry_z()[1] and sv.debug_resident()[0]
+    pi = sv.path_info()
+    assert not sv.rows_carry_z()[1] and pi.batched_resident == 1 and pi.batched_points_carry_z == 0 and pi.batched_lanes == 256
+
+
+def test_batched_z_ragged_scans_and_idle_lanes(sv, oracle_mod):
+    """Problems of the reference's C1 shape (50 ragged scans of 0-154 points: lanes with few points, idle lanes, masked padding slots)
+    with z in every 3rd point, and a problem whose scans leave one point per lane — after a batch that filled every LDS slot with
+    large coordinates."""
+    dirty, offd, xd, _ = sd.sim_shard_records(77, 0, 4, 20, 500, 0.01)
+    dirty = _off_plane(dirty, 3, sigma=0.5)
+    dirty[:, 4:7] *= 300.0
+    sv.set_launch(0, -1)
+    sv.upload_batched(dirty, offd)
+    assert sv.path_info().batched_points_carry_z == 1
+    sv.solve_batched(xd)
+    recs, x0s = [], []
+    for k in range(6):
+        S = sd.GenerateSimData(60 + k, noise_sigma=0.01)
+        recs.append(_off_plane(clc.flatten_observations(S, False), 20 + k, sigma=0.03, every=3))
+    recs.append(_off_plane(clc.flatten_observations(sd.sim_fixed_count(9, 300, 1, noise_sigma=0.01), False), 30, sigma=0.02))  # 300 scans of ONE point
+    off = np.zeros(len(recs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([r.shape[0] for r in recs])
+    rec = np.concatenate(recs)
+    x0 = np.tile(X0, (len(recs), 1))
+    sv.upload_batched(rec, off)
+    pi = sv.path_info()
+    assert pi.batched_resident == 1 and pi.batched_points_carry_z == 1
+    p, s = sv.solve_batched(x0)
+    for k in range(len(recs)):
+        ref = oracle_mod.solve(recs[k], X0, linear_solver="qr")
+        assert s[k].termination == ref.summary.termination and s[k].num_iterations == ref.summary.num_iterations, k
+        assert _dT(p[k], ref.pose) <= T_TOL and abs(s[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
+
+
+def test_c3_size_batch_with_z_on_chip(sv, oracle_mod):
+    """BASELINE.json configs[2] with points off the lidar plane: 1 024 independent problems x 10^4 observations, every point with z != 0
+    (Oberserve::points is a vector of Eigen::Vector3d, include/LaseCamCalCeres.h:22): ONE launch of the 512-lane z form, parity at
+    the gates against the oracle on 64 sampled problems, the lockstep launches on all of them."""
+    P = 1024
+    rec, off, x0, gt = sd.sim_shard_records(4242, 0, P, 20, 500, 0.01)
+    rec = _off_plane(rec, 5, sigma=0.02)
+    sv.set_launch(0, -1)
+    sv.upload_batched(rec, off)
+    pi = sv.path_info()
+    assert pi.batched_resident == 1 and pi.batched_points_carry_z == 1 and pi.batched_lanes == 512 and pi.batched_points_per_lane == 20
+    p, s = sv.solve_batched(x0)
+    sv.set_launch(0, BASE | 4096)
+    p2, s2 = sv.solve_batched(x0)
+    sv.set_launch(0, -1)
+    assert all(s[k].termination == s2[k].termination and s[k].num_iterations == s2[k].num_iterations for k in range(P))
+    assert np.abs(p - p2).max() <= 1e-9
+    assert all(s[k].termination in (1, 2, 3) for k in range(P))
+    for k in range(0, P, 16):
+        ref = oracle_mod.solve(rec[off[k]:off[k + 1]], x0[k], linear_solver="qr")
+        assert s[k].termination == ref.summary.termination and s[k].num_iterations == ref.summary.num_iterations, k
+        assert _dT(p[k], ref.pose) <= T_TOL and abs(s[k].final_cost - ref.summary.final_cost) <= COST_TOL, k
 
 
 def _on_chip(sv):
@@ -238,14 +305,15 @@ def test_cooperative_kernel_z_capacity_edge(sv, oracle_mod):
 
 
 @pytest.mark.parametrize("use_loss", [1, 0])
+@pytest.mark.parametrize("cut", [False, True])
 @pytest.mark.parametrize("wgs", [32, 256])
 @pytest.mark.parametrize("ppl", [9, 10])
-def test_cooperative_kernel_z_with_9_and_10_points_per_lane(sv, oracle_mod, ppl, wgs, use_loss):
+def test_cooperative_kernel_z_with_9_and_10_points_per_lane(sv, oracle_mod, ppl, wgs, cut, use_loss):
     """The z form keeps 10 points per lane in registers, and a pass walks blocks of 8 slots: at 9 or 10 points per lane the block that
     holds slots 8..15 runs on into LDS-held slots 10..15, which must hold zeros (round 4 left them unwritten: whatever the previous
     launch had there — here a 26-points-per-lane problem with coordinates of hundreds of metres — entered the moments).  Both launch
-    forms (32 workgroups one-hop, 256 workgroups), loss on and off, against the oracle's DENSE_QR solve; idle lanes included (the
-    last scan is shorter)."""
+    forms (32 workgroups one-hop, 256 workgroups), loss on and off, against the oracle's DENSE_QR solve; `cut`: the array ends inside a
+    scan, so chunks cut scans — lanes with fewer points, idle lanes (9 points per scan-lane then become 10 per lane: the other bug case)."""
     o, oo = clc.default_options(), oracle_mod.default_options()
     o.use_loss = oo.use_loss = use_loss
     sv.set_launch(0, -1)
@@ -259,10 +327,13 @@ def test_cooperative_kernel_z_with_9_and_10_points_per_lane(sv, oracle_mod, ppl,
     n_scans = wgs * 16
     S = sd.sim_fixed_count(40 + ppl, n_scans, K, noise_sigma=0.01)
     rec = _off_plane(clc.flatten_observations(S, False), 12, sigma=0.02)
-    rec = np.ascontiguousarray(rec[: n_scans * K - 3 * ppl - 1])  # the last scan is short: lanes with fewer points, idle lanes
+    if cut:
+        rec = np.ascontiguousarray(rec[: n_scans * K - 3 * ppl - 1])
     sv.upload(rec)
     pi = sv.path_info()
-    assert _on_chip(sv) and pi.coop_points_per_lane == ppl and pi.coop_workgroups == wgs, (pi.coop_points_per_lane, pi.coop_workgroups)
+    assert _on_chip(sv)
+    if not cut:  # (a cut array may need one point per lane more, and then the next launch form)
+        assert pi.coop_points_per_lane == ppl and pi.coop_workgroups == wgs, (pi.coop_points_per_lane, pi.coop_workgroups)
     x0 = sv.pose_plus(sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))[None, :], np.array([[0.03, -0.02, 0.02, 0.02, -0.02, 0.01]]))[0]
     n0 = pi.coop_solves
     r = sv.solve(x0, o, trace_cap=0)
