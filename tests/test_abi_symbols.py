@@ -48,7 +48,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Options) == 4 * 4 + 10 * 8 + 2 * 4
     assert C.sizeof(_capi.Iteration) == 16 + 6 * 8
     assert C.sizeof(_capi.Summary) == 16 + 8 + 4 * 8 + 8
-    assert C.sizeof(_capi.PathInfo) == 14 * 4 + 4 * 8  # clc_path_info: 13 int32 + 1 reserved, 4 int64
+    assert C.sizeof(_capi.PathInfo) == 16 * 4 + 4 * 8  # clc_path_info: 15 int32 + 1 reserved, 4 int64
+    assert C.sizeof(_capi.BatchStats) == 4 * 8 + 2 * 4 + 2 * 8  # clc_batch_stats
     hdr = open(os.path.join(ROOT, "include", "clc.h")).read()
     body = re.sub(r"/\*.*?\*/", "", re.search(r"typedef struct clc_path_info \{(.*?)\} clc_path_info;", hdr, flags=re.S).group(1), flags=re.S)
     assert [m.group(2) for m in re.finditer(r"(int32_t|int64_t)\s+(\w+);", body)] == [f[0] for f in _capi.PathInfo._fields_]
