@@ -365,6 +365,32 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
 // clc_solve as ONE launch of 256 co-resident workgroups that keep the problem on chip (clc_coop.hpp).  Returns kCoopFallback when
 // the path cannot be used (device too small, or the launch timed out in its exchange): the caller runs the step chain instead.
 constexpr int kCoopFallback = -1000;
+
+// One cooperative launch at a time per device in this process.  The kernel needs a CU per workgroup; a second cooperative launch from
+// another handle (another stream, another thread) interleaves its workgroups with the first one's, neither grid becomes co-resident,
+// and BOTH time out at their census — round 4: two threads alternated aborts.  A solve is ~0.1 ms, so the second caller waits for the
+// gate (bounded: 5 ms) rather than fall back to the slower step chain; if the wait runs out it takes the step chain without counting
+// an abort.  (Other PROCESSES on the same GPU cannot be seen from here: for them the census, the abort word and the back-off remain.)
+struct CoopGate {
+  static constexpr int kMaxDevices = 64;
+  static std::atomic<int>& slot(int device) {
+    static std::atomic<int> busy[kMaxDevices];
+    return busy[device >= 0 && device < kMaxDevices ? device : 0];
+  }
+  std::atomic<int>* held = nullptr;
+  bool acquire(int device) {
+    std::atomic<int>& a = slot(device);
+    const auto t0 = std::chrono::steady_clock::now();
+    long long spins = 0;
+    for (;;) {
+      int expected = 0;
+      if (a.compare_exchange_weak(expected, 1, std::memory_order_acquire)) { held = &a; return true; }
+      if ((++spins & 0x3FF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5e-3) return false;
+    }
+  }
+  ~CoopGate() { if (held) held->store(0, std::memory_order_release); }
+};
+
 int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summary* summary, clc_iteration* trace, int trace_cap,
                std::chrono::steady_clock::time_point t0) {
   if (h->coop_checked == 0) {
@@ -384,6 +410,8 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
   }
   if (h->coop_checked < 0) return kCoopFallback;
   if (h->num_cus < (h->cres.wgs > 0 ? h->cres.wgs : clc::COOP_WGS)) return kCoopFallback;  // one workgroup per CU, or not at all
+  CoopGate gate;  // (released when this function returns: the kernel has finished, or was never launched)
+  if (!gate.acquire(h->device)) { ++h->coop_gate_waits_expired; return kCoopFallback; }
   if (!h->d_board) {
     CLC_HIP(hipMalloc(&h->d_board, sizeof(clc::CoopBoard)));
     // (ordered on the handle's stream AND waited for: the caller may switch streams, clc_set_stream, before the next solve)

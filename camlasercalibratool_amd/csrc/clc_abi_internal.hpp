@@ -211,6 +211,7 @@ struct clc_handle {
   // census timeout, 0.2 ms, once)
   long long coop_eligible = 0, coop_retry_at = 0, coop_backoff = clc_abi::kCoopBackoff0;
   int coop_aborts = 0;
+  int coop_gate_waits_expired = 0;  // solves that took the step chain because another handle's cooperative launch held the device for > 5 ms
   long long coop_solves = 0;
   int coop_test_drop = 0;  // test hook: launch the next cooperative solve this many workgroups short (its exchange must time out)
   // single-problem resident solve: start pose in / result out through page-locked, device-mapped host memory
