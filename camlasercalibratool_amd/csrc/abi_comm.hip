@@ -71,6 +71,18 @@ RcclApi& rccl() {
   return api;
 }
 
+int rccl_fail(const char* what, ncclResult_t r);
+// The all-gather of a communicator.  A communicator WITHOUT an RCCL handle exists only in the -DCLC_TEST_HOOKS build
+// (clc_debug_comm_create_layout: "rank r of n" on the one visible GPU, which RCCL refuses to give two ranks): its all-gather moves this
+// rank's segment into place and leaves the other ranks' segments as they are — what the buffer arithmetic of the gather calls
+// (segment offsets, padding, which parts are copied to the host) can be tested against at rank > 0.
+ncclResult_t comm_all_gather(ncclComm_t comm, int rank, const double* send, double* recv, size_t count, hipStream_t stream) {
+  if (comm) return rccl().AllGather(send, recv, count, ncclDouble, comm, stream);
+  double* mine = recv + (size_t)rank * count;
+  if (send != mine && hipMemcpyAsync(mine, send, count * sizeof(double), hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+  return ncclSuccess;
+}
+
 int rccl_fail(const char* what, ncclResult_t r) {
   char buf[512];
   std::snprintf(buf, sizeof(buf), "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error");
@@ -210,7 +222,7 @@ int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_r
                      c->d_send);
   CLC_HIP(hipGetLastError());
   const size_t count = cap_per_rank * (sizeof(clc_result_record) / sizeof(double));
-  ncclResult_t r = rccl().AllGather(c->d_send, c->d_recv, count, ncclDouble, c->comm, h->stream);
+  ncclResult_t r = comm_all_gather(c->comm, c->rank, c->d_send, c->d_recv, count, h->stream);
   if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
   const size_t bytes = sizeof(clc_result_record) * cap_per_rank * (size_t)c->world;
   CLC_HIP(hipMemcpyAsync(c->h_recv, c->d_recv, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -319,7 +331,7 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const doubl
   // host memory already — the kernel wrote them there —, so only the OTHER ranks' segments are copied down (world size 1: nothing);
   // one synchronisation.
   const size_t count = cap_per_rank * (sizeof(clc_result_record) / sizeof(double));
-  ncclResult_t r = rccl().AllGather(seg, c->d_recv, count, ncclDouble, c->comm, h->stream);
+  ncclResult_t r = comm_all_gather(c->comm, c->rank, seg, c->d_recv, count, h->stream);
   if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
   const size_t seg_bytes = sizeof(clc_result_record) * cap_per_rank;
   const size_t bytes = seg_bytes * (size_t)c->world;
@@ -351,6 +363,22 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const doubl
   if (local_rc != CLC_OK) return fail(local_rc, local_msg.c_str());
   return CLC_OK;
 }
+
+#ifdef CLC_TEST_HOOKS
+// Test hook (hooks build only): a communicator laid out as rank `rank` of `world` WITHOUT RCCL behind it (see comm_all_gather).
+#pragma GCC visibility push(default)
+int clc_debug_comm_create_layout(clc_comm** out, clc_handle* h, int rank, int world);
+#pragma GCC visibility pop
+int clc_debug_comm_create_layout(clc_comm** out, clc_handle* h, int rank, int world) {
+  if (!out || !h || world < 1 || rank < 0 || rank >= world) return fail(CLC_ERR_INVALID_ARG, "clc_debug_comm_create_layout: bad argument");
+  clc_comm* c = new clc_comm();
+  c->h = h;
+  c->rank = rank;
+  c->world = world;
+  *out = c;
+  return CLC_OK;
+}
+#endif
 
 const clc_result_record* clc_comm_records(const clc_comm* c) {
   return c ? reinterpret_cast<const clc_result_record*>(c->h_recv) : nullptr;

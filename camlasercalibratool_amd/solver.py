@@ -55,13 +55,18 @@ class Comm:
     """RCCL communicator bound to one Solver (clc_comm): collectives run on the solver's stream.
     Creating it is a collective call — every rank of the job must do so with the same id."""
 
-    def __init__(self, solver: "Solver", uid: bytes, rank: int, world: int):
-        assert len(uid) == COMM_ID_BYTES
+    def __init__(self, solver: "Solver", uid: Optional[bytes], rank: int, world: int):
+        """uid None (hooks build only, tests): a communicator laid out as `rank` of `world` without RCCL behind it — its all-gather
+        moves this rank's segment into place and nothing else (clc_debug_comm_create_layout)."""
         self._L = solver._L
         self._c = C.c_void_p()
         self._solver = solver  # keep the handle alive
-        check(self._L.clc_comm_create(C.byref(self._c), solver._h, C.c_char_p(uid), C.c_int(rank), C.c_int(world)),
-              "clc_comm_create")
+        if uid is None:
+            check(solver._hook("clc_debug_comm_create_layout")(C.byref(self._c), solver._h, C.c_int(rank), C.c_int(world)), "clc_debug_comm_create_layout")
+        else:
+            assert len(uid) == COMM_ID_BYTES
+            check(self._L.clc_comm_create(C.byref(self._c), solver._h, C.c_char_p(uid), C.c_int(rank), C.c_int(world)),
+                  "clc_comm_create")
         self.rank, self.world = rank, world
 
     @property

@@ -972,6 +972,38 @@ def test_solve_batched_gather_one_call_equals_the_two_calls(oracle_mod):
     assert _dT(two[k, :7], ref.pose) <= T_TOL and two[k, 9] == ref.summary.num_iterations
 
 
+def test_gather_buffer_arithmetic_at_rank_1_of_3():
+    """What cannot be run for real on one GPU — a rank other than 0 of a world larger than 1 — through the hooks build's layout-only
+    communicator (no RCCL behind it: its all-gather moves this rank's segment into place, the other ranks' segments stay as they are).
+    Both gather forms at rank 1 of 3 with a capacity above the shard: this rank's records in the SECOND segment with their global
+    indices, its padding records behind them, the other two segments copied to the host untouched (zeros), totals of the shard."""
+    from camlasercalibratool_amd import dist as cdist
+    from camlasercalibratool_amd.solver import Comm
+
+    P, cap, lo = 23, 29, 29  # rank 1's shard of 3 x 29 problems would start at global index 29
+    rec, off, x0, gt = sd.sim_shard_records(31, lo, lo + P, 7, 80, 0.01)
+    with clc.Solver(0, library="hooks") as s0:
+        s0.upload_batched(rec, off)
+        poses, sms = s0.solve_batched(x0)
+        c = Comm(s0, None, 1, 3)
+        try:
+            two = c.gather_results(lo, cap)
+            one, st = c.solve_gather(x0, lo, cap)
+            one2, st2 = c.solve_gather(x0, lo, cap, copy=False)
+            one2 = one2.copy()  # (a view of the communicator's pinned buffer: gone with the communicator)
+        finally:
+            c.close()
+    for name, g in (("two-call", two), ("one-call", one), ("one-call again", one2)):
+        assert g.shape == (3 * cap, 12), name
+        assert np.all(g[:cap] == 0) and np.all(g[2 * cap:] == 0), name               # ranks 0 and 2: nothing arrived (no RCCL), nothing overwritten
+        mine = g[cap:2 * cap]
+        assert np.array_equal(mine[:P, :7], poses) and np.array_equal(mine[:P, 11], lo + np.arange(P)), name
+        assert np.all(mine[P:, 11] == -1) and np.all(mine[P:, :11] == 0), name        # this rank's padding records
+        assert np.array_equal(mine[:P, 9], [sms[k].num_iterations for k in range(P)]), name
+    ev = sum(sms[k].num_evaluations for k in range(P))
+    assert (st.problems, st.evaluations, st.fused) == (P, ev, 1) and (st2.problems, st2.evaluations) == (P, ev)
+
+
 def test_c4_full_size_shard(sv, oracle_mod):
     """configs[3], one GPU's share at full size: 8 192 independent T_cl problems x 10^4 observations (5.2 GB of
     records), solved by clc_solve_batched and gathered through RCCL.  Size-independent properties on ALL problems
