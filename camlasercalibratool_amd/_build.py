@@ -35,12 +35,13 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
 
 
 def csrc_sha16() -> str:
-    """Identity of what the libraries are built from: sha256 over the bytes of every csrc source (in SOURCES order) and the compiler flags.
-    Constants that were measured on a build (the VALU instruction counts bench.py prices the whole-solve kernels with,
-    profiles/valu_counts.json) carry it, and bench.py refuses them when it differs from the sources in the tree."""
+    """Identity of what the KERNELS are built from: sha256 over the bytes of every csrc header (HEADERS order: all device code lives in
+    the .hpp files; the abi_*.hip units are the host side — launchers, checks, RCCL calls) and the compiler flags.  Constants that were
+    measured on a build (the VALU instruction counts bench.py prices the whole-solve kernels with, profiles/valu_counts.json) carry
+    it, and bench.py refuses them when it differs from the sources in the tree."""
     import hashlib
     h = hashlib.sha256()
-    for s in SOURCES:
+    for s in HEADERS:
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(s.encode() + b"\0" + f.read() + b"\0")
     h.update(" ".join(HIPCC_FLAGS).encode())

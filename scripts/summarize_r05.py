@@ -170,7 +170,9 @@ import subprocess, sys
 sys.path.insert(0, root)
 from camlasercalibratool_amd import _build
 vc = {"csrc_sha16": _build.csrc_sha16(),
-      "head": subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip() or None,
+      # the commit the profile was MEASURED on: --head <sha> when summarising later than measuring (gpurun sends the working tree, which has no .git)
+      "head": (sys.argv[sys.argv.index("--head") + 1] if "--head" in sys.argv else
+               subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip() or None),
       "source": "rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/r03_prof_probe.py: scripts/profile_r05.sh -> scripts/summarize_r05.py "
                 "(profiles/r05_coop.md, r05_resident.md)", "coop": {}, "resident": {}}
 try:
