@@ -2,7 +2,13 @@
 """bench.py — headline benchmark of the point-to-plane extrinsic LM path on MI355X.
 
 Contract:  python bench.py --gpus N --steps K --warmup W
-  (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N>1: launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+  --gpus N ...` — or WITHOUT a launcher: `python bench.py --gpus N` then starts the N ranks itself (it never measures fewer GPUs than
+  it reports: --gpus != WORLD_SIZE is an error).
+
+Output: ONE JSON line of at most 4 KB on stdout (compact_line: the contract's fields + config + roofline + cpu_baseline + parity +
+scale_base + one-number summaries of the side measurements under `side`); the full result — every sub-object of the side measurements —
+goes to bench_detail.json beside this file (`detail_file` on the line; --detail-file moves it) and to stderr.
 
 Workload (BASELINE.json configs[1], "C2"): a single T_cl problem with 10^6 synthetic
 point-to-plane observations (2000 board poses x 500 scan points, range noise sigma = 0.01 m,
@@ -15,17 +21,22 @@ This is the N=1 line: BASELINE.json quotes the metric on C2, and C2 is a single 
 N>1 (BASELINE.json configs[3], "C4"): 65 536 independent T_cl problems x 10^4 observations sharded over
 8 GPUs, i.e. 8 192 problems per GPU — weak scaling, so --gpus N runs 8 192 x N problems.  Every rank GENERATES
 ONLY ITS OWN contiguous shard (problem k is a pure function of (seed, k)), keeps it resident in HBM
-(clc_upload_batched), and a step is: clc_solve_batched of the shard + ONE RCCL all-gather over xGMI of the
-12-double result records of all 8 192 x N problems (clc_gather_results, include/clc.h), inside the timed region.
+(clc_upload_batched), and a step is ONE call, clc_solve_batched_gather (include/clc.h): the on-chip batched solve of the shard, whose
+epilogue writes every problem's 12-double result record into the gather buffer, + ONE RCCL all-gather (in place) over xGMI of the
+records of all 8 192 x N problems + the copy of the other ranks' records to the host, inside the timed region.
 No collective on the data path.  At N=1 the same shard workload (with a world-size-1 RCCL communicator) is reported
-as the `batched_c4_shard` sub-object, the like-for-like base of the 1 -> 8 curve: the N=1 line carries it at top level as
-`scale_base` {workload, value}, the N>1 lines carry `per_gpu_value` (= value / N) to set against it.
+as the `batched_c4_shard` sub-object (detail file; `side.c4_*` on the line), the like-for-like base of the 1 -> 8 curve: the N=1 line
+carries it at top level as `scale_base` {workload, value, ms_per_step}, the N>1 lines carry `per_gpu_value` (= value / N).
+
+Timed region: K steps bracketed by barrier + torch.cuda.synchronize() on both sides, `--blocks` (5) times over; every block's time is
+the MAX over ranks; ms_per_step is the MEDIAN block (min / max / first block ride along).
 
 `roofline` is the dominant kernel of the timed region.  Both whole-solve kernels (coop_solve_kernel at C2, resident_solve_kernel
 at C4) read the data from HBM once per SOLVE and are bound by FP64 VALU issue / latency: their object has "bound": "valu_f64"
-and `frac` = VALU lane-instructions (constants of the build x this run's passes) / this run's kernel time / issue peak;
-`frac_moved` (bytes moved / time / 8 TB/s, bounded by 1) and `contract_64B_frac` (the contract's 64 algorithmic bytes per evaluation,
-not a bandwidth) are siblings.  The streaming kernels' objects have "bound": "hbm" with `frac` = `frac_moved`.
+and `frac` = VALU lane-instructions (measured counts of profiles/valu_counts.json — used only when they belong to the kernel sources
+in the tree — x this run's passes) / this run's kernel time / issue peak; `frac_moved` (bytes moved / time / 8 TB/s, bounded by 1) and
+`contract_64B_frac` (the contract's 64 algorithmic bytes per evaluation, not a bandwidth) are siblings.  The streaming kernels'
+objects (detail file) have "bound": "hbm" with `frac` = `frac_moved`.
 
 value = residual+Jacobian evaluations per second, whole job:
         sum over ranks of (observations x evaluation passes) / max-over-ranks wall time.
