@@ -146,3 +146,14 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_or_refuses():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env2)
     assert p.returncode != 0 and "--gpus 8 but WORLD_SIZE=1" in p.stderr and not p.stdout.strip()
+
+
+def test_committed_valu_counts_belong_to_the_kernel_sources_in_the_tree():
+    """profiles/valu_counts.json (the PMC instruction counts behind roofline.frac) was measured on exactly the kernel sources that are in
+    the tree: a change to any csrc header or to the compiler flags without re-running scripts/profile_r05.sh + scripts/summarize_r05.py
+    turns this red (and bench.py would report frac = null rather than a stale figure)."""
+    counts, info = bench.valu_counts()
+    assert counts is not None and info["current"] is True, info
+    assert "16" in counts["coop"] and 3000 < counts["coop"]["16"]["valu_per_workgroup_pass"] < 3600   # C2: 16 points per lane
+    assert "42" in counts["resident"] and 1300 < counts["resident"]["42"]["valu_per_wave_pass"] < 1700  # C3 / C4: 42 points per lane
+    assert len(info["source_head"]) >= 7
