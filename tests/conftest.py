@@ -23,7 +23,7 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     """A GPU test that never returns (a wedged queue, a collective that never completes) must end the run with a stack dump, not sit
-    until the box's own limit: every gpu test gets a 300 s pytest-timeout limit (the longest, the full-size C4 shard, takes ~20 s),
+    until the box's own limit: every gpu test gets a 600 s pytest-timeout limit (the longest, the full-size C4 shard, takes ~20 s),
     enforced from a watchdog thread — a signal handler cannot run while the main thread is inside a C call that does not return."""
     try:
         import pytest_timeout  # noqa: F401
@@ -31,7 +31,18 @@ def pytest_collection_modifyitems(config, items):
         return
     for item in items:
         if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(300, method="thread"))
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
+def pytest_collection_finish(session):
+    """On a fresh GPU box the first `import torch` pages the wheel in from a cold image — observed: more than five minutes once, inside
+    the first test that needed torch.distributed, whose per-test limit then ended the whole `-x` run.  When GPU tests are selected the
+    import happens here, before any test's clock runs."""
+    if any(item.get_closest_marker("gpu") is not None for item in session.items):
+        try:
+            import torch.distributed  # noqa: F401
+        except ImportError:
+            pass
 
 
 @pytest.fixture(scope="session")
