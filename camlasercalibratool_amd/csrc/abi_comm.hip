@@ -345,6 +345,17 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt_in, const doubl
   unsigned long long now[4];
   std::memcpy(now, c->h_base, sizeof(now));
   if (n_local == 0) std::memcpy(now, c->stats_seen, sizeof(now));  // (no launch: the totals stand)
+  if (n_local > 0 && now[3] != c->stats_seen[3] + (unsigned long long)P) {
+    // the last workgroup publishes the totals when the arrival count reaches stats_seen[3] + P: anything else means an earlier call
+    // left the count and the host's copy of it apart (it returned on an error between its launch and this bookkeeping) — resynchronise
+    // from the device and report this call's totals as unknown rather than as a difference of unrelated numbers
+    unsigned long long dev[4] = {0, 0, 0, 0};
+    CLC_HIP(hipMemcpy(dev, c->d_base, sizeof(dev), hipMemcpyDeviceToHost));
+    std::memcpy(c->stats_seen, dev, sizeof(dev));
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->problems = -1; stats->evaluations = -1; stats->iterations = -1; stats->not_converged = -1; stats->fused = 1; }
+    if (local_rc != CLC_OK) return fail(local_rc, local_msg.c_str());
+    return CLC_OK;
+  }
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->evaluations = (int64_t)(now[0] - c->stats_seen[0]);

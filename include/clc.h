@@ -407,7 +407,8 @@ const clc_result_record* clc_comm_records(const clc_comm* c);
  * the one-launch on-chip solve falls back to the two calls (stats->fused = 0).  Collective call; same error convention as
  * clc_gather_results (a rank with a local error still takes part, with padding records, and reports afterwards). */
 typedef struct clc_batch_stats {
-  int64_t problems;        /* local problems solved by this call */
+  int64_t problems;        /* local problems solved by this call (-1 in all four counters: totals unknown for this call — the call
+                            * after one that failed between its launch and its bookkeeping; the records are complete either way) */
   int64_t evaluations;     /* sum of their evaluation passes (clc_summary.num_evaluations) */
   int64_t iterations;      /* sum of their LM iterations */
   int64_t not_converged;   /* of them: terminated with CLC_NO_CONVERGENCE or CLC_FAILURE */
