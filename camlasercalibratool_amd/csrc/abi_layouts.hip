@@ -253,12 +253,19 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   }
   if (T.coop != nullptr) {
     T.coop->ok = false;
-    // (records with p.z != 0: the cooperative kernel's WITH_Z form holds 24-byte slots — the only on-chip form that does)
+    // (records with p.z != 0: the cooperative kernel's WITH_Z form holds 24-byte slots)
     if (P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && !(T.res != nullptr && T.res->ok)) {
       // the one problem in chunks of equal record counts, one per workgroup (a chunk may begin and end inside a scan: res_scan_extent):
-      // COOP_WGS of them, or COOP_SMALL_WGS where that leaves a lane at most COOP_SMALL_MAX_PPL points (the one-hop form of the kernel)
+      // COOP_WGS of them, or COOP_SMALL_WGS where that leaves a lane at most kCoopSmallMaxPpl points (the one-hop form of the kernel)
       const int cap_ppl = any_z ? clc::COOP_PR_Z + clc::COOP_PL_Z : clc::COOP_PR + clc::COOP_PL;
-      const int small_ppl = std::min(clc::COOP_SMALL_MAX_PPL, cap_ppl);
+      // Up to this many points per lane of 32 workgroups the one-hop form runs (a host-side choice between two launch forms of the same
+      // kernel).  Round 5 sweep (scripts/r05_small_form.py, us per pass, 32 / 256 workgroups): 1e5 observations 5.00 / 5.61, 1.3e5
+      // 5.61 / 5.54, 1.6e5 5.55 / 5.51, 2e5 5.94 / 5.53 — a lane's extra points cost 0.065 us each, the second hop ~1 us: 13 points
+      // per lane (106 496 observations) is where the one-hop form stops paying (round 4: 10).
+      constexpr int kCoopSmallMaxPpl = 13;
+      int small_cap = kCoopSmallMaxPpl;
+      if (const char* e = std::getenv("CLC_COOP_SMALL_MAX_PPL")) small_cap = std::max(1, std::atoi(e));  // (tuning hook: scripts/r05_small_form.py)
+      const int small_ppl = std::min(small_cap, cap_ppl);
       const bool small_ok = n <= (long long)clc::COOP_SMALL_WGS * clc::COOP_NL * small_ppl && (h->auto_disable & 8) == 0;
       for (int attempt = small_ok ? 0 : 1; attempt < 2 && !T.coop->ok; ++attempt) {
         const int wgs = attempt == 0 ? clc::COOP_SMALL_WGS : clc::COOP_WGS;

@@ -45,9 +45,10 @@
 namespace clc {
 
 constexpr int COOP_WGS = 256, COOP_GROUPS = 8, COOP_PER_GROUP = COOP_WGS / COOP_GROUPS, COOP_ROW_WORDS = 64;
-// The small form: problems of at most COOP_SMALL_MAX_PPL points per lane of 32 workgroups run on 32 workgroups with a ONE-hop exchange
-// (every workgroup reads all 32 rows): a pass of ~4-5 us instead of ~5.8 where the 256-workgroup form has 1-2 points per lane.
-constexpr int COOP_SMALL_WGS = 32, COOP_SMALL_MAX_PPL = 10;
+// The small form: problems of few points per lane of 32 workgroups (the host decides up to how many: abi_layouts.hip, kCoopSmallMaxPpl)
+// run on 32 workgroups with a ONE-hop exchange (every workgroup reads all 32 rows): a pass of ~4.5-5 us instead of ~5.5 where the
+// 256-workgroup form has 1-2 points per lane.
+constexpr int COOP_SMALL_WGS = 32;
 // Row strides of the two boards in 8-byte words (>= COOP_ROW_WORDS: a row is 28 elements x 16 bytes = 448 bytes).  Everybody polls the
 // 8 group rows at once; whether rows 512 bytes apart queue behind each other in one memory channel was measured with 1 KB and 4 KB
 // strides (group rows alone, and both boards): no difference (C2 kernel 82.5-83.9 us each way) — the hops are latency, not a hot spot.

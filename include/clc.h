@@ -194,7 +194,7 @@ typedef struct clc_path_info {
   int32_t batched_points_per_lane;
   int32_t rows_layout;             /* single problem's streaming row layout: 0 none, 1 (x, y) rows, 2 rows that carry z */
   int32_t batched_rows_layout;
-  int32_t coop_workgroups;         /* 256, or 32: the one-hop form for problems of at most 32 x 256 x 10 points */
+  int32_t coop_workgroups;         /* 256, or 32: the one-hop form for problems of at most 32 x 256 x 13 points */
   int32_t batched_points_carry_z;  /* 1: the batch has p.z != 0 somewhere and is held on chip in 24-byte slots (512 lanes x <= 22 points per problem) */
   int32_t reserved_;
   int64_t coop_solves;             /* solves that ran on the cooperative kernel */

@@ -271,14 +271,14 @@ def test_cooperative_solve_pass_tags_wrap(sv):
 
 
 def test_small_problems_run_the_one_hop_form_on_32_workgroups(sv, oracle_mod):
-    """Up to 32 x 256 x 10 = 81 920 observations the cooperative solve runs on 32 workgroups, every one of which gathers all 32 rows
+    """Up to 32 x 256 x 13 = 106 496 observations the cooperative solve runs on 32 workgroups, every one of which gathers all 32 rows
     itself: one store-to-load hop per pass instead of two.  Same termination, iteration count and trace decisions as the
     256-workgroup form (clc_set_auto_paths bit 8 at upload) and as the oracle; results to rounding (another summation order);
     bit-repeatable; a launch a workgroup short times out and the step chain answers."""
     import time
     sv.debug_coop_control(reenable=True)
     t_outs = sv.path_info().coop_timeouts
-    for n_poses, pts, loss in ((24, 500, 1), (100, 500, 1), (163, 500, 0), (300, 137, 1)):
+    for n_poses, pts, loss in ((24, 500, 1), (100, 500, 1), (163, 500, 0), (300, 137, 1), (212, 500, 1)):
         rec = clc.flatten_observations(sd.sim_fixed_count(31 + n_poses, n_poses, pts, noise_sigma=0.01), False)
         o, oo = clc.default_options(), oracle_mod.default_options()
         o.use_loss = oo.use_loss = loss
@@ -286,7 +286,7 @@ def test_small_problems_run_the_one_hop_form_on_32_workgroups(sv, oracle_mod):
         sv.set_auto_paths(0)
         sv.upload(rec)
         pi = sv.path_info()
-        assert pi.coop_resident == 1 and pi.coop_workgroups == 32 and pi.coop_points_per_lane <= 10, (n_poses, pts)
+        assert pi.coop_resident == 1 and pi.coop_workgroups == 32 and pi.coop_points_per_lane <= 13, (n_poses, pts)
         n0 = pi.coop_solves
         r = sv.solve(X0, o)
         r2 = sv.solve(X0, o)
@@ -303,8 +303,8 @@ def test_small_problems_run_the_one_hop_form_on_32_workgroups(sv, oracle_mod):
             assert _dT(x.pose, ref.pose) <= T_TOL and abs(x.summary.final_cost - ref.summary.final_cost) <= COST_TOL
         assert _key(r.summary) == _key(w.summary) and np.abs(r.pose - w.pose).max() <= 1e-9
         assert [(a.step_is_valid, a.step_is_successful) for a in r.trace] == [(a.step_is_valid, a.step_is_successful) for a in w.trace]
-    # 81 921 observations: one lane would need an 11th point -> 256 workgroups
-    rec = clc.flatten_observations(sd.sim_fixed_count(5, 164, 500, noise_sigma=0.01), False)
+    # 107 000 observations: some lane would need a 14th point -> 256 workgroups
+    rec = clc.flatten_observations(sd.sim_fixed_count(5, 214, 500, noise_sigma=0.01), False)
     sv.upload(rec)
     assert sv.path_info().coop_workgroups == 256
     # the one-hop launch a workgroup short: bounded time-out, the step chain's answer, the path rests and comes back
