@@ -278,7 +278,7 @@ def test_small_problems_run_the_one_hop_form_on_32_workgroups(sv, oracle_mod):
     import time
     sv.debug_coop_control(reenable=True)
     t_outs = sv.path_info().coop_timeouts
-    for n_poses, pts, loss in ((24, 500, 1), (100, 500, 1), (163, 500, 0), (300, 137, 1), (212, 500, 1)):
+    for n_poses, pts, loss in ((24, 500, 1), (100, 500, 1), (163, 500, 0), (300, 137, 1), (200, 500, 1)):
         rec = clc.flatten_observations(sd.sim_fixed_count(31 + n_poses, n_poses, pts, noise_sigma=0.01), False)
         o, oo = clc.default_options(), oracle_mod.default_options()
         o.use_loss = oo.use_loss = loss
