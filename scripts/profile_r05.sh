@@ -15,7 +15,7 @@ run() {  # name, timeout, rocprof args..., -- target args
 P="python $R/scripts/r03_prof_probe.py"
 VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU SQ_INSTS_LDS"
 if [ "$1" != "--bench-only" ]; then
-run coop_trace 120 --kernel-trace --stats --output-format csv -d $O/coop_trace -o w -- $P coop 1000000
+CLC_PROBE_SOLVES=60 run coop_trace 120 --kernel-trace --stats --output-format csv -d $O/coop_trace -o w -- $P coop 1000000
 run coop_fetch 120 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/coop_fetch -o w -- $P coop 1000000
 run coop_write 120 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/coop_write -o w -- $P coop 1000000
 run coop_valu 120 --pmc $VALU --kernel-trace --output-format csv -d $O/coop_valu -o w -- $P coop 1000000

@@ -56,7 +56,7 @@ if inf:
     rd, wr = 2 * 1024 * statistics.median(fetch), 1024 * statistics.median(write)
     passes = inf.get("passes", 0)
     L = ["# rocprofv3 evidence for the cooperative solve, round 5 (MI355X) — `scripts/profile_r05.sh`", "",
-         f"Target: `scripts/r03_prof_probe.py coop 1000000` — 5 default `clc_solve` of the C2 problem (1e6 observations, {inf.get('points_per_lane')} points per lane, "
+         f"Target: `scripts/r03_prof_probe.py coop 1000000` — {len(d)} (trace run; 5 in the counter runs) default `clc_solve` of the C2 problem (1e6 observations, {inf.get('points_per_lane')} points per lane, "
          f"{passes} evaluation passes per solve), each ONE launch of `coop_solve_kernel` (5 waves per workgroup: 4 point waves + the controller wave of "
          f"`csrc/clc_lmuni.hpp`); launches that timed out: {inf.get('aborts')}.", "",
          "| | round 5 | round 3 (`profiles/r03_coop.md`; round 4: `profiles/r04_coop.md`) |", "|---|---|---|",
