@@ -202,7 +202,8 @@ static int create_init(clc_handle* h) {
     warm_layouts();
     warm_solve();
     warm_frontend();
-    warm_batched();
+    // (the batched unit's code object — the twelve resident instantiations, a quarter of the library — is loaded by the first
+    // clc_upload_batched instead: the reference's one calibration per process never launches a batched kernel)
     // ... and what else only the FIRST launch / copy / allocation of a process pays: the stream's hardware queue (first launch), the
     // runtime's staging buffers for pageable copies (first hipMemcpy each way), the buffers every solve uses
     hipLaunchKernelGGL(first_launch_kernel, dim3(1), dim3(64), 0, h->stream, h->d_queue);

@@ -463,6 +463,11 @@ int upload_batched_impl(clc_handle* h, const clc_observation* records, bool on_d
   if (!h || !offsets || (n_problems > 0 && !records))
     return fail(CLC_ERR_INVALID_ARG, "clc_upload_batched: bad argument");
   CLC_HIP(hipSetDevice(h->device));
+  {  // the batched unit's code object: loaded here, once per device and process, before the first batched solve (see clc_create)
+    static std::atomic<bool> warm[64];
+    std::atomic<bool>& w = warm[h->device >= 0 && h->device < 64 ? h->device : 0];
+    if (!w.exchange(true) && !std::getenv("CLC_LAZY_MODULES")) warm_batched();
+  }
   const size_t P = n_problems;
   std::vector<long long> tile_off(P + 1, 0), nobs(P, 0);
   long long max_tiles = 0;

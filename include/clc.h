@@ -125,10 +125,11 @@ const char* clc_last_error(void);
 void clc_options_default(clc_options* opt);
 
 /* ---- handle ------------------------------------------------------------------------- */
-/* Creates a solver context on HIP device `device` (one stream, scratch buffers).  It also loads the kernels' code objects and pays
- * what only the first launch / copy / allocation of a process pays (~20 ms next to the ~150 ms of HIP context creation), so that the
- * first call on the handle costs about what a warm one does — the reference's programs call the path once per process
- * (main/calibr_offline.cpp:166-170).  CLC_LAZY_MODULES=1 in the environment leaves that to the first launches.
+/* Creates a solver context on HIP device `device` (one stream, scratch buffers).  It also loads the code objects of the single-problem
+ * paths and pays what only the first launch / copy / allocation of a process pays (tens of ms next to the ~130-150 ms of HIP context
+ * creation), so that the first call on the handle costs about what a warm one does — the reference's programs call the path once
+ * per process (main/calibr_offline.cpp:166-170).  The batched kernels' code object is loaded by the first clc_upload_batched.
+ * CLC_LAZY_MODULES=1 in the environment leaves all of it to the first launches.
  * CLC_ERR_NO_DEVICE without a GPU: there is no CPU fallback. */
 int clc_create(clc_handle** out, int device);
 void clc_destroy(clc_handle* h);
