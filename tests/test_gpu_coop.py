@@ -200,10 +200,13 @@ def test_two_handles_solving_at_once(oracle_mod):
     ref = oracle_mod.solve(rec, X0, linear_solver="qr")
     out = {}
 
+    ready = threading.Barrier(2, timeout=60)
+
     def work(name):
         s = clc.Solver(0)
         try:
             s.upload(rec)
+            ready.wait()  # (both uploads are done: what overlaps from here on is cooperative solves only — what the gate is about)
             out[name] = [s.solve(X0) for _ in range(30)] + [s.debug_coop()]
         finally:
             s.close()
