@@ -173,7 +173,7 @@ int clc_create(clc_handle** out, int device) {
 static int create_init(clc_handle* h) {
   if (const char* e = std::getenv("CLC_AUTO_PATHS_DISABLE")) {
     const int m = std::atoi(e);
-    if (m >= 0 && m <= 15) h->auto_disable = m;
+    if (m >= 0 && m <= 31) h->auto_disable = m;
   }
   CLC_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
@@ -263,7 +263,7 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_auto_paths(clc_handle* h, int disable_mask) {
-  if (!h || disable_mask < 0 || disable_mask > 15) return fail(CLC_ERR_INVALID_ARG, "clc_set_auto_paths: bad argument");
+  if (!h || disable_mask < 0 || disable_mask > 31) return fail(CLC_ERR_INVALID_ARG, "clc_set_auto_paths: bad argument");
   h->auto_disable = disable_mask;
   return CLC_OK;
 }

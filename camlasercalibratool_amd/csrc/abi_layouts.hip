@@ -254,7 +254,9 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   if (T.coop != nullptr) {
     T.coop->ok = false;
     // (records with p.z != 0: the cooperative kernel's WITH_Z form holds 24-byte slots)
-    if (P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && !(T.res != nullptr && T.res->ok)) {
+    // (clc_set_auto_paths bit 16: the cooperative layout also for a problem one workgroup holds — clc_solve then prefers it)
+    const bool small_on_coop = (h->auto_disable & 16) != 0;
+    if (P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && (small_on_coop || !(T.res != nullptr && T.res->ok))) {
       // the one problem in chunks of equal record counts, one per workgroup (a chunk may begin and end inside a scan: res_scan_extent):
       // COOP_WGS of them, or COOP_SMALL_WGS where that leaves a lane at most kCoopSmallMaxPpl points (the one-hop form of the kernel)
       const int cap_ppl = any_z ? clc::COOP_PR_Z + clc::COOP_PL_Z : clc::COOP_PR + clc::COOP_PL;

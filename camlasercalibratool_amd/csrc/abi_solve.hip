@@ -527,12 +527,16 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 
   // a problem one workgroup holds: the whole solve in one single-workgroup launch (default flags only: the explicit flag
   // sets select the step chain / launch pair the bit-identity tests compare; profile_events = 1 asks for per-pass events)
-  if (h->sres.ok && h->launch_auto && (h->auto_disable & 2) == 0 && h->grid_override == 0 && opt.profile_events != 1) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
-  // a problem the 256 CUs hold together: the whole solve in one launch of 256 co-resident workgroups (same conditions)
+  // (clc_set_auto_paths bit 16 at upload: such a problem ALSO has the cooperative layout and runs on 32 workgroups first — 4.6 instead
+  // of 5.3-5.9 us per pass —, with this kernel as the fall-back when the cooperative launch times out or rests)
+  const bool single_ok = h->sres.ok && h->launch_auto && (h->auto_disable & 2) == 0 && h->grid_override == 0 && opt.profile_events != 1;
+  if (single_ok && !(h->cres.ok && (h->auto_disable & 16) != 0)) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
+  // a problem the 256 CUs hold together: the whole solve in one launch of 256 (or 32) co-resident workgroups (same conditions)
   if (h->cres.ok && h->launch_auto && (h->auto_disable & 1) == 0 && h->grid_override == 0 && opt.profile_events != 1 && ++h->coop_eligible > h->coop_retry_at) {
     const int rc = solve_coop(h, opt, pose, summary, trace, trace_cap, t0);
     if (rc != kCoopFallback) return rc;
   }
+  if (single_ok) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
   const int grid = eval_grid(h, h->n_obs);
   int rc = ensure_partials(h, grid);
   if (rc != CLC_OK) return rc;

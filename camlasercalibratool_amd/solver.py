@@ -169,7 +169,9 @@ class Solver:
 
     def set_auto_paths(self, disable_mask: int = 0):
         """clc_set_auto_paths: 1 = no cooperative one-launch solve, 2 = no single-workgroup on-chip solve,
-        4 = the single-workgroup solve runs the cooperative kernel's register-resident controller; 0 = library default."""
+        4 = the single-workgroup solve runs the cooperative kernel's register-resident controller, 8 = (at upload) not the 32-workgroup
+        one-hop form, 16 = (at upload) problems one workgroup holds also get the cooperative layout and run on 32 workgroups first;
+        0 = library default."""
         check(self._L.clc_set_auto_paths(self._h, C.c_int(disable_mask)), "clc_set_auto_paths")
 
     def set_launch(self, grid_blocks: int = 0, flags: int = 0):

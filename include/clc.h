@@ -172,8 +172,13 @@ int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
  * 4 = the single-workgroup solve runs the LM controller of the cooperative kernel (wave-uniform arithmetic, state in registers)
  *     instead of its own (state in LDS) — same arithmetic, bit-identical results, slower there; how the cooperative kernel's
  *     controller is compared with the serial one on identical totals (tests/test_gpu_lmuni.py).
- * 8 = (at upload) not the 32-workgroup one-hop form of the cooperative solve for problems of at most 81 920 observations
+ * 8 = (at upload) not the 32-workgroup one-hop form of the cooperative solve for problems of at most 106 496 observations
  *     (every workgroup reads all 32 rows itself: one store-to-load hop per pass instead of two) — the 256-workgroup form then.
+ * 16 = (at upload; the one bit that switches something ON) a problem one workgroup holds (n <= 11 264) ALSO gets the cooperative layout
+ *     and clc_solve runs it on 32 co-resident workgroups first — 4.6 instead of 5.3-5.9 us per pass (C1 0.132 -> 0.116 ms per solve,
+ *     10 000 observations 0.135 -> 0.107) —, with the single-workgroup kernel as the fall-back when that launch times out or rests.
+ *     Not the default: upload and first solve cost ~0.2 ms more (a second layout, the exchange boards), which the reference's one
+ *     calibration per process never earns back; worth it from about a dozen solves per upload on an otherwise idle GPU.
  * 0 = library default.  The environment variable CLC_AUTO_PATHS_DISABLE sets the initial mask of every handle. */
 int clc_set_auto_paths(clc_handle* h, int disable_mask);
 

@@ -324,3 +324,48 @@ def test_small_problems_run_the_one_hop_form_on_32_workgroups(sv, oracle_mod):
     sv.debug_coop_control(reenable=True)
     again = sv.solve(X0)
     assert np.array_equal(again.pose, good.pose)
+
+
+def test_small_problems_on_32_workgroups_by_request(sv, oracle_mod):
+    """clc_set_auto_paths bit 16 (at upload): a problem one workgroup holds ALSO gets the cooperative layout and clc_solve runs it on 32
+    co-resident workgroups (the faster pass); same decisions as the single-workgroup kernel and the oracle; when the cooperative launch
+    cannot complete (a workgroup short) the single-workgroup kernel answers — not the step chain; without the bit nothing changes."""
+    S = sd.GenerateSimData(1, noise_sigma=0.01)  # the reference's C1 size
+    rec = clc.flatten_observations(S, False)
+    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
+    sv.debug_coop_control(reenable=True)
+    sv.set_launch(0, -1)
+    sv.set_auto_paths(0)
+    sv.upload(rec)
+    assert sv.path_info().single_resident == 1 and sv.path_info().coop_resident == 0
+    single = sv.solve(X0)
+    try:
+        sv.set_auto_paths(16)
+        sv.upload(rec)
+        pi = sv.path_info()
+        assert pi.single_resident == 1 and pi.coop_resident == 1 and pi.coop_workgroups == 32
+        n0, t0 = pi.coop_solves, pi.coop_timeouts
+        r = sv.solve(X0)
+        assert sv.path_info().coop_solves == n0 + 1 and sv.path_info().coop_timeouts == t0
+        for x in (single, r):
+            assert x.summary.termination == ref.summary.termination and x.summary.num_iterations == ref.summary.num_iterations
+            assert _dT(x.pose, ref.pose) <= T_TOL and abs(x.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+        assert _key(r.summary) == _key(single.summary) and np.abs(r.pose - single.pose).max() <= 1e-9
+        assert len(r.trace) == len(single.trace)
+        # the cooperative launch a workgroup short: it times out, and the SINGLE-WORKGROUP kernel answers, bit for bit its own result
+        sv.debug_coop_control(drop_next=1)
+        bad = sv.solve(X0)
+        assert sv.path_info().coop_timeouts == t0 + 1
+        assert np.array_equal(bad.pose, single.pose) and bad.summary.final_cost == single.summary.final_cost
+        # while the cooperative path rests, the single-workgroup kernel keeps answering
+        again = sv.solve(X0)
+        assert np.array_equal(again.pose, single.pose)
+        sv.debug_coop_control(reenable=True)
+        assert np.array_equal(sv.solve(X0).pose, r.pose)
+        # the bit cleared at solve time: the single-workgroup kernel, although both layouts are there
+        sv.set_auto_paths(0)
+        n1 = sv.path_info().coop_solves
+        assert np.array_equal(sv.solve(X0).pose, single.pose) and sv.path_info().coop_solves == n1
+    finally:
+        sv.set_auto_paths(0)
+        sv.debug_coop_control(reenable=True)
