@@ -519,6 +519,10 @@ def compact_line(out, detail_file=None):
     if isinstance(rl, dict):
         summ["large"] = _pick(rl, ("frac", "frac_min", "frac_max", "after_idle_worst_frac", "avg_kernel_ms", "kernel_ms_min", "kernel_ms_max", "observations", "launches"), 5)
         summ["large"]["stat"] = rl.get("stat")
+    lsv = out.get("roofline_large_solve")
+    if isinstance(lsv, dict) and "frac" in lsv:
+        summ["large_solve_frac"] = _num(lsv["frac"], 4)
+        summ["large_solve"] = _pick(lsv, ("us_per_pass", "evaluation_passes", "ms_per_solve", "step_period_us", "observations"), 5)
     if isinstance(cs, dict):
         for shape in ("c1", "offline"):
             d = cs.get(shape) or {}
@@ -805,7 +809,6 @@ def main():
         big = np.ascontiguousarray(np.tile(rec, (reps, 1))[: args.large_obs])
         nb = int(big.shape[0])
         hs.upload(big)
-        del big
         rows_ok_l, n_rows_l, _, _ = hs.debug_rows()
         streamed_l = (n_rows_l * ROW_BYTES) if rows_ok_l else COMPACT_BYTES_PER_EVAL * nb
         # The same launch takes 85 us in steady state and up to ~125 us for a few milliseconds after an idle -> load transition (a
@@ -839,6 +842,54 @@ def main():
                  "contract's 64 algorithmic bytes per evaluation and exceeds 1 because the layout is a 3.8x lossless compression",
             compact28=dict(hbm_figures(COMPACT_BYTES_PER_EVAL * nb, BYTES_PER_EVAL * nb, msc * 1e-3), avg_kernel_ms=msc),
             tiled64=dict(hbm_figures(BYTES_PER_EVAL * nb, BYTES_PER_EVAL * nb, ms64 * 1e-3), avg_kernel_ms=ms64))
+        # ---- the WHOLE default-path clc_solve at this size (SURVEY.md §8 row g): no on-chip form holds 3.2e7 observations, so the default
+        # path is the step chain — one step_kernel launch per LM iteration (controller on the previous launch's partial rows in front, then
+        # the rows re-streamed from HBM).  Per pass = wall time of a solve / its evaluation passes, controller and launch boundary included.
+        try:
+            pi_l = hs.path_info()
+            for _ in range(20):  # ~30 ms of sustained load first (the clock transient above)
+                rl_ = hs.solve(x0, trace_cap=0)
+            walls = []
+            for _ in range(9):
+                t1 = time.perf_counter()
+                rl_ = hs.solve(x0, trace_cap=0)
+                walls.append(time.perf_counter() - t1)
+            passes_l = int(rl_.summary.num_evaluations)
+            wall = float(np.median(walls))
+            per_pass = wall / passes_l
+            period_ms, _ = hs.time_steps(x0, 2, passes_l - 2)  # HIP events around launches 2 .. passes-2 of one more solve
+            ls = dict(hbm_figures(streamed_l, BYTES_PER_EVAL * nb, per_pass),
+                      observations=nb, streamed_bytes_per_pass=int(streamed_l), evaluation_passes=passes_l,
+                      lm_iterations=int(rl_.summary.num_iterations), termination=rl_.termination,
+                      ms_per_solve=1e3 * wall, ms_per_solve_min=1e3 * min(walls), ms_per_solve_max=1e3 * max(walls), us_per_pass=1e6 * per_pass,
+                      step_period_us=1e3 * period_ms, frac_step_period=streamed_l / (period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      eval_kernel_alone_us=1e3 * ms, frac_eval_kernel_alone=streamed_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      default_path="step chain" if not (pi_l.coop_resident or pi_l.single_resident) else "on chip",
+                      kernel="clc::step_kernel<loss=1,nt=1,mode 0|1|2,rows,equal shares> x passes (one launch per LM iteration)",
+                      served_from="infinity_cache" if streamed_l <= INFINITY_CACHE_BYTES else "hbm", traffic_measured_in_run=False,
+                      stat="median of 9 solves after 20 warm ones; per pass = wall / evaluation passes (launch boundary + partial rows + LM controller included)",
+                      where_the_difference_goes="profiles/r06_large_solve.md: launch boundary 3.9 us + partial rows 2.3 + barrier 0.6 + controller 3.1 in "
+                                                "front of ~88 us of streaming (stamped build); overlapping them (deeper launch queue, LDS-DMA prefetch) "
+                                                "was measured slower: the part runs power-managed in this regime")
+            tfile = os.path.join(ROOT, "profiles", "pmc_traffic_large_solve.json")
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    ls["traffic"] = tj.get("hbm_bytes_per_launch")
+                    ls["traffic_source"] = tj.get("source")
+                except Exception:
+                    pass
+            if not args.no_cpu_baseline:  # parity of this very solve (normal-equation oracle with threads: the dense-Jacobian QR is 1.5 GB here)
+                import oracle
+                ref_l = oracle.solve(big, x0, linear_solver="ne", threads=min(64, oracle.max_threads()))
+                ls["parity"] = {"oracle": "oracle/clc_oracle.cpp, normal-equation form, threads (pinned against DENSE_QR on the CPU: tests/test_oracle_solver.py)",
+                                "T_cl_max_abs_err": float(np.abs(sd.T_from_pose7(rl_.pose) - sd.T_from_pose7(ref_l.pose)).max()),
+                                "final_cost_abs_err": float(abs(rl_.summary.final_cost - ref_l.summary.final_cost)),
+                                "iterations_gpu": int(rl_.summary.num_iterations), "iterations_oracle": int(ref_l.summary.num_iterations)}
+            out["roofline_large_solve"] = ls
+        except Exception as e:  # (never fatal for the line)
+            out["roofline_large_solve"] = {"error": repr(e)}
+        del big
         hs.upload(rec[:64])  # (frees nothing: the handle keeps its capacity; the large array is simply no longer referenced)
 
     # ---- BASELINE.json configs[2] (C3): 1 024 independent T_cl problems x 10^4 observations ----

@@ -4,6 +4,7 @@
    step N          5 clc_solve of an N-observation problem through the step-kernel chain
    coop N [ITERS]  5 default clc_solve of an N-observation problem: one coop_solve_kernel launch each (csrc/clc_coop.hpp); ITERS caps
                    max_num_iterations (two pass counts give the instructions per pass)
+   large N         30 default clc_solve of ONE N-observation problem beyond the chip's capacity (the step chain; the last 10 behind a marker kernel)
    eval N          20 launches of the row-layout evaluation kernel on N observations + 20 of the 64-byte-tile kernel (PMC calibration)"""
 import json, os, sys, time
 import numpy as np
@@ -44,6 +45,19 @@ elif what in ("coop", "coopz"):
     _, _, solves, aborts, off = sv.debug_coop()
     out.update(workgroups=sv.path_info().coop_workgroups, z=sv.path_info().coop_points_carry_z, coop_built=built, points_per_lane=ppl, coop_solves=solves, aborts=aborts, passes=int(r.summary.num_evaluations), solve_ms=r.summary.solve_ms,
                lane_layout_bytes=256 * ppl * 256 * 16 + 256 * 256 * 8 + (n // 500) * 48)
+elif what == "large":  # the DEFAULT clc_solve of one problem beyond the chip (step chain; n >= 2.7e6): 20 warm solves, a marker, 10 solves
+    rec = clc.flatten_observations(sd.sim_fixed_count(1000 + n // 500, n // 500, 500, noise_sigma=0.01), False)
+    sv.upload(rec)
+    pi = sv.path_info()
+    for _ in range(20):
+        r = sv.solve(x0, trace_cap=0)
+    sv.pose_plus(x0[None, :], np.zeros((1, 6)))  # marker
+    ts = []
+    for _ in range(10):
+        t = time.perf_counter(); r = sv.solve(x0, trace_cap=0); ts.append(time.perf_counter() - t)
+    sv.pose_plus(x0[None, :], np.zeros((1, 6)))
+    out.update(observations=int(rec.shape[0]), coop_resident=int(pi.coop_resident), n_rows=int(pi.n_rows), row_layout_bytes=int(pi.n_rows) * (64 * 16 + 64),
+               passes=int(r.summary.num_evaluations), iterations=int(r.summary.num_iterations), solve_ms_median=1e3 * float(np.median(ts)))
 elif what == "step":
     rec = clc.flatten_observations(sd.sim_fixed_count(1000, n // 500, 500, noise_sigma=0.01), False)
     sv.set_launch(0, BASE)

@@ -1039,3 +1039,40 @@ def test_c4_full_size_shard(sv, oracle_mod):
         assert np.array_equal(one.start_poses()[0], x0[k])
         assert raw[k, 9] == ref.summary.num_iterations and raw[k, 10] == ref.summary.termination, k
         assert _dT(raw[k, :7], ref.pose) <= T_TOL and abs(raw[k, 7] - ref.summary.final_cost) <= COST_TOL, k
+
+
+# ---------------------------------------------------------------------------------------
+# the reference iterates ONE ceres::Solve over whatever N it is given
+# (src/LaseCamCalCeres.cpp:299-309).  Beyond what the chip holds (> 256 x 256 x 40 observations) clc_solve with the DEFAULT flags runs the
+# step chain (csrc/clc_kernels.hpp step_kernel: one launch per LM iteration, the rows re-streamed from the Infinity Cache / from HBM).
+@pytest.mark.parametrize("n_poses, beyond_cache", [(8000, False), (64000, True)])
+def test_default_path_beyond_chip_capacity(oracle_mod, n_poses, beyond_cache):
+    """4e6 observations (70 MB of rows: cache-resident) and 3.2e7 (557 MB: beyond the 256 MiB Infinity Cache, non-temporal row loads), default
+    flags, against the oracle: same termination and iteration count, T_cl <= 1e-6, cost <= 1e-8, every trace record's decision equal, and
+    the solve repeats bit for bit.  Oracle: DENSE_QR at 4e6; at 3.2e7 the normal-equation form with threads (the dense 3.2e7 x 6 Jacobian +
+    Householder QR is 1.5 GB and ~100 s per solve on one core; test_oracle_solver.py pins 'ne' against 'qr' to 1e-15 on the CPU)."""
+    rec = clc.flatten_observations(sd.sim_fixed_count(1000 + n_poses, n_poses, 500, noise_sigma=0.01), False)
+    assert rec.shape[0] == n_poses * 500
+    with clc.Solver(0) as s:
+        s.upload(rec)
+        pi = s.path_info()
+        assert pi.coop_resident == 0 and pi.single_resident == 0  # neither on-chip form holds it: the step chain is the default path
+        assert pi.rows_layout == 1 and pi.n_rows == n_poses * 8   # 500-point scans = 8 rows of 64
+        layout_bytes = pi.n_rows * (64 * 16 + 64)
+        assert (layout_bytes > (256 << 20) * 3 // 2) == beyond_cache
+        res = s.solve(X0)
+        again = s.solve(X0)
+        assert s.path_info().coop_solves == 0
+    ref = oracle_mod.solve(rec, X0, linear_solver="ne" if beyond_cache else "qr",
+                           threads=min(64, oracle_mod.max_threads()) if beyond_cache else 1)
+    assert res.summary.termination == ref.summary.termination == 3  # CONVERGENCE(function)
+    assert res.summary.num_iterations == ref.summary.num_iterations
+    assert _dT(res.pose, ref.pose) <= T_TOL
+    assert abs(res.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+    assert abs(res.summary.initial_cost - ref.summary.initial_cost) <= 1e-11 * ref.summary.initial_cost
+    assert len(res.trace) == len(ref.trace)
+    for a, b in zip(res.trace, ref.trace):
+        assert (a.step_is_valid, a.step_is_successful) == (b.step_is_valid, b.step_is_successful)
+        assert abs(a.cost - b.cost) <= 1e-11 * max(b.cost, 1e-300)
+    assert np.array_equal(res.pose, again.pose) and res.summary.final_cost == again.summary.final_cost  # fixed summation order
+    assert np.abs(sd.T_from_pose7(res.pose) - sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)).max() < 2e-3  # ground truth; sigma = 0.01 m over >= 4e6 points
