@@ -122,6 +122,8 @@ def parse():
     ap.add_argument("--pts", type=int, default=500)
     ap.add_argument("--noise", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-all-ranks", action="store_true", help="N>1 step: ncclAllGather + a host copy of every record on EVERY rank (default: gather to rank 0)")
+    ap.add_argument("--no-pipeline", action="store_true", help="N>1 step: the plain one-call step instead of the pipelined stream of steps")
     ap.add_argument("--kernel-events", action="store_true",
                     help="bracket every evaluation-kernel launch with HIP event pairs INSIDE the timed region "
                          "(perturbs the timed solves; default: events are used after the timed region)")
@@ -297,7 +299,10 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
 
     n_total = args.problems_total if args.problems_total > 0 else args.problems_per_gpu * world
     t_gen0 = time.perf_counter()
-    ss = cdist.ShardSolver(n_total, device_index=local_rank, rank=rank, world=world, use_rccl=use_rccl)
+    # the gathered records are delivered to rank 0 (clc_comm_set_root: ncclGather, one host copy at the root) unless
+    # --gather-all-ranks asks for the all-gather + a host copy on every rank
+    root = 0 if (use_rccl and not args.gather_all_ranks) else None
+    ss = cdist.ShardSolver(n_total, device_index=local_rank, rank=rank, world=world, use_rccl=use_rccl, root=root)
     rccl_ranks = None
     if ss.comm is not None:  # RCCL itself must span the job: a future SCALE record shows that it saw N ranks
         rccl_ranks = ss.comm.rccl_ranks
@@ -323,15 +328,24 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
     # The step: with the RCCL communicator ONE call, clc_solve_batched_gather (the kernel's epilogue writes the result records into the
     # gather buffer; all-gather in place; one copy to the host); in the gloo dry runs the two calls + torch.distributed.
     fused = ss.comm is not None and not args.two_call_step
+    # a stream of steps: clc_solve_batched_gather_pipelined — call k enqueues step k and hands back step k-1; the root's copy of the other
+    # ranks' records to its host runs behind step k's kernel.  The flush that completes the last step is INSIDE the timed region.
+    pipelined = fused and not args.no_pipeline
 
     def step():
+        if pipelined:
+            return ss.solve_gather_pipelined(x0, ordered=False)
         if fused:
             return ss.solve_gather(x0, ordered=False, copy=False)
         # start poses into the handle's pinned buffer, solve this shard in place, all-gather of all ranks' records
         return ss.solve(x0, ordered=False, copy=False, inplace=True)
 
+    def finish(last):
+        return ss.flush(ordered=False) if pipelined else last
+
     for _ in range(warmup):
         step()
+    finish(None)
     # the timed region: `steps` steps bracketed by barrier + synchronize on both sides, `blocks` times over; every block's time is
     # the MAX over ranks, ms_per_step the median block
     block_s = []
@@ -340,6 +354,7 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
+        out = finish(out)
         barrier()
         block_s.append(time.perf_counter() - t0)
     per = args.shard_poses * args.shard_pts
@@ -359,6 +374,7 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
         block_s, evals_step, iters_step = [float(v) for v in tmax], float(t[0]), float(t[1])
     elapsed = float(np.median(block_s))
     res = None
+    ci = ss.comm.info() if ss.comm is not None else None
     if rank == 0:
         raw = np.array(out).reshape(-1, 12)
         full = cdist.order_records(raw, n_total)
@@ -376,9 +392,15 @@ def run_c4_shard(args, torch, dist, rank, world, local_rank, steps, warmup, use_
             "lm_iters_per_s": iters_step / dt,
             "lm_iterations_min_max": [int(its.min()), int(its.max())],
             "terminations": {clc.TERMINATION.get(int(c), str(int(c))): int((full[:, 10] == c).sum()) for c in np.unique(full[:, 10])},
-            "step_call": ("clc_solve_batched_gather (one launch whose epilogue writes the records into the gather buffer + in-place ncclAllGather + one D2H copy, "
+            "step_call": (("clc_solve_batched_gather_pipelined (step k's launch + collective enqueued, step k-1's records handed back; " if pipelined else "clc_solve_batched_gather (")
+                          + "one launch whose epilogue writes the records into the gather buffer + in-place collective + the host copy at the root, "
                           f"fused={int(ss.last_stats.fused)})" if fused else "clc_solve_batched + clc_gather_results" if use_rccl else "clc_solve_batched + torch.distributed all_gather"),
-            "gather": {"collective": ("ncclAllGather (in place) via clc_solve_batched_gather" if fused else "ncclAllGather via clc_gather_results") if use_rccl else "torch.distributed all_gather (dry run)",
+            "gather": {"collective": (("ncclGather to rank 0 (in place)" if (ci is not None and ci.rooted_collectives > 0) else "ncclAllGather (in place)")
+                                      + (" via clc_solve_batched_gather" + ("_pipelined" if pipelined else "") if fused else " via clc_gather_results")) if use_rccl
+                                     else "torch.distributed all_gather (dry run)",
+                       "root": root, "host_copy_ranks": (1 if root is not None else world) if use_rccl else None, "pipelined": bool(pipelined),
+                       "host_copy_bytes_per_step_at_root": (96 * ss.cap * (world - 1)) if use_rccl else None,
+                       "rooted_collectives": int(ci.rooted_collectives) if ci is not None else None, "collectives": int(ci.collectives) if ci is not None else None,
                        "library": ss.comm.library if ss.comm is not None else None, "rccl_ranks": rccl_ranks,
                        "bytes_per_rank": 96 * ss.cap, "bytes_total": 96 * ss.cap * world,
                        "records_per_rank": ss.cap, "padding_records": int((raw[:, 11] < 0).sum()),
@@ -514,6 +536,7 @@ def compact_line(out, detail_file=None):
         summ["c4_kernel_ms"], summ["c4_kernel_frac"] = _num(k4.get("avg_kernel_ms"), 5), _num(k4.get("frac"), 4)
         g = c4.get("gather") or {}
         summ["c4_rccl_ranks"] = g.get("rccl_ranks")
+        summ["c4_gather"] = {"root": g.get("root"), "host_copy_ranks": g.get("host_copy_ranks"), "pipelined": g.get("pipelined")}
     elif isinstance(c4, dict) and "error" in c4:
         summ["c4_error"] = _short(c4["error"], 120)
     if isinstance(rl, dict):

@@ -29,7 +29,8 @@ EXPORTED = [
     "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
     "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",
     "clc_comm_unique_id", "clc_comm_create", "clc_comm_destroy", "clc_comm_rank", "clc_comm_world",
-    "clc_gather_results", "clc_comm_records", "clc_solve_batched_gather",
+    "clc_gather_results", "clc_comm_records", "clc_solve_batched_gather", "clc_comm_set_root", "clc_comm_get_info",
+    "clc_solve_batched_gather_pipelined", "clc_gather_flush",
     "clc_store_observations", "clc_select_observations", "clc_upload_batched_device", "clc_line_fit_batched_device",
     "clc_scan_to_points_device", "clc_pinned_alloc", "clc_pinned_free", "clc_store_generation", "clc_batched_host_buffers",
     "clc_get_path_info", "clc_device_info", "clc_comm_library",
@@ -99,6 +100,13 @@ class BatchStats(C.Structure):
     """clc_batch_stats (include/clc.h): the local shard's totals of one clc_solve_batched_gather."""
     _fields_ = [("problems", C.c_int64), ("evaluations", C.c_int64), ("iterations", C.c_int64), ("not_converged", C.c_int64),
                 ("fused", C.c_int32), ("pad_", C.c_int32), ("kernel_ms", C.c_double), ("solve_ms", C.c_double)]
+
+
+class CommInfo(C.Structure):
+    """clc_comm_info (include/clc.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("struct_size", "rank", "world", "root", "rooted_collective_available", "copies_other_ranks_to_host",
+                                         "step_in_flight", "pad_")] + \
+               [(n, C.c_int64) for n in ("collectives", "rooted_collectives", "host_copies", "host_copy_bytes", "pipelined_steps")]
 
 
 class PathInfo(C.Structure):
@@ -175,6 +183,12 @@ def load(path: str):
         L.clc_comm_library.restype = C.c_char_p
         L.clc_solve_batched_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p, C.c_void_p]
         L.clc_solve_batched_gather.restype = C.c_int
+        L.clc_solve_batched_gather_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.clc_solve_batched_gather_pipelined.restype = C.c_int
+        L.clc_gather_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.clc_gather_flush.restype = C.c_int
+        L.clc_comm_set_root.argtypes = [C.c_void_p, C.c_int]
+        L.clc_comm_get_info.argtypes = [C.c_void_p, C.c_void_p]
         L.clc_comm_records.argtypes = [C.c_void_p]
         L.clc_comm_records.restype = C.POINTER(C.c_double)
         L.clc_get_path_info.argtypes = [C.c_void_p, C.c_void_p]

@@ -108,9 +108,11 @@ class ShardSolver:
     the shard resident, plus the RCCL communicator for the result gather.  Construct once, solve many times."""
 
     def __init__(self, n_problems: int, device_index: Optional[int] = None, rank: Optional[int] = None,
-                 world: Optional[int] = None, use_rccl: bool = True):
+                 world: Optional[int] = None, use_rccl: bool = True, root: Optional[int] = None):
         """use_rccl=False (dry runs on a CPU process group, e.g. two ranks sharing one GPU, which RCCL refuses):
-        the records are gathered with torch.distributed instead of clc_gather_results."""
+        the records are gathered with torch.distributed instead of clc_gather_results.
+        root: None = every rank ends up with every record; r = only rank r does (clc_comm_set_root: ncclGather to r, one host copy at r):
+        the solve calls then return None on the other ranks."""
         from .solver import Comm, Solver
 
         r, w = _rank_world()
@@ -126,6 +128,16 @@ class ShardSolver:
         self.device_index = device_index
         self.solver = Solver(device_index)
         self.comm = Comm(self.solver, exchange_unique_id(self.rank, self.world), self.rank, self.world) if use_rccl else None
+        self.root = root
+        if self.comm is not None and root is not None:
+            self.comm.set_root(root)
+
+    def _deliver(self, out, ordered: bool):
+        """What a solve call returns on this rank: the gathered records (ordered by global index or raw), or None where a root is set
+        and this rank is not it."""
+        if out is None or (self.root is not None and self.rank != self.root):
+            return None
+        return order_records(out, self.n_problems) if ordered else out
 
     def upload(self, records: np.ndarray, offsets: np.ndarray):
         """This rank's shard only: records of problems [lo, hi), offsets relative to the shard."""
@@ -149,7 +161,7 @@ class ShardSolver:
             local = pack_records(self.last_poses, self.last_summaries, self.lo) if self.hi > self.lo else np.zeros((0, RECORD))
             return gather_result_records(local, self.n_problems, ordered=ordered)
         out = self.comm.gather_results(self.lo, self.cap, copy=copy)
-        return order_records(out, self.n_problems) if ordered else out
+        return self._deliver(out, ordered)
 
     def solve_gather(self, poses0: np.ndarray, options=None, ordered: bool = True, copy: bool = True) -> np.ndarray:
         """The same step as solve() through ONE call, clc_solve_batched_gather (include/clc.h): the kernel's epilogue writes the result
@@ -159,7 +171,23 @@ class ShardSolver:
         assert self.comm is not None, "solve_gather() needs the RCCL communicator; dry runs on a CPU process group use solve()"
         self.last_poses, self.last_summaries = None, None
         out, self.last_stats = self.comm.solve_gather(poses0 if self.hi > self.lo else None, self.lo, self.cap, options, copy=copy)
-        return order_records(out, self.n_problems) if ordered else out
+        return self._deliver(out, ordered)
+
+    def solve_gather_pipelined(self, poses0: np.ndarray, options=None, ordered: bool = False):
+        """A stream of steps (clc_solve_batched_gather_pipelined): enqueues this step and returns the PREVIOUS step's records (None on the
+        first call, and on ranks other than a set root) — the copy of the other ranks' records to the host overlaps this step's kernel.
+        `last_stats` are the previous step's totals.  flush() returns the last step's records."""
+        assert self.comm is not None, "solve_gather_pipelined() needs the RCCL communicator"
+        out, st = self.comm.solve_gather_pipelined(poses0 if self.hi > self.lo else None, self.lo, self.cap, options)
+        if st is not None:
+            self.last_stats = st
+        return self._deliver(out, ordered)
+
+    def flush(self, ordered: bool = False):
+        out, st = self.comm.flush(self.cap)
+        if st is not None:
+            self.last_stats = st
+        return self._deliver(out, ordered)
 
     def close(self):
         if self.comm is not None:

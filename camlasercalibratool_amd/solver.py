@@ -117,6 +117,50 @@ class Comm:
             out = np.ctypeslib.as_array(self._L.clc_comm_records(self._c), shape=(n, RESULT_RECORD))
         return out, st
 
+    def set_root(self, root: int = -1):
+        """clc_comm_set_root: -1 = every rank receives (and copies to its host) every record; r >= 0 = only rank r does (ncclGather to r),
+        the other ranks keep their own segment only.  Every rank must choose the same root."""
+        check(self._L.clc_comm_set_root(self._c, C.c_int(root)), "clc_comm_set_root")
+
+    def info(self) -> "_capi.CommInfo":
+        ci = _capi.CommInfo()
+        check(self._L.clc_comm_get_info(self._c, C.byref(ci)), "clc_comm_get_info")
+        return ci
+
+    def _records_view(self, ptr, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n, RESULT_RECORD))
+
+    def solve_gather_pipelined(self, poses0: np.ndarray, first_global_index: int, cap_per_rank: int, options: Optional[Options] = None):
+        """clc_solve_batched_gather_pipelined: enqueue THIS step, get the PREVIOUS step's (records view [world*cap_per_rank, 12], BatchStats)
+        — (None, None) on the first call.  The view stays valid until the call after the next; flush() returns the last step's."""
+        n = self.world * cap_per_rank
+        st = _capi.BatchStats()
+        o = options or default_options()
+        if poses0 is None:
+            pp = C.POINTER(C.c_double)()
+            if self._solver.num_problems > 0:
+                check(self._L.clc_batched_host_buffers(self._solver._h, C.byref(pp), None), "clc_batched_host_buffers")
+            p_arg = C.cast(pp, C.c_void_p)
+        else:
+            poses = np.ascontiguousarray(poses0, dtype=np.float64)
+            assert poses.size == 7 * self._solver.num_problems, "one start pose per local problem"
+            p_arg = C.cast(dptr(poses), C.c_void_p)
+        prev = C.c_void_p()
+        check(self._L.clc_solve_batched_gather_pipelined(self._c, C.byref(o), p_arg, C.c_int64(first_global_index), C.c_size_t(cap_per_rank),
+                                                         C.byref(prev), C.byref(st)), "clc_solve_batched_gather_pipelined")
+        if not prev.value:
+            return None, None
+        return self._records_view(prev, n), st
+
+    def flush(self, cap_per_rank: int):
+        """clc_gather_flush: complete the step in flight -> (records view, BatchStats), or (None, None) when none is."""
+        st = _capi.BatchStats()
+        rec = C.c_void_p()
+        check(self._L.clc_gather_flush(self._c, C.byref(rec), C.byref(st)), "clc_gather_flush")
+        if not rec.value:
+            return None, None
+        return self._records_view(rec, self.world * cap_per_rank), st
+
     def close(self):
         if getattr(self, "_c", None) is not None and self._c:
             self._L.clc_comm_destroy(self._c)

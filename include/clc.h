@@ -391,13 +391,36 @@ int clc_comm_world(const clc_comm* c);
 /* Path of the RCCL library the collectives are bound to at run time (the one already loaded in the process — torch's — or
  * librccl.so from the loader's path); "" before the first clc_comm_* call resolved it. */
 const char* clc_comm_library(void);
-/* ncclAllGather of the result records the LAST clc_solve_batched on the comm's handle left in device
+/* WHERE the gathered records go (SURVEY.md §8e specifies a gather to rank 0).  root = -1 (default): every rank receives every
+ * record — ncclAllGather, and every rank copies the other ranks' segments to its pinned host buffer.  root >= 0: only `root` does —
+ * the collective is ncclGather to root (RCCL extension; ncclAllGather when the loaded librccl lacks it) and only root copies the other
+ * segments down; every other rank returns from the gather calls below with ITS OWN segment valid (all_records / clc_comm_records())
+ * and the other segments unspecified.  At N = 8 the all-ranks form costs every rank a 5.5 MB device-to-host copy per step; the rooted
+ * form costs the root that copy (hidden behind the next step's kernel by the pipelined call below) and the other ranks nothing.
+ * Every rank must set the same root before its next gather. */
+int clc_comm_set_root(clc_comm* c, int root);
+typedef struct clc_comm_info {
+  int32_t struct_size;                 /* sizeof(clc_comm_info) of the library that filled it (fields are only ever appended) */
+  int32_t rank, world, root;
+  int32_t rooted_collective_available; /* the loaded RCCL exports ncclGather */
+  int32_t copies_other_ranks_to_host;  /* this rank copies the other ranks' segments to its host (no root, or it is the root) */
+  int32_t step_in_flight;              /* a pipelined step has been enqueued and not yet been returned */
+  int32_t pad_;
+  int64_t collectives;                 /* collectives enqueued on this communicator so far */
+  int64_t rooted_collectives;          /* of them ncclGather */
+  int64_t host_copies;                 /* device-to-host copy commands issued by the gather calls on this rank */
+  int64_t host_copy_bytes;
+  int64_t pipelined_steps;
+} clc_comm_info;
+int clc_comm_get_info(const clc_comm* c, clc_comm_info* out);
+
+/* Gather (see clc_comm_set_root) of the result records the LAST clc_solve_batched on the comm's handle left in device
  * memory.  This rank owns global problem indices [first_global_index, first_global_index + P_local);
  * every rank contributes exactly cap_per_rank records (P_local <= cap_per_rank, the rest padded with
  * global_index = -1).  all_records (host, world * cap_per_rank records, rank-major; contiguous shards in
  * rank order make that the global problem order) is filled on every rank that passes one; NULL skips
  * the copy — the gathered records then stay readable in the communicator's pinned host buffer,
- * clc_comm_records(), until the next gather.  Collective call. */
+ * clc_comm_records(), until the next gather.  With a root set, ranks other than the root hold only their own segment.  Collective call. */
 int clc_gather_results(clc_comm* c, int64_t first_global_index, size_t cap_per_rank,
                        clc_result_record* all_records);
 const clc_result_record* clc_comm_records(const clc_comm* c);
@@ -425,6 +448,19 @@ typedef struct clc_batch_stats {
 } clc_batch_stats;
 int clc_solve_batched_gather(clc_comm* c, const clc_options* opt, const double* poses0, int64_t first_global_index,
                              size_t cap_per_rank, clc_result_record* all_records, clc_batch_stats* stats);
+
+/* The same step for a STREAM of steps: the call enqueues step k (kernel + collective on the solver's stream) and returns the records
+ * and totals of step k-1 (*prev_records = NULL on the first call).  The device-to-host copy of step k-1's other-rank segments runs on
+ * the communicator's copy stream WHILE step k's kernel runs (step k's collective waits for it by event before it overwrites the
+ * segments), and the host buffers alternate between two pinned twins, so *prev_records stays valid and untouched until the call after
+ * the next.  clc_gather_flush completes the last step (returns CLC_OK with *records = NULL when none is in flight).  Between a
+ * pipelined call and its flush the other gather calls and clc_comm_set_root refuse.  The start poses of step k are read by its kernel:
+ * `poses0` is copied into the handle's pinned buffer before the launch, the caller's array is free on return.  Requires the one-launch
+ * on-chip batch (otherwise CLC_ERR_INVALID_ARG: use clc_solve_batched_gather).  Collective calls, same error convention: a LOCAL error
+ * of step k-1 is returned by the call that hands back its records. */
+int clc_solve_batched_gather_pipelined(clc_comm* c, const clc_options* opt, const double* poses0, int64_t first_global_index,
+                                       size_t cap_per_rank, const clc_result_record** prev_records, clc_batch_stats* prev_stats);
+int clc_gather_flush(clc_comm* c, const clc_result_record** records, clc_batch_stats* stats);
 
 #ifdef __cplusplus
 }

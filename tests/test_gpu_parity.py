@@ -1004,6 +1004,96 @@ def test_gather_buffer_arithmetic_at_rank_1_of_3():
     assert (st.problems, st.evaluations, st.fused) == (P, ev, 1) and (st2.problems, st2.evaluations) == (P, ev)
 
 
+def test_gather_to_root_copies_to_the_host_at_the_root_only():
+    """clc_comm_set_root (a gather to rank 0): at rank 1 of 3 with root 0 the gather calls issue NO
+    device-to-host copy of other ranks' segments (the one-call form: none at all — the kernel itself wrote this rank's records to the
+    host), at root 1 they copy both other segments; this rank's segment is the same either way.  The layout-only communicator of the
+    hooks build stands in for ranks RCCL cannot be given on one GPU; the byte counts are clc_comm_get_info's."""
+    from camlasercalibratool_amd.solver import Comm
+
+    P, cap, lo = 23, 29, 29
+    rec, off, x0, gt = sd.sim_shard_records(31, lo, lo + P, 7, 80, 0.01)
+    seg = 96 * cap
+    with clc.Solver(0, library="hooks") as s0:
+        s0.upload_batched(rec, off)
+        poses, sms = s0.solve_batched(x0)
+        c = Comm(s0, None, 1, 3)
+        try:
+            i0 = c.info()
+            assert (i0.struct_size, i0.rank, i0.world, i0.root, i0.copies_other_ranks_to_host) == (C.sizeof(_capi.CommInfo), 1, 3, -1, 1)
+            all_ranks, _ = c.solve_gather(x0, lo, cap)
+            i1 = c.info()
+            assert (i1.host_copies - i0.host_copies, i1.host_copy_bytes - i0.host_copy_bytes) == (2, 2 * seg)  # segments 0 and 2
+            c.set_root(0)                                   # this rank (1) is NOT the root
+            assert c.info().copies_other_ranks_to_host == 0
+            not_root, st = c.solve_gather(x0, lo, cap)
+            i2 = c.info()
+            assert (i2.host_copies, i2.host_copy_bytes) == (i1.host_copies, i1.host_copy_bytes)                # nothing crossed PCIe
+            s0.solve_batched(x0)
+            not_root_two = c.gather_results(lo, cap)        # the two-call form copies its own segment only
+            i3 = c.info()
+            assert (i3.host_copies - i2.host_copies, i3.host_copy_bytes - i2.host_copy_bytes) == (1, seg)
+            c.set_root(1)                                   # this rank IS the root
+            at_root, _ = c.solve_gather(x0, lo, cap)
+            i4 = c.info()
+            assert (i4.host_copies - i3.host_copies, i4.host_copy_bytes - i3.host_copy_bytes) == (2, 2 * seg)
+            assert i4.collectives == 4 and i4.rooted_collectives == 0  # (no RCCL behind this communicator: nothing to call ncclGather on)
+            with pytest.raises(_capi.ClcError):
+                c.set_root(3)
+        finally:
+            c.close()
+    for g in (all_ranks, not_root, not_root_two, at_root):
+        mine = g[cap:2 * cap]
+        assert np.array_equal(mine[:P, :7], poses) and np.array_equal(mine[:P, 11], lo + np.arange(P))
+        assert np.all(mine[P:, 11] == -1)
+    assert st.problems == P and st.fused == 1
+
+
+def test_pipelined_steps_return_the_previous_step_and_leave_it_untouched():
+    """clc_solve_batched_gather_pipelined: call k enqueues step k and returns step k-1's records and totals; the device-to-host copy of
+    step k-1's other-rank segments goes to the copy stream and overlaps step k's kernel; the host buffers alternate, so the records
+    handed back stay untouched while the next step's kernel writes.  Steps with DIFFERENT start poses tell the steps apart.  On the
+    layout-only communicator at rank 1 of 3 (copies really issued) and on real RCCL at world size 1."""
+    from camlasercalibratool_amd import dist as cdist
+    from camlasercalibratool_amd.solver import Comm
+
+    P, cap, lo = 40, 41, 41
+    rec, off, x0, gt = sd.sim_shard_records(77, lo, lo + P, 7, 80, 0.01)
+    rng = np.random.default_rng(5)
+    starts = [x0] + [np.array([sd.pose7_from_T(g) for g in gt]) for _ in range(1)]
+    with clc.Solver(0, library="hooks") as s0:
+        starts.append(s0.pose_plus(starts[1], rng.normal(size=(P, 6)) * 0.02))
+        s0.upload_batched(rec, off)
+        want = [s0.solve_batched(x)[0] for x in starts]   # the poses each step must deliver
+        for rank, world, comm_of in ((1, 3, lambda: Comm(s0, None, 1, 3)), (0, 1, lambda: Comm(s0, cdist.exchange_unique_id(0, 1), 0, 1))):
+            c = comm_of()
+            try:
+                c.set_root(rank)  # the root: copies issued (world 3), nothing to copy (world 1)
+                r0, st0 = c.solve_gather_pipelined(starts[0], lo, cap)
+                assert r0 is None and st0 is None and c.info().step_in_flight == 1
+                with pytest.raises(_capi.ClcError):
+                    c.solve_gather(starts[0], lo, cap)    # refused while a step is in flight
+                r1, st1 = c.solve_gather_pipelined(starts[1], lo, cap)
+                keep1 = r1.copy()
+                r2, st2 = c.solve_gather_pipelined(starts[2], lo, cap)
+                assert np.array_equal(r1, keep1)           # step 0's records untouched by step 2's launch (twin buffers)
+                keep2 = r2.copy()
+                r3, st3 = c.flush(cap)
+                assert np.array_equal(r2, keep2)
+                assert c.flush(cap) == (None, None) and c.info().step_in_flight == 0
+                for k, (r, st) in enumerate(((keep1, st1), (keep2, st2), (r3, st3))):
+                    mine = r[rank * cap:(rank + 1) * cap]
+                    assert np.array_equal(mine[:P, :7], want[k]), (world, k)
+                    assert np.array_equal(mine[:P, 11], lo + np.arange(P)) and np.all(mine[P:, 11] == -1)
+                    assert st.problems == P and st.fused == 1 and st.iterations == int(mine[:P, 9].sum())
+                ci = c.info()
+                assert ci.pipelined_steps == 3 and ci.host_copy_bytes == (0 if world == 1 else 3 * 2 * 96 * cap)
+                one, st = c.solve_gather(starts[0], lo, cap)  # the plain call works again after the flush
+                assert np.array_equal(one[rank * cap:rank * cap + P, :7], want[0])
+            finally:
+                c.close()
+
+
 def test_c4_full_size_shard(sv, oracle_mod):
     """configs[3], one GPU's share at full size: 8 192 independent T_cl problems x 10^4 observations (5.2 GB of
     records), solved by clc_solve_batched and gathered through RCCL.  Size-independent properties on ALL problems
