@@ -24,7 +24,7 @@ TERMINATION = {
 # every symbol include/clc.h declares (checked by tests/test_abi_symbols.py)
 EXPORTED = [
     "clc_version", "clc_last_error", "clc_options_default", "clc_create", "clc_destroy", "clc_set_stream",
-    "clc_set_launch", "clc_set_auto_paths", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
+    "clc_set_launch", "clc_set_auto_paths", "clc_set_small_on_coop", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
     "clc_factor_evaluate", "clc_pose_plus", "clc_pose_plus_jacobian", "clc_eval", "clc_solve",
     "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
     "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",
@@ -41,7 +41,7 @@ HOOKS = [
     "clc_debug_flatten_device", "clc_debug_math", "clc_debug_wave_reduce", "clc_debug_eval_timeline", "clc_debug_build_features", "clc_debug_rows",
     "clc_debug_wave_split", "clc_debug_resident", "clc_debug_resident_single", "clc_debug_coop", "clc_debug_coop_control",
     "clc_debug_coop_set_tag", "clc_debug_layout", "clc_debug_lm_profile", "clc_time_steps", "clc_time_batched_eval", "clc_time_eval",
-    "clc_debug_comm_create_layout",
+    "clc_debug_comm_create_layout", "clc_debug_single_controller",
 ]
 
 
@@ -114,7 +114,7 @@ class PathInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("single_resident", "single_lanes", "single_points_per_lane", "coop_resident", "coop_points_per_lane",
                                          "coop_points_carry_z", "coop_resting", "coop_timeouts", "batched_resident", "batched_lanes", "batched_points_per_lane",
                                          "rows_layout", "batched_rows_layout", "coop_workgroups", "batched_points_carry_z", "reserved_")] + \
-               [(n, C.c_int64) for n in ("coop_solves", "batched_lane_rows", "n_rows", "batched_n_rows")]
+               [(n, C.c_int64) for n in ("coop_solves", "batched_lane_rows", "n_rows", "batched_n_rows", "coop_gate_waits_expired")]
 
 
 class ClcError(RuntimeError):

@@ -173,8 +173,9 @@ int clc_create(clc_handle** out, int device) {
 static int create_init(clc_handle* h) {
   if (const char* e = std::getenv("CLC_AUTO_PATHS_DISABLE")) {
     const int m = std::atoi(e);
-    if (m >= 0 && m <= 31) h->auto_disable = m;
+    if (m >= 0 && m <= 11 && (m & 4) == 0) h->auto_disable = m;
   }
+  if (const char* e = std::getenv("CLC_SMALL_ON_COOP")) h->small_on_coop = std::atoi(e) != 0;
   CLC_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   CLC_HIP(hipMalloc(&h->d_block, sizeof(clc::SolveBlock)));
@@ -263,8 +264,14 @@ int clc_set_stream(clc_handle* h, void* hip_stream) {
 }
 
 int clc_set_auto_paths(clc_handle* h, int disable_mask) {
-  if (!h || disable_mask < 0 || disable_mask > 31) return fail(CLC_ERR_INVALID_ARG, "clc_set_auto_paths: bad argument");
+  if (!h || disable_mask < 0 || (disable_mask & ~(1 | 2 | 8)) != 0) return fail(CLC_ERR_INVALID_ARG, "clc_set_auto_paths: the mask is a sum of 1, 2, 8");
   h->auto_disable = disable_mask;
+  return CLC_OK;
+}
+
+int clc_set_small_on_coop(clc_handle* h, int enable) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_set_small_on_coop: NULL handle");
+  h->small_on_coop = enable != 0;
   return CLC_OK;
 }
 
@@ -290,6 +297,7 @@ int clc_get_path_info(const clc_handle* h, clc_path_info* out) {
   out->batched_lane_rows = h->bres.ok ? h->bres.rows : 0;
   out->n_rows = h->n_rows;
   out->batched_n_rows = h->bn_rows;
+  out->coop_gate_waits_expired = h->coop_gate_waits_expired;
   return CLC_OK;
 }
 

@@ -210,6 +210,15 @@ extern "C" int clc_debug_coop_control(clc_handle* h, int drop_next, int reenable
   return CLC_OK;
 }
 
+// Test hook: the single-workgroup solve runs the LM controller of the cooperative kernel (wave-uniform arithmetic, state in registers)
+// instead of its own (state in LDS) — same arithmetic, bit-identical results, slower there; how the cooperative kernel's controller is
+// compared with the serial one on identical totals (tests/test_gpu_lmuni.py).
+extern "C" int clc_debug_single_controller(clc_handle* h, int cooperative_kernels) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_single_controller: NULL handle");
+  h->single_uni_ctrl = cooperative_kernels != 0;
+  return CLC_OK;
+}
+
 // Test hook: the next cooperative solve starts its pass tags here (to exercise the wrap of the 32-bit tags).
 extern "C" int clc_debug_coop_set_tag(clc_handle* h, unsigned int tag) {
   if (!h || tag == 0) return fail(CLC_ERR_INVALID_ARG, "clc_debug_coop_set_tag: bad argument");

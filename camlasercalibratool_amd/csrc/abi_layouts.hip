@@ -254,8 +254,8 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   if (T.coop != nullptr) {
     T.coop->ok = false;
     // (records with p.z != 0: the cooperative kernel's WITH_Z form holds 24-byte slots)
-    // (clc_set_auto_paths bit 16: the cooperative layout also for a problem one workgroup holds — clc_solve then prefers it)
-    const bool small_on_coop = (h->auto_disable & 16) != 0;
+    // (clc_set_small_on_coop: the cooperative layout also for a problem one workgroup holds — clc_solve then prefers it)
+    const bool small_on_coop = h->small_on_coop;
     if (P == 1 && n > 0 && h->num_cus >= clc::COOP_WGS && (small_on_coop || !(T.res != nullptr && T.res->ok))) {
       // the one problem in chunks of equal record counts, one per workgroup (a chunk may begin and end inside a scan: res_scan_extent):
       // COOP_WGS of them, or COOP_SMALL_WGS where that leaves a lane at most kCoopSmallMaxPpl points (the one-hop form of the kernel)
@@ -266,7 +266,9 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
       // per lane (106 496 observations) is where the one-hop form stops paying (round 4: 10).
       constexpr int kCoopSmallMaxPpl = 13;
       int small_cap = kCoopSmallMaxPpl;
-      if (const char* e = std::getenv("CLC_COOP_SMALL_MAX_PPL")) small_cap = std::max(1, std::atoi(e));  // (tuning hook: scripts/r05_small_form.py)
+#ifdef CLC_TEST_HOOKS
+      if (const char* e = std::getenv("CLC_COOP_SMALL_MAX_PPL")) small_cap = std::max(1, std::atoi(e));  // (tuning hook, hooks build only: scripts/r05_small_form.py)
+#endif
       const int small_ppl = std::min(small_cap, cap_ppl);
       const bool small_ok = n <= (long long)clc::COOP_SMALL_WGS * clc::COOP_NL * small_ppl && (h->auto_disable & 8) == 0;
       for (int attempt = small_ok ? 0 : 1; attempt < 2 && !T.coop->ok; ++attempt) {

@@ -321,7 +321,7 @@ int solve_resident_single(clc_handle* h, const clc_options& opt, double pose[7],
 #define CLC_LAUNCH_SINGLE(LOSS, CTRL)                                                                                                   \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, false, 8, kResPR512, kResPL512, CTRL>), dim3(1), dim3(512), 0, h->stream, h->sres.d_xy, \
                      d_row, d_desc, h->d_groups, h->sres.uni_ppl, opt, d_trace, d_cap, h->d_spose, h->d_ssummary, h->d_small, d_done, nullptr)
-  const bool uni_ctrl = (h->auto_disable & 4) != 0;  // the cooperative kernel's controller here: the bit-identity test of the two
+  const bool uni_ctrl = h->single_uni_ctrl;  // the cooperative kernel's controller here: the bit-identity test of the two (hooks build)
   const bool timed = opt.profile_events == 2;  // an event pair around the one launch -> eval_kernel_ms, eval_kernel_launches = 1
   if (timed) {
     const int rc = ensure_events(h, 2);
@@ -385,7 +385,11 @@ struct CoopGate {
     for (;;) {
       int expected = 0;
       if (a.compare_exchange_weak(expected, 1, std::memory_order_acquire)) { held = &a; return true; }
-      if ((++spins & 0x3FF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5e-3) return false;
+      // the holder's solve is ~0.1 ms: spin briefly, then give the core away (with more solver threads than cores the spinners would
+      // otherwise take the CPU the gate's holder needs to finish)
+      if (++spins < 64) continue;
+      std::this_thread::yield();
+      if ((spins & 0xF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5e-3) return false;
     }
   }
   ~CoopGate() { if (held) held->store(0, std::memory_order_release); }
@@ -418,12 +422,14 @@ int solve_coop(clc_handle* h, const clc_options& opt, double pose[7], clc_summar
     CLC_HIP(hipMemsetAsync(h->d_board, 0, sizeof(clc::CoopBoard), h->stream));
     CLC_HIP(hipStreamSynchronize(h->stream));
     h->coop_tag = 1;
-    {  // (tuning hook: first-poll offsets, clc_coop.hpp)
+#ifdef CLC_TEST_HOOKS
+    {  // (tuning hook, hooks build only: first-poll offsets, clc_coop.hpp)
       unsigned long long d[2] = {0, 0};
       if (const char* e = std::getenv("CLC_COOP_D1")) d[0] = (unsigned long long)std::atoll(e);
       if (const char* e = std::getenv("CLC_COOP_D2")) d[1] = (unsigned long long)std::atoll(e);
       if (d[0] || d[1]) CLC_HIP(hipMemcpy(&h->d_board->ctl[1], d, sizeof(d), hipMemcpyHostToDevice));
     }
+#endif
   }
   const unsigned int passes = (unsigned int)opt.max_num_iterations + 4u;
   if (h->coop_tag > 0xFFFFFFFFu - passes - 8u) {  // the 32-bit pass tags are used up: start over on clean boards
@@ -527,10 +533,10 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 
   // a problem one workgroup holds: the whole solve in one single-workgroup launch (default flags only: the explicit flag
   // sets select the step chain / launch pair the bit-identity tests compare; profile_events = 1 asks for per-pass events)
-  // (clc_set_auto_paths bit 16 at upload: such a problem ALSO has the cooperative layout and runs on 32 workgroups first — 4.6 instead
+  // (clc_set_small_on_coop at upload: such a problem ALSO has the cooperative layout and runs on 32 workgroups first — 4.6 instead
   // of 5.3-5.9 us per pass —, with this kernel as the fall-back when the cooperative launch times out or rests)
   const bool single_ok = h->sres.ok && h->launch_auto && (h->auto_disable & 2) == 0 && h->grid_override == 0 && opt.profile_events != 1;
-  if (single_ok && !(h->cres.ok && (h->auto_disable & 16) != 0)) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
+  if (single_ok && !(h->cres.ok && h->small_on_coop)) return solve_resident_single(h, opt, pose, summary, trace, trace_cap, t0);
   // a problem the 256 CUs hold together: the whole solve in one launch of 256 (or 32) co-resident workgroups (same conditions)
   if (h->cres.ok && h->launch_auto && (h->auto_disable & 1) == 0 && h->grid_override == 0 && opt.profile_events != 1 && ++h->coop_eligible > h->coop_retry_at) {
     const int rc = solve_coop(h, opt, pose, summary, trace, trace_cap, t0);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -166,7 +167,9 @@ struct clc_handle {
   // launch geometry
   int grid_override = 0;
   int launch_flags = clc_abi::kDefaultLaunchFlags;
-  int auto_disable = 0;     // clc_set_auto_paths: 1 no cooperative solve, 2 no single-workgroup resident solve, 4 cooperative kernel's controller in the single-workgroup kernel
+  int auto_disable = 0;     // clc_set_auto_paths: 1 no cooperative solve, 2 no single-workgroup resident solve, 8 (at upload) no one-hop form
+  bool small_on_coop = false;    // clc_set_small_on_coop (at upload): problems one workgroup holds also get the cooperative layout
+  bool single_uni_ctrl = false;  // hooks build (clc_debug_single_controller): the single-workgroup kernel runs the cooperative kernel's controller
   bool launch_auto = true;  // default flags: size-dependent choices (deep pipeline) are made per launch
   double* d_partials = nullptr;
   int partials_cap_blocks = 0;

@@ -132,7 +132,7 @@ class Comm:
 
     def solve_gather_pipelined(self, poses0: np.ndarray, first_global_index: int, cap_per_rank: int, options: Optional[Options] = None):
         """clc_solve_batched_gather_pipelined: enqueue THIS step, get the PREVIOUS step's (records view [world*cap_per_rank, 12], BatchStats)
-        — (None, None) on the first call.  The view stays valid until the call after the next; flush() returns the last step's."""
+        — (None, None) on the first call.  The view stays valid until the NEXT pipelined call / flush; flush() returns the last step's."""
         n = self.world * cap_per_rank
         st = _capi.BatchStats()
         o = options or default_options()
@@ -212,11 +212,17 @@ class Solver:
         check(self._L.clc_set_stream(self._h, C.c_void_p(hip_stream or 0)), "clc_set_stream")
 
     def set_auto_paths(self, disable_mask: int = 0):
-        """clc_set_auto_paths: 1 = no cooperative one-launch solve, 2 = no single-workgroup on-chip solve,
-        4 = the single-workgroup solve runs the cooperative kernel's register-resident controller, 8 = (at upload) not the 32-workgroup
-        one-hop form, 16 = (at upload) problems one workgroup holds also get the cooperative layout and run on 32 workgroups first;
-        0 = library default."""
+        """clc_set_auto_paths: 1 = no cooperative one-launch solve, 2 = no single-workgroup on-chip solve, 8 = (at upload) not the
+        32-workgroup one-hop form; 0 = library default.  Every bit disables a path."""
         check(self._L.clc_set_auto_paths(self._h, C.c_int(disable_mask)), "clc_set_auto_paths")
+
+    def set_small_on_coop(self, enable: bool = True):
+        """clc_set_small_on_coop (at upload): problems one workgroup holds also get the cooperative layout and run on 32 workgroups first."""
+        check(self._L.clc_set_small_on_coop(self._h, C.c_int(int(enable))), "clc_set_small_on_coop")
+
+    def debug_single_controller(self, cooperative_kernels: bool):
+        """Test hook: the single-workgroup solve runs the cooperative kernel's register-state LM controller instead of its own."""
+        check(self._hook("clc_debug_single_controller")(self._h, C.c_int(int(cooperative_kernels))), "clc_debug_single_controller")
 
     def set_launch(self, grid_blocks: int = 0, flags: int = 0):
         check(self._L.clc_set_launch(self._h, C.c_int(grid_blocks), C.c_int(flags)), "clc_set_launch")

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLC_VERSION 200
+#define CLC_VERSION 210
 
 /* status codes */
 #define CLC_OK 0
@@ -169,18 +169,17 @@ int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
  *     resident within 0.2 ms aborts, falls back to the step chain and rests the path on the handle for 16 solves, doubling):
  *     a process that shares the GPU with long-running kernels can switch it off here and keep every other default;
  * 2 = not the single-workgroup on-chip solve (n <= 11 264 observations);
- * 4 = the single-workgroup solve runs the LM controller of the cooperative kernel (wave-uniform arithmetic, state in registers)
- *     instead of its own (state in LDS) — same arithmetic, bit-identical results, slower there; how the cooperative kernel's
- *     controller is compared with the serial one on identical totals (tests/test_gpu_lmuni.py).
  * 8 = (at upload) not the 32-workgroup one-hop form of the cooperative solve for problems of at most 106 496 observations
  *     (every workgroup reads all 32 rows itself: one store-to-load hop per pass instead of two) — the 256-workgroup form then.
- * 16 = (at upload; the one bit that switches something ON) a problem one workgroup holds (n <= 11 264) ALSO gets the cooperative layout
- *     and clc_solve runs it on 32 co-resident workgroups first — 4.6 instead of 5.3-5.9 us per pass (C1 0.132 -> 0.116 ms per solve,
- *     10 000 observations 0.135 -> 0.107) —, with the single-workgroup kernel as the fall-back when that launch times out or rests.
- *     Not the default: upload and first solve cost ~0.2 ms more (a second layout, the exchange boards), which the reference's one
- *     calibration per process never earns back; worth it from about a dozen solves per upload on an otherwise idle GPU.
- * 0 = library default.  The environment variable CLC_AUTO_PATHS_DISABLE sets the initial mask of every handle. */
+ * 0 = library default: every bit of the mask DISABLES a path.  The environment variable CLC_AUTO_PATHS_DISABLE sets the initial mask
+ * of every handle. */
 int clc_set_auto_paths(clc_handle* h, int disable_mask);
+/* Opt-in (at upload): a problem one workgroup holds (n <= 11 264) ALSO gets the cooperative layout and clc_solve runs it on 32 co-resident
+ * workgroups first — 4.6 instead of 5.3-5.9 us per pass (C1 0.132 -> 0.116 ms per solve, 10 000 observations 0.135 -> 0.107) —, with the
+ * single-workgroup kernel as the fall-back when that launch times out or rests.  Not the default: upload and first solve cost ~0.2 ms more
+ * (a second layout, the exchange boards), which the reference's one calibration per process never earns back; worth it from about a
+ * dozen solves per upload on an otherwise idle GPU.  CLC_SMALL_ON_COOP=1 in the environment sets it on every new handle. */
+int clc_set_small_on_coop(clc_handle* h, int enable);
 
 /* Which layouts the last clc_upload* / clc_select_observations / clc_upload_batched* built on this handle, and how the
  * cooperative path is doing: a caller that sizes its problems, or shares the GPU, can see whether clc_solve and
@@ -207,6 +206,8 @@ typedef struct clc_path_info {
   int64_t batched_lane_rows;       /* point rows of the batched lane layout (x lanes x 16 bytes = its size) */
   int64_t n_rows;                  /* rows of 64 points of the streaming row layouts */
   int64_t batched_n_rows;
+  int64_t coop_gate_waits_expired; /* cooperative solves that took the step chain because another handle of this process held the device's
+                                    * one-cooperative-launch-at-a-time gate for more than 5 ms (clc_version() >= 210; fields are only appended) */
 } clc_path_info;
 int clc_get_path_info(const clc_handle* h, clc_path_info* out);
 
@@ -452,8 +453,8 @@ int clc_solve_batched_gather(clc_comm* c, const clc_options* opt, const double* 
 /* The same step for a STREAM of steps: the call enqueues step k (kernel + collective on the solver's stream) and returns the records
  * and totals of step k-1 (*prev_records = NULL on the first call).  The device-to-host copy of step k-1's other-rank segments runs on
  * the communicator's copy stream WHILE step k's kernel runs (step k's collective waits for it by event before it overwrites the
- * segments), and the host buffers alternate between two pinned twins, so *prev_records stays valid and untouched until the call after
- * the next.  clc_gather_flush completes the last step (returns CLC_OK with *records = NULL when none is in flight).  Between a
+ * segments), and the host buffers alternate between two pinned twins: *prev_records stays valid and untouched while step k runs, until
+ * the NEXT pipelined call or flush (whose step writes into that twin).  clc_gather_flush completes the last step (returns CLC_OK with *records = NULL when none is in flight).  Between a
  * pipelined call and its flush the other gather calls and clc_comm_set_root refuse.  The start poses of step k are read by its kernel:
  * `poses0` is copied into the handle's pinned buffer before the launch, the caller's array is free on return.  Requires the one-launch
  * on-chip batch (otherwise CLC_ERR_INVALID_ARG: use clc_solve_batched_gather).  Collective calls, same error convention: a LOCAL error

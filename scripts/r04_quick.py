@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 4 quick timing on the GPU box: the cooperative C2 solve (wall + kernel), single-workgroup solves under both controllers
-(clc_set_auto_paths bit 4 = the cooperative kernel's register-state controller instead of the LDS-state one), C3 and a C4 shard through the resident batched kernel.  One JSON line each."""
+(hooks build, clc_debug_single_controller = the cooperative kernel's register-state controller instead of the LDS-state one), C3 and a C4 shard through the resident batched kernel.  One JSON line each."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -41,7 +41,7 @@ for name, S in (("c1", sd.GenerateSimData(1, noise_sigma=0.01)), ("20x500", sd.s
     sv.upload(rec)
     row = {"observations": int(rec.shape[0])}
     for label, mask in (("default_controller", 0), ("coop_controller", 4), ("default_controller", 0), ("coop_controller", 4)):
-        sv.set_auto_paths(mask)
+        sv.debug_single_controller(mask == 4)
         for _ in range(20):
             r = sv.solve(x0, trace_cap=0)
         ts = []
@@ -52,7 +52,7 @@ for name, S in (("c1", sd.GenerateSimData(1, noise_sigma=0.01)), ("20x500", sd.s
             ts.append((time.perf_counter() - t0) / 100)
         row.setdefault(label + "_ms", []).append(1e3 * float(np.median(ts)))
         row["passes"] = int(r.summary.num_evaluations)
-    sv.set_auto_paths(0)
+    sv.debug_single_controller(False)
     print("single", name, json.dumps(row), flush=True)
     out["single_" + name] = row
 # ---- batched ----

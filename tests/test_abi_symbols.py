@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     L = _capi.load(_build.PRODUCT_LIB_PATH)
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/clc.h but not exported"
-    assert L.clc_version() == 200
+    assert L.clc_version() == 210
 
 
 def _dynamic_symbols(path):
@@ -43,12 +43,20 @@ def test_product_library_exports_the_header_and_nothing_else():
     assert {s for s in hooks if s.startswith("clc_")} == set(_capi.EXPORTED) | set(_capi.HOOKS)
 
 
+def hdr_text():
+    return open(os.path.join(ROOT, "include", "clc.h")).read()
+
+
 def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(_capi.Options) == 4 * 4 + 10 * 8 + 2 * 4
     assert C.sizeof(_capi.Iteration) == 16 + 6 * 8
     assert C.sizeof(_capi.Summary) == 16 + 8 + 4 * 8 + 8
-    assert C.sizeof(_capi.PathInfo) == 16 * 4 + 4 * 8  # clc_path_info: 15 int32 + 1 reserved, 4 int64
+    assert C.sizeof(_capi.PathInfo) == 16 * 4 + 5 * 8  # clc_path_info: 15 int32 + 1 reserved, 5 int64 (fields are only ever appended)
+    assert C.sizeof(_capi.CommInfo) == 8 * 4 + 5 * 8  # clc_comm_info
+    body = re.sub(r"/\*.*?\*/", "", re.search(r"typedef struct clc_comm_info \{(.*?)\} clc_comm_info;", hdr_text(), flags=re.S).group(1), flags=re.S)
+    names = [n.strip() for m in re.finditer(r"(int32_t|int64_t)\s+([\w, ]+);", body) for n in m.group(2).split(",")]
+    assert names == [f[0] for f in _capi.CommInfo._fields_]
     assert C.sizeof(_capi.BatchStats) == 4 * 8 + 2 * 4 + 2 * 8  # clc_batch_stats
     hdr = open(os.path.join(ROOT, "include", "clc.h")).read()
     body = re.sub(r"/\*.*?\*/", "", re.search(r"typedef struct clc_path_info \{(.*?)\} clc_path_info;", hdr, flags=re.S).group(1), flags=re.S)

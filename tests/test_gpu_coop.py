@@ -207,7 +207,7 @@ def test_two_handles_solving_at_once(oracle_mod):
         try:
             s.upload(rec)
             ready.wait()  # (both uploads are done: what overlaps from here on is cooperative solves only — what the gate is about)
-            out[name] = [s.solve(X0) for _ in range(30)] + [s.debug_coop()]
+            out[name] = [s.solve(X0) for _ in range(30)] + [s.debug_coop() + (s.path_info().coop_gate_waits_expired,)]
         finally:
             s.close()
 
@@ -225,7 +225,10 @@ def test_two_handles_solving_at_once(oracle_mod):
     # one cooperative launch at a time per device in this process (the gate of solve_coop): no launch meets another one's workgroups on
     # the CUs, so none times out (round 4: the two threads alternated aborts) and every solve ran as the one-launch kernel
     assert out["a"][-1][3] == 0 and out["b"][-1][3] == 0, (out["a"][-1], out["b"][-1])
-    assert out["a"][-1][2] == 30 and out["b"][-1][2] == 30
+    # (a wait for the gate that outlasts its 5 ms bound — a descheduled holder — sends that one solve down the step chain, counted in
+    # clc_path_info.coop_gate_waits_expired: every solve is accounted for either way)
+    assert out["a"][-1][2] + out["a"][-1][5] == 30 and out["b"][-1][2] + out["b"][-1][5] == 30
+    assert out["a"][-1][5] + out["b"][-1][5] <= 2
     for k in ("a", "b"):
         *res, dbg = out[k]
         for r in res:
@@ -327,7 +330,7 @@ def test_small_problems_run_the_one_hop_form_on_32_workgroups(sv, oracle_mod):
 
 
 def test_small_problems_on_32_workgroups_by_request(sv, oracle_mod):
-    """clc_set_auto_paths bit 16 (at upload): a problem one workgroup holds ALSO gets the cooperative layout and clc_solve runs it on 32
+    """clc_set_small_on_coop (at upload): a problem one workgroup holds ALSO gets the cooperative layout and clc_solve runs it on 32
     co-resident workgroups (the faster pass); same decisions as the single-workgroup kernel and the oracle; when the cooperative launch
     cannot complete (a workgroup short) the single-workgroup kernel answers — not the step chain; without the bit nothing changes."""
     S = sd.GenerateSimData(1, noise_sigma=0.01)  # the reference's C1 size
@@ -340,7 +343,7 @@ def test_small_problems_on_32_workgroups_by_request(sv, oracle_mod):
     assert sv.path_info().single_resident == 1 and sv.path_info().coop_resident == 0
     single = sv.solve(X0)
     try:
-        sv.set_auto_paths(16)
+        sv.set_small_on_coop(True)
         sv.upload(rec)
         pi = sv.path_info()
         assert pi.single_resident == 1 and pi.coop_resident == 1 and pi.coop_workgroups == 32
@@ -362,10 +365,13 @@ def test_small_problems_on_32_workgroups_by_request(sv, oracle_mod):
         assert np.array_equal(again.pose, single.pose)
         sv.debug_coop_control(reenable=True)
         assert np.array_equal(sv.solve(X0).pose, r.pose)
-        # the bit cleared at solve time: the single-workgroup kernel, although both layouts are there
-        sv.set_auto_paths(0)
+        # the switch cleared at solve time: the single-workgroup kernel, although both layouts are there
+        sv.set_small_on_coop(False)
         n1 = sv.path_info().coop_solves
         assert np.array_equal(sv.solve(X0).pose, single.pose) and sv.path_info().coop_solves == n1
+        with pytest.raises(clc.ClcError):
+            sv.set_auto_paths(16)  # (no enable bit hides in the disable mask any more)
     finally:
+        sv.set_small_on_coop(False)
         sv.set_auto_paths(0)
         sv.debug_coop_control(reenable=True)

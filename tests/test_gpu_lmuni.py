@@ -2,7 +2,7 @@
 
 It replaces ceres::Solve's trust-region loop (src/LaseCamCalCeres.cpp:301-307) for the problems that stay on chip.  Every
 expression keeps the operand order and the fused multiply-adds of the serial controller (csrc/clc_lm.hpp), so for the same totals
-the two must agree BIT FOR BIT: the single-workgroup kernel is instantiated with both (clc_set_auto_paths bit 4 puts the cooperative
+the two must agree BIT FOR BIT: the single-workgroup kernel is instantiated with both (the hooks build's clc_debug_single_controller puts the cooperative
 kernel's controller in place of the wavefront controller on the LDS state, itself bit-identical to the serial one; the evaluation
 pass, the reduction and therefore the totals are the same code) and whole
 solves — pose, summary, every field of every iteration record — are compared for equality, on noisy, ragged, far-start, outlier,
@@ -30,10 +30,10 @@ def _both(sv, rec, x0, opt=None):
     sv.upload(rec)
     assert sv.debug_resident_single()[0]
     out = []
-    for mask in (0, 4):
-        sv.set_auto_paths(mask)
+    for uni in (False, True):
+        sv.debug_single_controller(uni)
         out.append(sv.solve(x0, opt) if opt is not None else sv.solve(x0))
-    sv.set_auto_paths(0)
+    sv.debug_single_controller(False)
     return out
 
 
@@ -126,11 +126,11 @@ def test_register_controller_invalid_steps_take_the_serial_path(sv):
     bad[0] = np.inf
     rec2 = clc.flatten_observations(sd.sim_fixed_count(23, 10, 100, noise_sigma=0.01), False)
     sv.upload(rec2)
-    for mask in (0, 4):
-        sv.set_auto_paths(mask)
+    for uni in (False, True):
+        sv.debug_single_controller(uni)
         try:
             r = sv.solve(bad)
             assert r.summary.termination == 6
         except clc.ClcError:
             pass
-    sv.set_auto_paths(0)
+    sv.debug_single_controller(False)

@@ -1052,7 +1052,7 @@ def test_gather_to_root_copies_to_the_host_at_the_root_only():
 def test_pipelined_steps_return_the_previous_step_and_leave_it_untouched():
     """clc_solve_batched_gather_pipelined: call k enqueues step k and returns step k-1's records and totals; the device-to-host copy of
     step k-1's other-rank segments goes to the copy stream and overlaps step k's kernel; the host buffers alternate, so the records
-    handed back stay untouched while the next step's kernel writes.  Steps with DIFFERENT start poses tell the steps apart.  On the
+    handed back stay untouched while step k's kernel writes (they are valid until the next call).  Steps with DIFFERENT start poses tell the steps apart.  On the
     layout-only communicator at rank 1 of 3 (copies really issued) and on real RCCL at world size 1."""
     from camlasercalibratool_amd import dist as cdist
     from camlasercalibratool_amd.solver import Comm
@@ -1073,13 +1073,16 @@ def test_pipelined_steps_return_the_previous_step_and_leave_it_untouched():
                 assert r0 is None and st0 is None and c.info().step_in_flight == 1
                 with pytest.raises(_capi.ClcError):
                     c.solve_gather(starts[0], lo, cap)    # refused while a step is in flight
+                import time
                 r1, st1 = c.solve_gather_pipelined(starts[1], lo, cap)
                 keep1 = r1.copy()
+                time.sleep(0.05)                           # (step 1's kernel has run by now — into the OTHER twin)
+                assert np.array_equal(r1, keep1)           # step 0's records untouched by step 1's kernel: valid until the next call
                 r2, st2 = c.solve_gather_pipelined(starts[2], lo, cap)
-                assert np.array_equal(r1, keep1)           # step 0's records untouched by step 2's launch (twin buffers)
                 keep2 = r2.copy()
-                r3, st3 = c.flush(cap)
+                time.sleep(0.05)
                 assert np.array_equal(r2, keep2)
+                r3, st3 = c.flush(cap)
                 assert c.flush(cap) == (None, None) and c.info().step_in_flight == 0
                 for k, (r, st) in enumerate(((keep1, st1), (keep2, st2), (r3, st3))):
                     mine = r[rank * cap:(rank + 1) * cap]
@@ -1098,8 +1101,8 @@ def test_c4_full_size_shard(sv, oracle_mod):
     """configs[3], one GPU's share at full size: 8 192 independent T_cl problems x 10^4 observations (5.2 GB of
     records), solved by clc_solve_batched and gathered through RCCL.  Size-independent properties on ALL problems
     (termination by convergence at a cost no higher than the start, unit quaternions, own ground truth recovered to the
-    noise level, solving twice is bitwise repeatable) + oracle parity (DENSE_QR Ceres restatement) on 512 sampled
-    problems (every 16th) regenerated one by one from (seed, global index)."""
+    noise level, solving twice is bitwise repeatable) + oracle parity (DENSE_QR Ceres restatement) on ALL 8 192 problems (the oracle's
+    answers frozen in tests/golden/oracle_c4_shard.npz) and on 16 of them run live, regenerated one by one from (seed, global index)."""
     from camlasercalibratool_amd import dist as cdist
 
     P, n_poses, K, seed, lo = 8192, 20, 500, 65536, 3 * 8192  # the shard rank 3 of 8 would own
@@ -1122,13 +1125,82 @@ def test_c4_full_size_shard(sv, oracle_mod):
     assert np.abs(np.linalg.norm(raw[:, 3:7], axis=1) - 1).max() < 1e-14
     worst = max(np.abs(sd.T_from_pose7(raw[k, :7]) - gt[k]).max() for k in range(P))
     assert worst < 0.02, worst
-    for k in range(0, P, 16):  # 512 problems
+    # ALL 8 192 problems against the oracle's frozen answers (tests/golden/oracle_c4_shard.npz, made by tests/golden/make_c4_golden.py; the
+    # file itself is checked against the live oracle on the CPU: tests/test_golden_regression.py) ...
+    G = _golden_c4()
+    assert (G["meta"]["seed"], G["meta"]["lo"], G["meta"]["P"]) == (seed, lo, P)
+    assert np.array_equal(raw[:, 9], G["iterations"]) and np.array_equal(raw[:, 10], G["termination"])
+    dT = np.abs(_T_batch(raw[:, :7]) - _T_batch(G["pose"])).reshape(P, -1).max(axis=1)
+    assert dT.max() <= T_TOL and np.abs(raw[:, 7] - G["final_cost"]).max() <= COST_TOL, (dT.max(), np.abs(raw[:, 7] - G["final_cost"]).max())
+    assert np.abs(raw[:, 8] - G["initial_cost"]).max() <= 1e-11 * G["initial_cost"].max()
+    # ... and 16 of them against the oracle run live (every 512th)
+    for k in range(0, P, 512):
         one = sd.sim_shard(seed, lo + k, lo + k + 1, n_poses, K, 0.01)
         r1, _ = one.records()
         ref = oracle_mod.solve(r1, x0[k], linear_solver="qr")
         assert np.array_equal(one.start_poses()[0], x0[k])
         assert raw[k, 9] == ref.summary.num_iterations and raw[k, 10] == ref.summary.termination, k
         assert _dT(raw[k, :7], ref.pose) <= T_TOL and abs(raw[k, 7] - ref.summary.final_cost) <= COST_TOL, k
+
+
+def _golden_c4():
+    import json, os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_c4_shard.npz"))
+    G = {k: z[k] for k in ("iterations", "termination", "final_cost", "initial_cost", "pose")}
+    G["meta"] = json.loads(str(z["meta"]))
+    return G
+
+
+def _T_batch(p):
+    """[P, 7] poses -> [P, 3, 4] of R | t (Appendix B of SURVEY.md: toRotationMatrix, no normalisation)."""
+    t, x, y, z, w = p[:, :3], p[:, 3], p[:, 4], p[:, 5], p[:, 6]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                  2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+    return np.concatenate([R, t[:, :, None]], axis=2)
+
+
+def _golden_variants():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_variants.json")))
+
+
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("sigma", [0.0, 0.01])
+def test_c1_all_ten_seeds_against_frozen_oracle(sv, seed, sigma):
+    """SURVEY.md 8(d) C1 in full: the simulation node's default input, seeds 0..9, noise-free and sigma = 0.01 m, init Tcl = I — iterations,
+    termination, accepted / rejected steps, T_cl and cost against the oracle's frozen answers (tests/golden/oracle_variants.json)."""
+    g = next(v for v in _golden_variants()["c1"] if v["seed"] == seed and v["sigma"] == sigma)
+    rec = clc.flatten_observations(sd.GenerateSimData(seed, noise_sigma=sigma), False)
+    assert rec.shape[0] == g["n"]
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    res = sv.solve(np.array(g["start"]))
+    assert (res.summary.num_iterations, res.summary.termination) == (g["iterations"], g["termination"])
+    assert [t.step_is_successful for t in res.trace] == g["accepted"]
+    assert _dT(res.pose, np.array(g["pose"])) <= T_TOL and abs(res.summary.final_cost - g["final_cost"]) <= COST_TOL
+    if sigma == 0.0:
+        assert np.abs(sd.T_from_pose7(res.pose) - sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)).max() < 1e-6 and res.summary.final_cost < 1e-12
+
+
+@pytest.mark.parametrize("sigma", [0.0, 0.01])
+@pytest.mark.parametrize("init", ["identity", "closed_form"])
+def test_c2_variants_against_frozen_oracle(sv, sigma, init):
+    """SURVEY.md 8(d) C2 in full: 1e6 observations, noise-free and sigma = 0.01 m, init Tcl = I and init = the closed form (the frozen
+    start pose, so that both solves start from identical bits; the GPU's own closed form is held to 1e-9 of the frozen Tlc beside it)."""
+    g = next(v for v in _golden_variants()["c2"] if v["sigma"] == sigma and v["init"] == init)
+    rec = clc.flatten_observations(sd.sim_fixed_count(g["seed"], 2000, 500, noise_sigma=sigma), False)
+    assert rec.shape[0] == g["n"] == 1_000_000
+    sv.set_launch(0, -1)
+    sv.upload(rec)
+    if init == "closed_form":
+        Tlc, unobs, _ = sv.closed_form()
+        assert not unobs and np.abs(Tlc - np.array(g["Tlc"]).reshape(4, 4)).max() < 1e-9
+    res = sv.solve(np.array(g["start"]))
+    assert sv.path_info().coop_resident == 1
+    assert (res.summary.num_iterations, res.summary.termination) == (g["iterations"], g["termination"])
+    assert [t.step_is_successful for t in res.trace] == g["accepted"]
+    assert _dT(res.pose, np.array(g["pose"])) <= T_TOL and abs(res.summary.final_cost - g["final_cost"]) <= COST_TOL
 
 
 # ---------------------------------------------------------------------------------------
