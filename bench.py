@@ -542,6 +542,10 @@ def compact_line(out, detail_file=None):
     if isinstance(rl, dict):
         summ["large"] = _pick(rl, ("frac", "frac_min", "frac_max", "after_idle_worst_frac", "avg_kernel_ms", "kernel_ms_min", "kernel_ms_max", "observations", "launches"), 5)
         summ["large"]["stat"] = rl.get("stat")
+    msv = out.get("multistart")
+    if isinstance(msv, dict) and "ms_per_call" in msv:
+        summ["multistart_1024_ms"] = _num(msv["ms_per_call"], 5)
+        summ["multistart_vs_c3"] = _num(msv.get("vs_c3_batch_of_uploaded_copies"), 4)
     lsv = out.get("roofline_large_solve")
     if isinstance(lsv, dict) and "frac" in lsv:
         summ["large_solve_frac"] = _num(lsv["frac"], 4)
@@ -961,6 +965,30 @@ def main():
                 w = max(w, float(np.abs(sd.T_from_pose7(pb[k]) - sd.T_from_pose7(rk.pose)).max()))
             out["batched_c3"]["T_cl_max_abs_err_vs_oracle_sample"] = w
             out["batched_c3"]["oracle_sample"] = f"{len(sample)} of {Pb} problems (tests/test_gpu_parity.py::test_c3_full_size_batch checks all 1024)"
+
+        # ---- multi-hypothesis calibration on SHARED observations (north_star): 1 024 start poses on ONE problem of the C3 shape — one copy
+        # of its observations on the device (clc_solve_multistart) against the C3 batch of 1 024 uploaded problems above ----
+        try:
+            x_true0 = sd.pose7_from_T(gts[0])
+            starts = solver.pose_plus(np.tile(x_true0, (Pb, 1)), np.random.default_rng(3).normal(size=(Pb, 6)) * 0.05)
+            solver.upload_batched(recs[0], np.array([0, recs[0].shape[0]], dtype=np.int64))
+            tm = []
+            for _ in range(15):
+                t1 = time.perf_counter()
+                pm, smm = solver.solve_multistart(starts)
+                tm.append(time.perf_counter() - t1)
+            dtm = float(np.median(tm[5:]))
+            pi_m = solver.path_info()
+            out["multistart"] = {
+                "workload": f"{Pb} start poses (5 cm / 3 deg around the truth) on ONE problem of {recs[0].shape[0]} observations: clc_solve_multistart, one launch, a workgroup per start",
+                "ms_per_call": 1e3 * dtm, "starts_per_s": Pb / dtm, "vs_c3_batch_of_uploaded_copies": dtm / dtb,
+                "observation_bytes_on_device_lane_layout": int(pi_m.batched_lane_rows) * int(pi_m.batched_lanes) * 16,
+                "observation_bytes_of_1024_uploaded_copies_lane_layout": int(out["batched_c3"]["resident"]["rows"]) * int(out["batched_c3"]["resident"]["lanes_per_problem"]) * 16,
+                "lm_iterations_min_max": [min(s_.num_iterations for s_ in smm), max(s_.num_iterations for s_ in smm)],
+                "max_abs_T_spread_between_starts": float(max(np.abs(sd.T_from_pose7(pm[k]) - sd.T_from_pose7(pm[0])).max() for k in range(Pb))),
+                "resident": bool(pi_m.batched_resident)}
+        except Exception as e:
+            out["multistart"] = {"error": repr(e)}
 
     # ---- CPU baseline + parity (rank 0, N=1): the oracle's DENSE_QR Ceres restatement, 1 thread ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

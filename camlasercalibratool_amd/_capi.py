@@ -26,7 +26,7 @@ EXPORTED = [
     "clc_version", "clc_last_error", "clc_options_default", "clc_create", "clc_destroy", "clc_set_stream",
     "clc_set_launch", "clc_set_auto_paths", "clc_set_small_on_coop", "clc_flatten_observations", "clc_upload", "clc_upload_device", "clc_num_observations",
     "clc_factor_evaluate", "clc_pose_plus", "clc_pose_plus_jacobian", "clc_eval", "clc_solve",
-    "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_num_problems",
+    "clc_information", "clc_closed_form", "clc_upload_batched", "clc_solve_batched", "clc_solve_multistart", "clc_num_problems",
     "clc_line_options_default", "clc_line_fit_batched", "clc_scan_to_points",
     "clc_comm_unique_id", "clc_comm_create", "clc_comm_destroy", "clc_comm_rank", "clc_comm_world",
     "clc_gather_results", "clc_comm_records", "clc_solve_batched_gather", "clc_comm_set_root", "clc_comm_get_info",

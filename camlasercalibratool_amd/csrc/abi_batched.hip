@@ -125,14 +125,17 @@ void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLau
 }
 
 void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl, clc_summary* d_summaries, double* d_results,
-                           double rec_base, double* rec_host, long long seg_off, unsigned long long goal) {
+                           double rec_base, double* rec_host, long long seg_off, unsigned long long goal, const MultiStartLaunch* multistart) {
   // one workgroup per problem, the problem read from HBM once and kept in registers + LDS for its whole solve
-  const size_t P = h->n_problems;
+  // (multi-start: one workgroup per START, every one of them on problem 0's points)
+  const size_t P = multistart ? multistart->n_starts : h->n_problems;
+  double* const d_poses = multistart ? multistart->d_poses : h->d_poses;
+  const int uni_ppl = multistart ? -2 - h->bres.max_ppl : h->bres.uni_ppl;
   const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->bres.d_row);
   const clc::ResLane* d_desc = reinterpret_cast<const clc::ResLane*>(h->bres.d_desc);
 #define CLC_LAUNCH_RES(LOSS, NT, NW, PR, PL)                                                                                  \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, NW, PR, PL, kResCtrl##NW>), dim3((unsigned)P), dim3(NW * 64), 0, h->stream, \
-                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, d_summaries, d_results, nullptr, nullptr, \
+                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, uni_ppl, opt, nullptr, 0, d_poses, d_summaries, d_results, nullptr, nullptr, \
                      rec_base, rec_host, seg_off, goal)
 #define CLC_LAUNCH_RES_V(NW, PR, PL)                                                                                          \
   do {                                                                                                                        \
@@ -141,7 +144,7 @@ void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedL
   } while (0)
 #define CLC_LAUNCH_RESZ(LOSS, NT)                                                                                              \
   hipLaunchKernelGGL((clc::resident_solve_kernel<LOSS, NT, 8, kResPRz, kResPLz, kResCtrl8, true>), dim3((unsigned)P), dim3(512), 0, h->stream, \
-                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, h->bres.uni_ppl, opt, nullptr, 0, h->d_poses, d_summaries, d_results, nullptr, nullptr, \
+                     h->bres.d_xy, d_row, d_desc, h->d_bgroups, uni_ppl, opt, nullptr, 0, d_poses, d_summaries, d_results, nullptr, nullptr, \
                      rec_base, rec_host, seg_off, goal, h->bres.d_z)
   if (h->bres.with_z) {  // 24-byte slots (p.z != 0 in some record of the batch)
     if (opt.use_loss) { if (bl.res_nt) CLC_LAUNCH_RESZ(true, true); else CLC_LAUNCH_RESZ(true, false); }
@@ -309,6 +312,81 @@ int clc_solve_batched(clc_handle* h, const clc_options* opt_in, double* poses, c
   return CLC_OK;
 }
 
+
+// Multi-hypothesis calibration on SHARED observations (BASELINE.json north_star: "batched/multi-hypothesis calibration"): n_starts
+// independent LM solves — one ceres::Solve each, src/LaseCamCalCeres.cpp:299-309 — from n_starts start poses on the ONE problem the handle
+// holds as a batch of one (clc_upload_batched* with n_problems = 1).  Where the problem fits a workgroup (the on-chip lane layout: at most
+// 256 x 44 points and 256 scans, or 512 x 22 / 512 scans) ONE launch runs every start: a workgroup per start, every workgroup loading the
+// SAME lane layout (one copy in HBM — 0.17 MB for 1e4 observations where 1 024 uploaded copies are 178 MB — read by the first round of
+// workgroups, served from L2 to the rest) and solving from its own pose; otherwise the starts run one after the other on the batch's
+// streaming path.  Same kernel, same arithmetic as clc_solve_batched of n_starts uploaded copies: bit-identical results.
+int clc_solve_multistart(clc_handle* h, const clc_options* opt_in, size_t n_starts, double* poses, clc_summary* summaries) {
+  if (!h || !poses || !summaries || n_starts == 0) return fail(CLC_ERR_INVALID_ARG, "clc_solve_multistart: bad argument");
+  if (!h->d_btiles || h->n_problems != 1)
+    return fail(CLC_ERR_NO_DATA, "clc_solve_multistart: the shared observations must be uploaded as a batch of ONE problem (clc_upload_batched, n_problems = 1)");
+  clc_options opt;
+  if (opt_in) opt = *opt_in; else clc_options_default(&opt);
+  {
+    const int rc = batched_check_inputs("clc_solve_multistart", opt, poses, n_starts);
+    if (rc != CLC_OK) return rc;
+  }
+  CLC_HIP(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  BatchedLaunch bl;
+  {
+    const int rc = batched_launch_setup(h, opt, &bl);
+    if (rc != CLC_OK) return rc;
+  }
+  if (!bl.resident) {  // the problem does not fit a workgroup (or explicit flags): one start after the other, still ONE copy of the data
+    for (size_t k = 0; k < n_starts; ++k) {
+      const int rc = clc_solve_batched(h, &opt, poses + 7 * k, summaries + k);
+      if (rc != CLC_OK) return rc;
+    }
+    h->results_valid = 0;  // (the handle's result buffer holds the last start only: nothing for clc_gather_results)
+    return CLC_OK;
+  }
+  if (n_starts > h->ms_cap) {
+    if (h->h_ms_poses) CLC_HIP(hipHostFree(h->h_ms_poses));
+    if (h->h_ms_summaries) CLC_HIP(hipHostFree(h->h_ms_summaries));
+    if (h->d_ms_results) CLC_HIP(hipFree(h->d_ms_results));
+    h->h_ms_poses = h->d_ms_poses = h->d_ms_results = nullptr;
+    h->h_ms_summaries = h->d_ms_summaries = nullptr;
+    h->ms_cap = 0;
+    CLC_HIP(hipHostMalloc(&h->h_ms_poses, sizeof(double) * 7 * n_starts, hipHostMallocMapped));
+    CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_ms_poses), h->h_ms_poses, 0));
+    CLC_HIP(hipHostMalloc(&h->h_ms_summaries, sizeof(clc_summary) * n_starts, hipHostMallocMapped));
+    CLC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_ms_summaries), h->h_ms_summaries, 0));
+    CLC_HIP(hipMalloc(&h->d_ms_results, sizeof(clc_result_record) * n_starts));
+    h->ms_cap = n_starts;
+  }
+  // (the previous call ended with a stream synchronisation: nothing still reads or writes the staging buffers)
+  std::memcpy(h->h_ms_poses, poses, sizeof(double) * 7 * n_starts);
+  const bool timed = opt.profile_events == 1;
+  if (timed) {
+    const int rc = ensure_events(h, 2);
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(hipEventRecord(h->ev[0], h->stream));
+  }
+  MultiStartLaunch ms;
+  ms.n_starts = n_starts;
+  ms.d_poses = h->d_ms_poses;
+  launch_resident_batch(h, opt, bl, h->d_ms_summaries, h->d_ms_results, 0.0, nullptr, 0, 0, &ms);
+  CLC_HIP(hipGetLastError());
+  if (timed) CLC_HIP(hipEventRecord(h->ev[1], h->stream));
+  CLC_HIP(hipStreamSynchronize(h->stream));  // (kernel completion makes the outcomes written over PCIe visible)
+  float kernel_ms = 0.0f;
+  if (timed) CLC_HIP(hipEventElapsedTime(&kernel_ms, h->ev[0], h->ev[1]));
+  std::memcpy(poses, h->h_ms_poses, sizeof(double) * 7 * n_starts);
+  std::memcpy(summaries, h->h_ms_summaries, sizeof(clc_summary) * n_starts);
+  const double ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (size_t k = 0; k < n_starts; ++k) {
+    summaries[k].solve_ms = ms_wall;
+    if (timed) { summaries[k].eval_kernel_ms = (double)kernel_ms; summaries[k].eval_kernel_launches = 1; }
+  }
+  for (size_t k = 0; k < n_starts; ++k)
+    if (!all_finite(poses + 7 * k, 7)) return fail(CLC_ERR_NONFINITE, "clc_solve_multistart: non-finite result");
+  return CLC_OK;
+}
 
 }  // extern "C"
 

@@ -245,6 +245,9 @@ void clc_destroy(clc_handle* h) {
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_mailbox) (void)hipHostFree(h->h_mailbox);
   if (h->h_spose) (void)hipHostFree(h->h_spose);
+  if (h->h_ms_poses) (void)hipHostFree(h->h_ms_poses);
+  if (h->h_ms_summaries) (void)hipHostFree(h->h_ms_summaries);
+  if (h->d_ms_results) (void)hipFree(h->d_ms_results);
   if (h->h_poses) (void)hipHostFree(h->h_poses);
   if (h->h_summaries) (void)hipHostFree(h->h_summaries);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

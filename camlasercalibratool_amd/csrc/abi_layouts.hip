@@ -320,6 +320,7 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
   h->sres.ok = false;
   h->cres.ok = false;
   h->split_grid = -1;
+  h->selection_key = -1;
   int rc = retile_into(h, reinterpret_cast<const double*>(records_dev), n, &h->d_tiles, &h->tiles_cap_bytes);
   if (rc != CLC_OK) return rc;
   CLC_HIP(hipStreamSynchronize(h->stream));
@@ -437,6 +438,10 @@ int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz,
   }
   if (M > 0) CLC_HIP(hipMemcpyAsync(h->d_spts, pts + 3 * pts_off[0], M * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (ML > 0) CLC_HIP(hipMemcpyAsync(h->d_sptl, ptl + 3 * ptl_off[0], ML * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // points_on_line bit-identical to points (the simulation node's input): the selections (linefit, no boundary) and (no linefit) are
+  // then the same records and clc_select_observations builds them once.  Checked for reference-size inputs only (a memcmp of <= 384 KB).
+  h->store_lines_equal_points = M == ML && M <= 16384 && h->s_pts_off == h->s_ptl_off &&
+                                (M == 0 || std::memcmp(pts + 3 * pts_off[0], ptl + 3 * ptl_off[0], M * 3 * sizeof(double)) == 0);
   CLC_HIP(hipStreamSynchronize(h->stream));  // the caller's arrays may go away
   h->store_poses = n_poses;
   h->store_generation++;
@@ -448,12 +453,26 @@ int64_t clc_store_generation(const clc_handle* h) { return h ? h->store_generati
 int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_boundary_constraint, int64_t* n_records) {
   if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_select_observations: NULL handle");
   CLC_HIP(hipSetDevice(h->device));
+  // The selection the handle's observation array already IS (same stored scans, same residual blocks): nothing to build.  The sequence
+  // of main/calibr_offline.cpp:166-170 selects points_on_line for the closed form and again for the refinement; the simulation node
+  // stores points_on_line == points (main/calibr_simulation.cpp:102), so its two selections are the same records as well.
+  bool linefit = use_linefitting_data != 0;
+  const bool boundary = use_boundary_constraint != 0 && linefit;  // (the board-edge terms exist with points_on_line only, :258)
+  if (linefit && !boundary && h->store_lines_equal_points) linefit = false;
+  const long long key = h->store_poses < 0 ? -1 : h->store_generation * 4 + (linefit ? 2 : 0) + (boundary ? 1 : 0);
+  const long long cfg = ((long long)h->launch_flags << 8) | ((long long)h->auto_disable << 1) | (h->small_on_coop ? 1 : 0);  // what an upload depends on
+  if (key >= 0 && key == h->selection_key && cfg == h->selection_cfg) {
+    if (n_records) *n_records = (int64_t)h->n_obs;
+    return CLC_OK;
+  }
   DevBuf<double> aos(&h->pool);
   long long N = 0;
-  int rc = flatten_on_device(h, use_linefitting_data != 0, use_boundary_constraint != 0, &aos, &N);
+  int rc = flatten_on_device(h, linefit, boundary, &aos, &N);
   if (rc != CLC_OK) return rc;
   if (n_records) *n_records = (int64_t)N;
-  return clc_upload_device(h, reinterpret_cast<const clc_observation*>(aos.p), (size_t)N);
+  rc = clc_upload_device(h, reinterpret_cast<const clc_observation*>(aos.p), (size_t)N);
+  if (rc == CLC_OK) { h->selection_key = key; h->selection_cfg = cfg; }  // (clc_upload_device — any upload — forgets the previous selection)
+  return rc;
 }
 
 

@@ -164,6 +164,9 @@ struct clc_handle {
   std::vector<long long> s_pts_off, s_ptl_off;
   int store_poses = -1;                          // -1: nothing stored
   int64_t store_generation = 0;                  // bumped by every successful clc_store_observations (clc_store_generation)
+  bool store_lines_equal_points = false;         // points_on_line is bit for bit points (reference-size inputs only: see clc_store_observations)
+  long long selection_key = -1;                  // the (stored scans, selection) the observation array was built from by clc_select_observations; -1: none
+  long long selection_cfg = -1;                  // ... under these upload-time settings (launch flags, auto paths)
   // launch geometry
   int grid_override = 0;
   int launch_flags = clc_abi::kDefaultLaunchFlags;
@@ -245,6 +248,11 @@ struct clc_handle {
   size_t batch_total_tiles = 0;
   size_t n_problems = 0;
   size_t problems_cap = 0;
+  // clc_solve_multistart: start poses / summaries (pinned, device-mapped) and result records of the starts
+  double* h_ms_poses = nullptr; double* d_ms_poses = nullptr;
+  clc_summary* h_ms_summaries = nullptr; clc_summary* d_ms_summaries = nullptr;
+  double* d_ms_results = nullptr;
+  size_t ms_cap = 0;
 };
 
 namespace clc_abi {
@@ -323,8 +331,13 @@ void launch_batched_eval(clc_handle* h, const clc_options& opt, const BatchedLau
 // records-only form (clc_solve_batched_gather) — d_results / rec_host = the communicator's gather buffer and its pinned host twin
 // ([totals record][gathered array]), this rank's segment seg_off doubles into the array, global index rec_base + k, `goal` = the
 // totals' arrival count at the end of this launch (batched_write_record, clc_kernels.hpp).
+// multistart != nullptr (clc_solve_multistart): `n_starts` workgroups, all on problem 0's layout, start poses / outcomes in the given buffers.
+struct MultiStartLaunch {
+  size_t n_starts = 0;
+  double* d_poses = nullptr;
+};
 void launch_resident_batch(clc_handle* h, const clc_options& opt, const BatchedLaunch& bl, clc_summary* d_summaries, double* d_results,
-                           double rec_base, double* rec_host, long long seg_off, unsigned long long goal);
+                           double rec_base, double* rec_host, long long seg_off, unsigned long long goal, const MultiStartLaunch* multistart = nullptr);
 // the checks clc_solve_batched makes on its options and start poses (shared with clc_solve_batched_gather); CLC_OK or the error set
 int batched_check_inputs(const char* who, const clc_options& opt, const double* poses, size_t n_problems);
 

@@ -187,7 +187,8 @@ __device__ __forceinline__ v2d res_load(const v2d* p) {
 }
 
 // The whole LM solve of one problem per workgroup, the problem resident in registers + LDS.
-// uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read).
+// uni_ppl >= 0: every problem of the batch has this many points per lane (row0 = problem index x uni_ppl, no offset read); -1: offsets from
+// res_row; <= -2: multi-start — every workgroup holds problem 0's layout (-2 - uni_ppl points per lane) and solves from its own start pose.
 // trace (nullable; single-problem launches only): the iteration records of clc_solve.
 // rec_base, rec_host, rec_seg_off, rec_goal: see batched_write_record (clc_kernels.hpp) — used when summaries == nullptr.
 // host_done (nullable): set to 1 in host memory, system-scope release, once the outcome of EVERY problem of the launch is written
@@ -247,9 +248,16 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
   const double pose_w = poses[7 * (size_t)prob + (tid < 7 ? tid : 0)];
   unsigned int row0;
   int ppl;
+  int lay = prob;  // which problem's lane layout this workgroup holds
   if (uni_ppl >= 0) {
     row0 = (unsigned int)prob * (unsigned int)uni_ppl;
     ppl = uni_ppl;
+  } else if (uni_ppl <= -2) {
+    // multi-start on shared observations (clc_solve_multistart): every workgroup holds problem 0's points — ONE copy in HBM, served by
+    // L2 after the first round of workgroups — and solves from ITS OWN start pose; ppl = -2 - uni_ppl
+    row0 = 0u;
+    ppl = -2 - uni_ppl;
+    lay = 0;
   } else {
     row0 = res_row[prob];
     ppl = __builtin_amdgcn_readfirstlane((int)(res_row[prob + 1] - row0));
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, 2) void resident_solve_kernel(
     reg[j] = res_load<NT>(src + (size_t)(j < j_last ? j : j_last) * NL);
     if (WITH_Z) regz[j] = srcz[(size_t)(j < j_last ? j : j_last) * NL];
   }
-  const ResLane dl = lane_desc[(size_t)prob * NL + tid];
+  const ResLane dl = lane_desc[(size_t)lay * NL + tid];
 #pragma unroll
   for (int i = 0; i < PL; ++i) {
     v2d v = lds_v[i];

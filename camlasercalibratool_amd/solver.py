@@ -373,6 +373,16 @@ class Solver:
         check(self._L.clc_solve_batched(self._h, C.byref(o), dptr(poses), sm), "clc_solve_batched")
         return poses, sm
 
+    def solve_multistart(self, poses0: np.ndarray, options: Optional[Options] = None):
+        """clc_solve_multistart: S independent LM solves from S start poses [S, 7] on the ONE problem uploaded as a batch of one
+        (upload_batched(records, [0, n])) — one copy of the observations on the device -> (poses [S, 7], summaries [S])."""
+        poses = np.ascontiguousarray(np.array(poses0, dtype=np.float64).reshape(-1, 7)).copy()
+        S = poses.shape[0]
+        sm = (Summary * S)()
+        o = options or default_options()
+        check(self._L.clc_solve_multistart(self._h, C.byref(o), C.c_size_t(S), dptr(poses), sm), "clc_solve_multistart")
+        return poses, sm
+
     # ---- scan line fitting ----
     def line_fit_batched(self, xy: np.ndarray, offsets: np.ndarray, lines0: np.ndarray,
                          options: Optional[Options] = None, want_summaries: bool = True):

@@ -359,6 +359,15 @@ int clc_scan_to_points_device(clc_handle* h, const float* ranges_dev, const int6
                               size_t n_rays, const float* angle_min_dev, const float* angle_increment_dev,
                               const float* range_min_dev, double* points_dev);
 
+/* Multi-hypothesis calibration on SHARED observations: n_starts independent LM solves (one ceres::Solve each, src/LaseCamCalCeres.cpp
+ * :299-309) from n_starts start poses on the ONE problem the handle holds as a batch of one (clc_upload_batched* with n_problems = 1).
+ * poses: n_starts x 7, in/out; summaries: n_starts.  Where the problem fits a workgroup (clc_path_info.batched_resident) ONE launch runs
+ * every start — a workgroup per start, all of them loading the same on-chip layout: one copy of the observations in HBM instead of
+ * n_starts uploaded copies — and the results are bit-identical to clc_solve_batched of n_starts copies; a larger problem runs its
+ * starts one after the other on the batch's streaming path (a single problem beyond a workgroup is better served by clc_upload +
+ * one clc_solve per start: the cooperative solve uses the whole GPU for each). */
+int clc_solve_multistart(clc_handle* h, const clc_options* opt, size_t n_starts, double* poses_inout, clc_summary* summaries);
+
 /* ---- multi-GPU: sharded batches + RCCL gather ------------------------------------------------
  * BASELINE.json configs[3]: independent T_cl problems shard across the GPUs of a node, one process
  * per GPU, no collective on the data path; the fixed-size result records of all ranks are gathered

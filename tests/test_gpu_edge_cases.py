@@ -350,3 +350,36 @@ def test_sessions_on_the_shared_handle_do_not_solve_each_others_scans(oracle_mod
         ref = oracle_mod.solve(clc.flatten_observations(S, False), sd.pose7_from_T(np.eye(4)), linear_solver="qr")
         assert np.abs(sd.T_from_pose7(r.result.pose) - sd.T_from_pose7(ref.pose)).max() <= 1e-6
         assert abs(r.result.summary.final_cost - ref.summary.final_cost) <= 1e-8
+
+
+def test_repeated_selection_is_built_once_and_forgotten_by_any_upload(sv):
+    """clc_select_observations of the selection the observation array already IS returns at once (the flow of main/calibr_offline.cpp
+    :166-170 selects points_on_line twice; the simulation node's points_on_line == points, so its (linefit) and (no linefit) selections are
+    the same records): same answers, and any upload / new store / upload-time setting in between makes it build again."""
+    import time
+    S = sd.GenerateSimData(3, noise_sigma=0.01)          # points_on_line == points (main/calibr_simulation.cpp:102)
+    host = clc.flatten_observations(S, True, False)
+    assert np.array_equal(host, clc.flatten_observations(S, False, False))
+    sv.set_launch(0, -1)
+    sv.store_observations(S)
+    n = sv.select_observations(True, False)
+    c0, g0, H0 = sv.eval(X0)
+    t = []
+    for lf in (True, False, False, True):
+        t0 = time.perf_counter()
+        assert sv.select_observations(lf, False) == n == host.shape[0] == sv.num_observations
+        t.append(time.perf_counter() - t0)
+        c, g, H = sv.eval(X0)
+        assert c == c0 and np.array_equal(H, H0)
+    assert max(t) < 50e-6, t                              # (a cached selection is a few host instructions, not a dozen launches)
+    sv.upload(host[: n // 2])                             # any upload forgets the selection
+    assert sv.select_observations(True, False) == n and sv.num_observations == n
+    assert sv.eval(X0)[0] == c0
+    S2 = sd.sim_board_edges(5, 30, 40, noise_sigma=0.002)
+    S2.ptl = S2.ptl[::-1].copy()                          # points_on_line differ from points: the two selections are different records
+    sv.store_observations(S2)                             # a new store is a new generation
+    a = sv.select_observations(True, False); ca = sv.eval(X0)[0]
+    b = sv.select_observations(False, False); cb = sv.eval(X0)[0]
+    assert a == b and ca != cb
+    assert sv.select_observations(True, True) == a + 2 * S2.n_poses
+    assert sv.select_observations(False, True) == b and sv.eval(X0)[0] == cb   # (no board-edge terms without points_on_line, :258)

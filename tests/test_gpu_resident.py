@@ -275,3 +275,56 @@ def test_single_problem_resident_options_and_limits(sv, oracle_mod):
     r = sv.solve(X0)
     ref = oracle_mod.solve(rec, X0, linear_solver="qr")
     assert _dT(r.pose, ref.pose) <= T_TOL and abs(r.summary.final_cost - ref.summary.final_cost) <= COST_TOL
+
+
+def test_multistart_on_shared_observations_equals_the_batch_of_copies(oracle_mod):
+    """clc_solve_multistart (north_star: multi-hypothesis calibration): S start poses on ONE uploaded problem — a workgroup per start, every
+    workgroup on the same on-chip layout — against (a) clc_solve_batched of S uploaded COPIES of the problem, bit for bit (same kernel, same
+    arithmetic, same lane layout), and (b) the oracle's solve from every start.  Starts spread 0-15 cm / 0-9 deg around the truth: different
+    iteration counts, some rejected steps.  Both lane widths (256: the default of a batch; 512: a problem with more than 256 scans)."""
+    rng = np.random.default_rng(11)
+    S = 70
+    for n_poses, pts in ((20, 500), (300, 20)):
+        rec = clc.flatten_observations(sd.sim_fixed_count(5 + n_poses, n_poses, pts, noise_sigma=0.01), False)
+        n = rec.shape[0]
+        x_true = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+        with clc.Solver(0) as s:
+            starts = s.pose_plus(np.tile(x_true, (S, 1)), rng.normal(size=(S, 6)) * np.linspace(0.0, 0.05, S)[:, None])
+            s.upload_batched(rec, np.array([0, n], dtype=np.int64))
+            pi = s.path_info()
+            assert pi.batched_resident == 1 and pi.batched_lanes == (256 if n_poses <= 256 else 512)
+            poses, sms = s.solve_multistart(starts)
+            again, _ = s.solve_multistart(starts)
+            assert np.array_equal(poses, again)
+            one, sm1 = s.solve_multistart(starts[3:4])   # a single start: the same answer as in the crowd
+            assert np.array_equal(one[0], poses[3]) and sm1[0].num_iterations == sms[3].num_iterations
+            # the same S problems as uploaded copies
+            s.upload_batched(np.tile(rec, (S, 1)), np.arange(S + 1, dtype=np.int64) * n)
+            cp, csm = s.solve_batched(starts)
+            with pytest.raises(clc.ClcError):
+                s.solve_multistart(starts)               # a batch of S problems is not ONE shared problem
+        assert np.array_equal(poses, cp)
+        its = set()
+        for k in range(S):
+            assert (sms[k].num_iterations, sms[k].termination, sms[k].final_cost) == (csm[k].num_iterations, csm[k].termination, csm[k].final_cost)
+            ref = oracle_mod.solve(rec, starts[k], linear_solver="qr")
+            assert sms[k].num_iterations == ref.summary.num_iterations and sms[k].termination == ref.summary.termination, k
+            assert np.abs(sd.T_from_pose7(poses[k]) - sd.T_from_pose7(ref.pose)).max() <= 1e-6 and abs(sms[k].final_cost - ref.summary.final_cost) <= 1e-8, k
+            its.add(sms[k].num_iterations)
+        assert len(its) >= 2  # (the starts really differ)
+
+
+def test_multistart_on_a_problem_beyond_one_workgroup_runs_the_starts_in_turn(oracle_mod):
+    """A shared problem that no workgroup holds (60 poses x 500 points = 30 000 observations): clc_solve_multistart still answers every
+    start — one after the other on the batch's streaming path — with ONE copy of the data on the device."""
+    rec = clc.flatten_observations(sd.sim_fixed_count(9, 60, 500, noise_sigma=0.01), False)
+    x_true = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    with clc.Solver(0) as s:
+        starts = s.pose_plus(np.tile(x_true, (5, 1)), np.random.default_rng(2).normal(size=(5, 6)) * 0.03)
+        s.upload_batched(rec, np.array([0, rec.shape[0]], dtype=np.int64))
+        assert s.path_info().batched_resident == 0
+        poses, sms = s.solve_multistart(starts)
+    for k in range(5):
+        ref = oracle_mod.solve(rec, starts[k], linear_solver="qr")
+        assert sms[k].num_iterations == ref.summary.num_iterations
+        assert np.abs(sd.T_from_pose7(poses[k]) - sd.T_from_pose7(ref.pose)).max() <= 1e-6 and abs(sms[k].final_cost - ref.summary.final_cost) <= 1e-8
