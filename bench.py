@@ -64,8 +64,8 @@ MIN_BYTES_PER_SCAN = 40      # ... plus one plane (4 doubles) and one scale per 
 INFINITY_CACHE_BYTES = 256 * 2**20
 VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: FP64 (and any other) VALU issue peak
 # The whole-solve kernels are priced against FP64 VALU issue with instruction counts that are constants of a BUILD (the pass's
-# instruction stream does not depend on the data): PMC SQ_INSTS_VALU of the profile scripts (scripts/profile_r05.sh ->
-# scripts/summarize_r05.py), kept in profiles/valu_counts.json together with the identity of the sources they were measured on
+# instruction stream does not depend on the data): PMC SQ_INSTS_VALU of the profile scripts (scripts/profile_kernels.sh ->
+# scripts/summarize_kernels.py), kept in profiles/valu_counts.json together with the identity of the sources they were measured on
 # (`csrc_sha16` = camlasercalibratool_amd/_build.csrc_sha16(), `head`).  When the sources in the tree differ from that identity the
 # counts are NOT used: `roofline.frac` is null and `valu_issue.current` false, until the profile is regenerated.
 VALU_COUNTS_FILE = os.path.join(ROOT, "profiles", "valu_counts.json")
@@ -85,7 +85,7 @@ def valu_counts(path=None, sha=None):
     if not info["current"]:
         info["tree_csrc_sha16"] = sha
         print(f"bench.py: profiles/valu_counts.json was measured on sources {d.get('csrc_sha16')} but the tree is {sha}: VALU counts "
-              "not used (roofline.frac = null); regenerate with scripts/profile_r05.sh + scripts/summarize_r05.py", file=sys.stderr)
+              "not used (roofline.frac = null); regenerate with scripts/profile_kernels.sh + scripts/summarize_kernels.py", file=sys.stderr)
         return None, info
     return d, info
 
@@ -806,7 +806,7 @@ def main():
             roof["tiled64"] = dict(hbm_figures(BYTES_PER_EVAL * n_obs, BYTES_PER_EVAL * n_obs, b2b64 * 1e-3), avg_kernel_ms=b2b64,
                                    note="64-byte records streamed as stored: bytes moved == the contract's algorithmic bytes")
             roof["note"] = (f"{streamed / 2**20:.0f} MiB working set fits the 256 MiB Infinity Cache: steady-state passes are served on-die, and "
-                            "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 1.7, the LM controller 2.2, reductions 1.4: scripts/r02_stamps.py); "
+                            "~6.5 us of every launch is fixed cost (launch boundary 1.2, the previous launch's 57 KB of partial rows 1.7, the LM controller 2.2, reductions 1.4: scripts/stamps_step.py); "
                             "`frac` (= `frac_moved`) is bytes moved / time / 8 TB/s and is bounded by 1; `contract_64B_frac` prices the launch at the contract's 64 algorithmic bytes per "
                             "evaluation; see roofline_large for a working set beyond the cache")
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")

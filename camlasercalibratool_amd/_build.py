@@ -1,7 +1,6 @@
-"""Build of the HIP extension (in-tree, gfx950 only): the translation units csrc/abi_*.hip -> three libraries:
+"""Build of the HIP extension (in-tree, gfx950 only): the translation units csrc/abi_*.hip -> two libraries:
   csrc/libclc_hip.so         the product: exports include/clc.h and nothing else
   csrc/libclc_hip_hooks.so   -DCLC_TEST_HOOKS: + clc_debug_* / clc_time_* (tests, profiling scripts, bench.py's kernel-only legs)
-  csrc/libclc_hip_legacy.so  -DCLC_TEST_HOOKS -DCLC_LEGACY_PATHS: + the superseded paths of clc_legacy.hpp (bit-identity tests)
 The units are compiled in parallel (hipcc -c) and linked with hipcc -shared; objects live under csrc/.obj/<variant>/."""
 from __future__ import annotations
 
@@ -14,11 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 PRODUCT_LIB_PATH = os.path.join(CSRC, "libclc_hip.so")
 HOOKS_LIB_PATH = os.path.join(CSRC, "libclc_hip_hooks.so")
-LEGACY_LIB_PATH = os.path.join(CSRC, "libclc_hip_legacy.so")
 LIB_PATH = os.environ.get("CLC_LIBRARY") or PRODUCT_LIB_PATH  # CLC_LIBRARY: run the package on a different build
 UNITS = ["abi_core.hip", "abi_layouts.hip", "abi_solve.hip", "abi_frontend.hip", "abi_batched.hip", "abi_comm.hip", "abi_debug.hip"]
 HEADERS = ["clc_abi_internal.hpp", "clc_kernels.hpp", "clc_device.hpp", "clc_layouts.hpp", "clc_stream.hpp", "clc_controller.hpp", "clc_frontend.hpp",
-           "clc_legacy.hpp", "clc_resident.hpp", "clc_coop.hpp", "clc_lmuni.hpp", "clc_rows.hpp", "clc_lm.hpp", "clc_math.hpp", "clc_host.hpp"]
+           "clc_resident.hpp", "clc_coop.hpp", "clc_lmuni.hpp", "clc_rows.hpp", "clc_lm.hpp", "clc_math.hpp", "clc_host.hpp"]
 SOURCES = UNITS + HEADERS
 # -ffp-contract=on: FMA contraction only where the source spells one expression a*b+c (or fma()).  hipcc's default
 # (fast) lets the backend fuse across statements, and it did so differently in different kernels that inline the
@@ -105,11 +103,3 @@ def build_hooks_extension(force: bool = False, verbose: bool = False) -> str:
     if not force and not _is_stale(HOOKS_LIB_PATH):
         return HOOKS_LIB_PATH
     return build_variant(HOOKS_LIB_PATH, ("-DCLC_TEST_HOOKS",), verbose)
-
-
-def build_legacy_extension(force: bool = False, verbose: bool = False) -> str:
-    """The hooks library + the superseded paths (clc_legacy.hpp) that the bit-identity tests compare against (tests run with
-    CLC_LIBRARY=<this file>)."""
-    if not force and not _is_stale(LEGACY_LIB_PATH):
-        return LEGACY_LIB_PATH
-    return build_variant(LEGACY_LIB_PATH, ("-DCLC_TEST_HOOKS", "-DCLC_LEGACY_PATHS"), verbose)

@@ -87,48 +87,9 @@ int clc_debug_math(clc_handle* h, int op, const double* in, double* out, long lo
   return CLC_OK;
 }
 
-// Per-workgroup timeline of one compact-layout evaluation launch: stamps[grid*8] =
-// {wall_start, wall_end (10 ns ticks), cycles prologue, loop, epilogue, 0, 0, 0}; returns grid.
-int clc_debug_eval_timeline(clc_handle* h, const double pose[7], double lf, long long* stamps, int cap_waves,
-                            int block_threads) {
-  if (!h || !pose || !stamps || (block_threads != 256 && block_threads != 512))
-    return fail(CLC_ERR_INVALID_ARG, "clc_debug_eval_timeline: bad argument");
-#ifndef CLC_LEGACY_PATHS
-  return fail(CLC_ERR_INVALID_ARG, "clc_debug_eval_timeline: not in this build (-DCLC_LEGACY_PATHS)");
-#else
-  if (!h->compact_ok) return fail(CLC_ERR_NO_DATA, "clc_debug_eval_timeline: needs the compact layout");
-  CLC_HIP(hipSetDevice(h->device));
-  const int grid = eval_grid(h, h->n_obs);
-  const int n_waves = grid * (block_threads / 64);
-  if (n_waves > cap_waves) return fail(CLC_ERR_INVALID_ARG, "clc_debug_eval_timeline: stamps buffer too small");
-  int rc = ensure_partials(h, grid);
-  if (rc != CLC_OK) return rc;
-  DevBuf<long long> bs(&h->pool);
-  CLC_HIP(bs.alloc((size_t)n_waves * 8));
-  std::memcpy(h->h_small, pose, 7 * sizeof(double));
-  CLC_HIP(hipMemcpyAsync(h->d_small, h->h_small, 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  for (int rep = 0; rep < 4; ++rep) {  // the last launch is the one reported (warm)
-    if (block_threads == 256)
-      hipLaunchKernelGGL((clc::eval_timeline_kernel<256>), dim3(grid), dim3(256), 0, h->stream, h->d_ctiles, h->d_groups,
-                         (long long)h->n_obs, h->d_small, lf, h->d_partials, bs.p);
-    else
-      hipLaunchKernelGGL((clc::eval_timeline_kernel<512>), dim3(grid), dim3(512), 0, h->stream, h->d_ctiles, h->d_groups,
-                         (long long)h->n_obs, h->d_small, lf, h->d_partials, bs.p);
-  }
-  CLC_HIP(hipGetLastError());
-  CLC_HIP(hipStreamSynchronize(h->stream));
-  CLC_HIP(hipMemcpy(stamps, bs.p, sizeof(long long) * (size_t)n_waves * 8, hipMemcpyDeviceToHost));
-  return n_waves;
-#endif
-}
-
-// What this build of the library contains beyond the default: bit 0 = the legacy paths of clc_legacy.hpp
-// (-DCLC_LEGACY_PATHS: flag 8 of clc_set_launch, clc_debug_eval_timeline), bit 1 = debug stamps (-DCLC_STAMPS).
+// What this build of the library contains beyond the default: bit 1 = debug stamps (-DCLC_STAMPS).
 int clc_debug_build_features(void) {
   int f = 0;
-#ifdef CLC_LEGACY_PATHS
-  f |= 1;
-#endif
 #ifdef CLC_STAMPS
   f |= 2;
 #endif

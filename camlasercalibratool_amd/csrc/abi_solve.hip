@@ -564,15 +564,6 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
   // device has reported done (pinned mailbox), so the stream never drains and the host never
   // blocks; at most `lookahead` already-queued iterations turn into no-ops after termination.
   const int lookahead = opt.launch_ahead > 0 ? opt.launch_ahead : default_lookahead();
-  // Controller in the tail of the evaluation launch (one launch per LM iteration) vs its own launch: fused saves a
-  // launch boundary (~1 us per iteration) when the evaluation is short, and loses a little when many workgroups
-  // queue for the ticket (scripts/size_sweep.py: 0.178 vs 0.193 ms at 5 500 obs, 0.222 vs 0.213 at 1e5, equal at 1e6).
-#ifdef CLC_LEGACY_PATHS
-  const bool fused = !use_rows(h) && ((h->launch_flags & clc::FLAG_FUSED_LM) != 0 || (h->launch_auto && grid < h->num_cus));
-#else
-  const bool fused = false;  // (eval_lm_kernel lives in clc_legacy.hpp; the default build runs the launch pair here)
-#endif
-
   clc::HostMailbox* mb = h->h_mailbox;
   mb->n_done = 0;
   mb->status = CLC_RUNNING;
@@ -580,11 +571,6 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
 
   clc::Pose7 p0;
   for (int i = 0; i < 7; ++i) p0.v[i] = pose[i];
-  if (fused) {  // the fused kernel reads the LM state at entry: initialise it with its own launch
-    hipLaunchKernelGGL(clc::lm_init_kernel, dim3(1), dim3(64), 0, h->stream, h->d_state, opt, p0, h->d_ticket);
-    CLC_HIP(hipGetLastError());
-  }
-
   const double* d_x_eval = reinterpret_cast<const double*>(
       reinterpret_cast<const char*>(h->d_state) + offsetof(clc::LmState, x_eval));
   const int32_t* d_status = reinterpret_cast<const int32_t*>(
@@ -603,30 +589,6 @@ int clc_solve(clc_handle* h, const clc_options* opt_in, double pose[7], clc_summ
     const int done = std::min(__atomic_load_n(&mb->n_done, __ATOMIC_ACQUIRE), launched);  // see solve_stepped
     if (launched < max_evals && launched - done < lookahead) {
       if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched], h->stream));
-#ifdef CLC_LEGACY_PATHS
-      if (fused) {
-        const bool nt = (h->launch_flags & clc::FLAG_NONTEMPORAL) != 0;
-        const bool cp = (h->launch_flags & clc::FLAG_COMPACT) != 0 && h->compact_ok;
-        const bool big = (h->launch_flags & clc::FLAG_WG512) != 0;
-        const bool deep = (h->launch_flags & clc::FLAG_DEEP) != 0 ||
-                          (h->launch_auto && (size_t)h->n_obs * 28 > kInfinityCacheBytes);
-#define CLC_LAUNCH_FUSED(LOSS, NT, CP, DEEP, BT)                                                          \
-  hipLaunchKernelGGL((clc::eval_lm_kernel<LOSS, NT, CP, DEEP, BT>), dim3(grid), dim3(BT), 0, h->stream,   \
-                     (CP) ? h->d_ctiles : h->d_tiles, h->d_groups, (long long)h->n_obs, h->d_state, opt,  \
-                     h->d_partials, h->d_ticket, d_trace, d_trace_cap, h->d_mailbox)
-#define CLC_LAUNCH_FUSED_L(NT, CP, DEEP, BT)                                                               \
-  do { if (opt.use_loss) CLC_LAUNCH_FUSED(true, NT, CP, DEEP, BT); else CLC_LAUNCH_FUSED(false, NT, CP, DEEP, BT); } while (0)
-        if (cp && big && deep) CLC_LAUNCH_FUSED_L(false, true, true, 512);
-        else if (cp && big) CLC_LAUNCH_FUSED_L(false, true, false, 512);
-        else if (cp && deep) CLC_LAUNCH_FUSED_L(false, true, true, 256);
-        else if (cp) CLC_LAUNCH_FUSED_L(false, true, false, 256);
-        else if (nt) CLC_LAUNCH_FUSED_L(true, false, false, 256);
-        else CLC_LAUNCH_FUSED_L(false, false, false, 256);
-#undef CLC_LAUNCH_FUSED_L
-#undef CLC_LAUNCH_FUSED
-        if (opt.profile_events) CLC_HIP(hipEventRecord(h->ev[2 * launched + 1], h->stream));
-      } else
-#endif
       {
         // iteration 0 carries the initial pose by value and initialises the LM state in lm_kernel
         const bool first = launched == 0;

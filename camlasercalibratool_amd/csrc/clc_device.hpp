@@ -252,7 +252,6 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 constexpr int FLAG_REDUCE_SHUFFLE = 1;  // reference wave reduction instead of the butterfly
 constexpr int FLAG_PREFETCH = 2;        // software-pipelined tile loads (next tile in flight while computing)
 constexpr int FLAG_NONTEMPORAL = 4;     // nt loads for the streamed tiles
-constexpr int FLAG_FUSED_LM = 8;        // CLC_LEGACY_PATHS builds: clc_solve: controller in the tail of the evaluation launch
 constexpr int FLAG_COMPACT = 16;      // stream the compact layout (clc_stream.hpp) when it is available
 constexpr int FLAG_DEEP = 64;            // compact layout: two tiles of points in flight per wave (HBM-resident arrays)
 constexpr int FLAG_WG512 = 32;          // 512-thread workgroups with the 3:2 old/young wave tile weighting

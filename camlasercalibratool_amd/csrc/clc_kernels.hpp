@@ -613,4 +613,3 @@ static __global__ void pack_results_kernel(const double* __restrict__ results, l
 }  // namespace clc
 
 #include "clc_frontend.hpp"
-#include "clc_legacy.hpp"

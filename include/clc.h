@@ -139,28 +139,20 @@ void clc_destroy(clc_handle* h);
  * work of this handle on the old one.  Device pointers handed to this library (clc_upload_device,
  * the *_device entry points) must be ready on the handle's CURRENT stream. */
 int clc_set_stream(clc_handle* h, void* hip_stream);
-/* Tuning of the evaluation launch: grid_blocks = number of 256-thread workgroups (0 = library
- * default); flags: 1 = reference shuffle reduction instead of the butterfly, 2 = software
- * prefetch of the next tile (64-byte layout), 4 = non-temporal loads, 8 = clc_solve runs the LM
- * controller in the tail of the evaluation launch (one launch per iteration), 16 = compact 28-byte
- * layout, 32 = 512-thread workgroups with old/young wave tile weighting, 64 = compact layout with
- * two tiles in flight per wave, 128 = clc_solve issues ONE launch per LM iteration (every workgroup
- * runs the controller on the previous launch's partial rows before it streams; needs 32 and 16 or 256),
- * 256 = row layout (every scan padded to rows of 64 points, 16-byte (x, y) stream + one 64-byte
- * descriptor per row, per-scan moment accumulation; arrays with some p.z != 0 keep 64 z per row as well,
- * 24-byte stream, and run the lockstep batched solver), 512 = row layout with equal row shares per wave whose boundaries are moved to
- * the nearest scan start (instead of 3:2 old/young shares cut anywhere), 1024 = batched row
- * kernel in 256-thread workgroups (default: one wave per workgroup for batches of >= 8 problems per CU),
- * 2048 = batched solver: lockstep [evaluation, controller] launches per LM iteration even where the default
- * is one workgroup per problem running the problem's whole solve in ONE launch (row layout of at most 1 GiB,
- * no problem longer than 1 024 rows of 64 points — scans are padded to whole rows),
- * 4096 = batched solver: not the on-chip resident kernel (one workgroup per problem reads the problem's scan points from
- * HBM ONCE into registers + LDS and runs the whole solve there; the default whenever every problem of the batch fits a
- * workgroup: at most ~11 000 points and 512 scans, p.z == 0) — at upload: do not build its layout; at solve: run the
- * paths above, 8192 = resident layout over 512 lanes (one 512-thread workgroup per CU) even where 256 lanes (two
- * problems per CU) hold every problem;
- * -1 = library default (2|16|32|128|256|512; non-temporal loads / the deep pipeline chosen per launch when
- * the array exceeds the 256 MiB Infinity Cache).  Results change only in summation order. */
+/* Explicit choice of the streaming paths — what the A/B tests and the profiling scripts use; a caller keeps the default (-1).
+ * grid_blocks = workgroups of the evaluation / step launches (0 = library default: one 512-thread workgroup per CU).
+ * flags = -1: library default = 2|16|32|128|256|512 with the size-dependent choices made per launch (non-temporal loads and deeper
+ *   pipelines beyond the 256 MiB Infinity Cache) AND the on-chip solve paths of clc_solve (clc_set_auto_paths).  Any explicit value
+ *   selects the streaming paths only (clc_solve = step chain / launch pair), as a sum of:
+ *      1  reference shuffle reduction instead of the butterfly          2  software prefetch of the next tile (64-byte tiles)
+ *      4  non-temporal loads                                           16  compact 28-byte layout where available (lossless; arrays without
+ *     32  512-thread workgroups (3:2 old/young wave shares)                dense scans, and the step chain below 2e5 observations)
+ *     64  compact layout: two tiles in flight per wave                128  clc_solve = ONE step_kernel launch per LM iteration (needs 32 and 16 or 256)
+ *    256  row layout (scans padded to rows of 64 points: 16 B/point + a 64-byte descriptor per row, per-scan moments; 24 B/point when p.z != 0)
+ *    512  row layout: equal wave shares cut at scan starts           1024  batched row kernel in 256-thread workgroups (default: one wave each)
+ *   2048  batched solver: lockstep [evaluation, controller] launches 4096  batched solver: not the on-chip resident kernel (at upload: its
+ *   8192  resident layout over 512 lanes even where 256 hold it            layout is not built)
+ * Results change only in summation order. */
 int clc_set_launch(clc_handle* h, int grid_blocks, int flags);
 
 /* Which of the size-chosen default paths of clc_solve (flags = -1 above) may run; disable_mask is a sum of

@@ -6,7 +6,7 @@
   phase B   the same after 200 ms of idle (clock ramp-down?)
   phase C   40 single launches, each followed by a stream synchronisation (launch-to-launch gaps of ~20 us)
   phase D   10 groups of 100 back-to-back launches (10 ms of sustained streaming each: power / thermal management?)
-Prints one JSON line; scripts/summarize_r05.py turns it and the kernel trace into profiles/r05_large.md."""
+Prints one JSON line; scripts/summarize_kernels.py turns it and the kernel trace into profiles/r05_large.md."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

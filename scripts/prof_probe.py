@@ -40,7 +40,7 @@ elif what in ("coop", "coopz"):
     o = clc.default_options()
     if len(sys.argv) > 3:
         o.max_num_iterations = int(sys.argv[3])
-    for _ in range(int(os.environ.get("CLC_PROBE_SOLVES", "5"))):  # (the trace run of scripts/profile_r05.sh asks for 60: a steadier median)
+    for _ in range(int(os.environ.get("CLC_PROBE_SOLVES", "5"))):  # (the trace run of scripts/profile_kernels.sh asks for 60: a steadier median)
         r = sv.solve(x0, o, trace_cap=0)
     _, _, solves, aborts, off = sv.debug_coop()
     out.update(workgroups=sv.path_info().coop_workgroups, z=sv.path_info().coop_points_carry_z, coop_built=built, points_per_lane=ppl, coop_solves=solves, aborts=aborts, passes=int(r.summary.num_evaluations), solve_ms=r.summary.solve_ms,

@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box, round 4: rocprofv3 evidence for the cooperative solve (csrc/clc_coop.hpp, controller of csrc/clc_lmuni.hpp) and the resident
-# batched kernel — kernel trace + stats, PMC passes (separate runs, never with other trace domains) of scripts/r03_prof_probe.py, and the
+# GPU box: rocprofv3 evidence for the cooperative solve (csrc/clc_coop.hpp, controller of csrc/clc_lmuni.hpp) and the resident
+# batched kernel — kernel trace + stats, PMC passes (separate runs, never with other trace domains) of scripts/prof_probe.py, and the
 # kernel stats of the default bench command.  Every run under its own timeout.
-# Outputs: gpurun_out/prof_r04/ (scripts/summarize_r04.py turns them into profiles/r04_*.{md,json,csv}).
-R=$(pwd); O=$R/gpurun_out/prof_r04; mkdir -p $O
+# Outputs: gpurun_out/prof_kernels/ (scripts/summarize_kernels.py turns them into profiles/<round>_*.{md,json,csv}).
+R=$(pwd); O=$R/gpurun_out/prof_kernels; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 run() {  # name, timeout, rocprof args..., -- target args
@@ -12,10 +12,10 @@ run() {  # name, timeout, rocprof args..., -- target args
   timeout $to rocprofv3 "$@" > $O/$name.log 2>&1
   echo "$name rc=$? $(( $(date +%s) - s ))s"
 }
-P="python $R/scripts/r03_prof_probe.py"
+P="python $R/scripts/prof_probe.py"
 VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU SQ_INSTS_LDS"
 if [ "$1" != "--bench-only" ]; then
-run coop_trace 120 --kernel-trace --stats --output-format csv -d $O/coop_trace -o w -- $P coop 1000000
+CLC_PROBE_SOLVES=60 run coop_trace 120 --kernel-trace --stats --output-format csv -d $O/coop_trace -o w -- $P coop 1000000
 run coop_fetch 120 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/coop_fetch -o w -- $P coop 1000000
 run coop_write 120 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/coop_write -o w -- $P coop 1000000
 run coop_valu 120 --pmc $VALU --kernel-trace --output-format csv -d $O/coop_valu -o w -- $P coop 1000000

@@ -12,7 +12,7 @@ run() {  # name, timeout, rocprof args..., -- target args
   timeout $to rocprofv3 "$@" > $O/$name.log 2>&1
   echo "$name rc=$? $(( $(date +%s) - s ))s"
 }
-P="python $R/scripts/r03_prof_probe.py"
+P="python $R/scripts/prof_probe.py"
 run trace 300 --kernel-trace --stats --output-format csv -d $O/trace -o w -- $P large $N
 run fetch 300 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o w -- $P large $N
 run write 300 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- $P large $N

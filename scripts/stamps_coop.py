@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Where a pass of coop_solve_kernel goes, round 4 (C2 shape): a -DCLC_STAMPS build (python scripts/r04_coop_stamps.py --build where
+"""Where a pass of coop_solve_kernel goes, round 4 (C2 shape): a -DCLC_STAMPS build (python scripts/stamps_coop.py --build where
 hipcc is) stamps, per pass, wave 0 (and wave 3) of workgroups 0 and 7 (leaders), 8 and 255 with the shader clock — slots of
 csrc/clc_coop.hpp: 0 pass start, 8 pose + plane set up, 9 points done, 10 expansion done, 1 partials in LDS, 2 row published (behind
 barrier A), 3 group rows gathered / 4 group row published (leaders), 11 lmu_pre done (leaders: after 4), 5 the 8 group rows arrived,
 6 totals in LDS, 7 lmu_post done (before barrier B).  Slots 0-2, 8-10 are point wave 0's, the others the controller wave's.
-usage (GPU box): CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_stamps.so python scripts/r04_coop_stamps.py [n_poses] [pts]"""
+usage (GPU box): CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_stamps.so python scripts/stamps_coop.py [n_poses] [pts]"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Where a workgroup of resident_solve_kernel spends its time: a -DCLC_STAMPS build (python scripts/r03_res_stamps.py --build
+"""Where a workgroup of resident_solve_kernel spends its time: a -DCLC_STAMPS build (python scripts/stamps_resident.py --build
 where hipcc is; loaded through CLC_LIBRARY) stamps kernel entry / exit (100 MHz wall clock) and, per pass, pass start, end of
 the point loop, end of the wave reduction, barrier 1 passed, totals done, controller done / barrier 2 passed (shader clock)
 for waves 0 and 1 of the first 1 024 problems.
-usage (GPU box): CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_stamps.so python scripts/r03_res_stamps.py [P] [flags-at-upload]"""
+usage (GPU box): CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_stamps.so python scripts/stamps_resident.py [P] [flags-at-upload]"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

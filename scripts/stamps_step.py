@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where a step_kernel launch spends its time, for EVERY workgroup: a -DCLC_STAMPS build of the library (built by
-`python scripts/r02_stamps.py --build` where hipcc is, loaded through CLC_LIBRARY) records 100 MHz wall-clock stamps
+`python scripts/stamps_step.py --build` where hipcc is, loaded through CLC_LIBRARY) records 100 MHz wall-clock stamps
 (entry, rows summed, barrier passed, controller done, stream done, end; first and last wave) per workgroup and launch.
-usage (GPU box): CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_stamps.so python scripts/r02_stamps.py [obs_poses pts]"""
+usage (GPU box): CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_stamps.so python scripts/stamps_step.py [obs_poses pts]"""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

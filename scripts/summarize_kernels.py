@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_r05/ (scripts/profile_r05.sh) -> committed evidence under profiles/:
+"""gpurun_out/prof_kernels/ (scripts/profile_kernels.sh) -> committed evidence under profiles/ (TAG = the round, CLC_PROFILE_TAG, default r06):
   r05_coop.md                 rocprofv3 durations of coop_solve_kernel at C2, PMC HBM-side bytes, instruction counts per launch AND per pass
-                              (two launches with different pass counts), wait counters; the stamp table of scripts/r04_coop_stamps.py is
+                              (two launches with different pass counts), wait counters; the stamp table of scripts/stamps_coop.py is
                               appended from gpurun_out/r05_stamps.txt when present
   r05_coop_traffic.json       what bench.py reads: HBM bytes per launch, VALU wave-instructions per workgroup and pass
   r05_resident.md / r05_resident_traffic.json   the resident batched kernel at the C4 shard (8 192 problems x 1e4 observations)
@@ -10,7 +10,8 @@ PMC units (MI355X_MICROARCH.md, HBM / rocprofv3 section): read bytes = 2 x FETCH
 calibrated against the 64-byte-tile kernel in profiles/r03_kernels.md: 1.00008), write = WRITE_SIZE x 1024; separate --pmc passes."""
 import collections, csv, json, os, shutil, statistics
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", "prof_r05")
+TAG = os.environ.get("CLC_PROFILE_TAG", "r06")
+src = os.path.join(root, "gpurun_out", "prof_kernels")
 dst = os.path.join(root, "profiles")
 
 
@@ -55,11 +56,11 @@ if inf:
     inf4 = info("coop_valu4")
     rd, wr = 2 * 1024 * statistics.median(fetch), 1024 * statistics.median(write)
     passes = inf.get("passes", 0)
-    L = ["# rocprofv3 evidence for the cooperative solve, round 5 (MI355X) — `scripts/profile_r05.sh`", "",
-         f"Target: `scripts/r03_prof_probe.py coop 1000000` — {len(d)} (trace run; 5 in the counter runs) default `clc_solve` of the C2 problem (1e6 observations, {inf.get('points_per_lane')} points per lane, "
+    L = [f"# rocprofv3 evidence for the cooperative solve, {TAG} (MI355X) — `scripts/profile_kernels.sh`", "",
+         f"Target: `scripts/prof_probe.py coop 1000000` — {len(d)} (trace run; 5 in the counter runs) default `clc_solve` of the C2 problem (1e6 observations, {inf.get('points_per_lane')} points per lane, "
          f"{passes} evaluation passes per solve), each ONE launch of `coop_solve_kernel` (5 waves per workgroup: 4 point waves + the controller wave of "
          f"`csrc/clc_lmuni.hpp`); launches that timed out: {inf.get('aborts')}.", "",
-         "| | round 5 | round 3 (`profiles/r03_coop.md`; round 4: `profiles/r04_coop.md`) |", "|---|---|---|",
+         f"| | {TAG} | round 3 (`profiles/r03_coop.md`; rounds 4, 5: `profiles/r04_coop.md`, `profiles/r05_coop.md`) |", "|---|---|---|",
          f"| `coop_solve_kernel` dispatches in the trace | {len(d)} | 5 |",
          f"| duration per launch, rocprofv3 kernel trace (us) | median {statistics.median(d):.1f}, min {min(d):.1f}, max {max(d):.1f} | median 88.5, min 88.1, max 91.4 |",
          f"| per evaluation pass (us) | {statistics.median(d) / max(1, passes):.2f} | 6.81 |",
@@ -93,19 +94,19 @@ if inf:
     if wc and wc2 and "SQ_WAIT_ANY" in wc2[0] and "SQ_WAVE_CYCLES" in wc[0]:
         L.append(f"| waves waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) | {med(wc2, 'SQ_WAIT_ANY') / med(wc, 'SQ_WAVE_CYCLES'):.2f} | 0.69 |")
     L += ["", "PMC passes serialise kernels and slow the polling kernel down; durations are taken from the kernel-trace run only.", ""]
-    st = os.path.join(root, "gpurun_out", "r05_stamps.txt")
+    st = os.path.join(root, "gpurun_out", "coop_stamps.txt")
     if os.path.exists(st):
-        L += ["## Where a pass goes: shader-clock stamps of a `-DCLC_STAMPS` build (`scripts/r04_coop_stamps.py`; the stamps themselves cost ~10 % of a pass)", "",
+        L += ["## Where a pass goes: shader-clock stamps of a `-DCLC_STAMPS` build (`scripts/stamps_coop.py`; the stamps themselves cost ~10 % of a pass)", "",
               "```", open(st).read().rstrip(), "```", ""]
-    open(os.path.join(dst, "r05_coop.md"), "w").write("\n".join(L))
+    open(os.path.join(dst, TAG + "_coop.md"), "w").write("\n".join(L))
     json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "lane_layout_bytes": inf.get("lane_layout_bytes"), "passes": passes,
                "kernel_us_median": statistics.median(d),
                "valu_wave_instructions_per_launch": (med(valu, "SQ_INSTS_VALU") if valu else None),
                "valu_wave_instructions_per_workgroup_and_pass": (per_pass["SQ_INSTS_VALU"] / 256 if per_pass else None),
                "points_per_lane": inf.get("points_per_lane"),
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (separate passes) of scripts/r03_prof_probe.py coop 1000000 [4], median of 5 launches; "
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (separate passes) of scripts/prof_probe.py coop 1000000 [4], median of 5 launches; "
                          "read = 2 x FETCH_SIZE x 1024 (gfx950); per pass = difference of a 13-pass and a shorter launch"},
-              open(os.path.join(dst, "r05_coop_traffic.json"), "w"), indent=1)
+              open(os.path.join(dst, TAG + "_coop_traffic.json"), "w"), indent=1)
 
 # ---- resident batched kernel at the C4 shard ----
 KR = "resident_solve_kernel"
@@ -117,8 +118,8 @@ if infr:
     fr = [c["FETCH_SIZE"] for c in counters("res_fetch", KR)]
     wt = [c["WRITE_SIZE"] for c in counters("res_write", KR)]
     vr = counters("res_valu", KR)
-    R = ["# rocprofv3 evidence for the resident batched kernel, round 5 (MI355X) — `scripts/profile_r05.sh`", "",
-         f"Target: `scripts/r03_prof_probe.py resident {P}` — {P} problems x 10^4 observations (the C4 shard), 5 x `clc_solve_batched` on the default path "
+    R = [f"# rocprofv3 evidence for the resident batched kernel, {TAG} (MI355X) — `scripts/profile_kernels.sh`", "",
+         f"Target: `scripts/prof_probe.py resident {P}` — {P} problems x 10^4 observations (the C4 shard), 5 x `clc_solve_batched` on the default path "
          f"(ONE launch of `resident_solve_kernel` each); lane layout {once / 1e6:.1f} MB; {infr['passes_total'] / P:.2f} evaluation passes per problem.", "",
          "| | |", "|---|---|"]
     rec = {"problems": P, "bytes_of_one_pass_over_the_data": once, "passes_per_problem": infr["passes_total"] / P}
@@ -144,27 +145,26 @@ if infr:
             R.append(f"| VALU issue fraction (lane-instructions / kernel time / 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz) | {fracv:.3f} |")
             rec["valu_issue_frac"] = fracv
     R.append("")
-    rs = os.path.join(root, "gpurun_out", "r05_res_stamps.txt")
+    rs = os.path.join(root, "gpurun_out", "res_stamps.txt")
     if os.path.exists(rs):
-        R += ["## Where a workgroup's time goes, round 5: shader-clock stamps of a `-DCLC_STAMPS` build (`scripts/r03_res_stamps.py`, workgroups 4 096-5 119 of the C4 shard)", "",
+        R += ["## Where a workgroup's time goes: shader-clock stamps of a `-DCLC_STAMPS` build (`scripts/stamps_resident.py`, workgroups 4 096-5 119 of the C4 shard)", "",
               "```", open(rs).read().rstrip(), "```", "",
-              "Round 4 (same script, `DESIGN.md` K4r): load of the problem 11 000 cycles; per pass: point loop 6 000, expansion + padding correction + wave reduction 1 900, "
-              "barrier + totals 800, controller 5 500; lifetime 57 us per problem.  Round 5 changed the kernel's epilogue (records-only outcome), the plane fetch (global_load "
-              "instead of FLAT) and nothing in the pass: the table is the same within noise — the C4 step's gain this round is outside the kernel (below).", ""]
-    step = os.path.join(dst, "r05_c4_step.json")  # (hand-kept: the step forms measured during the round)
+              "Rounds 4-5 (same script, `profiles/r05_resident.md`): load of the problem 11 000 cycles; per pass: point loop 6 000, expansion + padding correction + wave "
+              "reduction 1 900, barrier + totals 800, controller 5 000-6 700; lifetime 57 us per problem.", ""]
+    step = os.path.join(dst, TAG + "_c4_step.json")  # (hand-kept: the step forms measured during the round)
     if os.path.exists(step):
         sj = json.load(open(step))
-        R += ["## The C4 step (8 192 problems x 1e4 observations per GPU + the gather of the result records), round 4 -> round 5", "",
+        R += ["## The C4 step (8 192 problems x 1e4 observations per GPU + the gather of the result records)", "",
               "| step form | ms per step (median of 5 blocks of 20) | kernel (HIP events) |", "|---|---|---|"]
         for row in sj["rows"]:
             R.append(f"| {row['form']} | {row['ms_per_step']:.4f}  (blocks {', '.join(f'{b:.3f}' for b in row['blocks'])}) | {row['kernel_ms']:.4f} |")
         R += ["", sj.get("note", ""), ""]
-    open(os.path.join(dst, "r05_resident.md"), "w").write("\n".join(R))
-    json.dump(rec, open(os.path.join(dst, "r05_resident_traffic.json"), "w"), indent=1)
+    open(os.path.join(dst, TAG + "_resident.md"), "w").write("\n".join(R))
+    json.dump(rec, open(os.path.join(dst, TAG + "_resident_traffic.json"), "w"), indent=1)
     L += R
 bs = os.path.join(src, "bench_trace", "b_kernel_stats.csv")
 if os.path.exists(bs):
-    shutil.copy(bs, os.path.join(dst, "r05_bench_kernel_stats.csv"))
+    shutil.copy(bs, os.path.join(dst, TAG + "_bench_kernel_stats.csv"))
 # ---- what bench.py prices the whole-solve kernels with: the instruction counts + the identity of the sources they were measured on ----
 import subprocess, sys
 sys.path.insert(0, root)
@@ -173,10 +173,10 @@ vc = {"csrc_sha16": _build.csrc_sha16(),
       # the commit the profile was MEASURED on: --head <sha> when summarising later than measuring (gpurun sends the working tree, which has no .git)
       "head": (sys.argv[sys.argv.index("--head") + 1] if "--head" in sys.argv else
                subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip() or None),
-      "source": "rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/r03_prof_probe.py: scripts/profile_r05.sh -> scripts/summarize_r05.py "
-                "(profiles/r05_coop.md, r05_resident.md)", "coop": {}, "resident": {}}
+      "source": "rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/prof_probe.py: scripts/profile_kernels.sh -> scripts/summarize_kernels.py "
+                f"(profiles/{TAG}_coop.md, {TAG}_resident.md)", "coop": {}, "resident": {}}
 try:
-    cj = json.load(open(os.path.join(dst, "r05_coop_traffic.json")))
+    cj = json.load(open(os.path.join(dst, TAG + "_coop_traffic.json")))
     if cj.get("valu_wave_instructions_per_workgroup_and_pass"):
         per = cj["valu_wave_instructions_per_workgroup_and_pass"]
         vc["coop"][str(cj["points_per_lane"])] = {"valu_per_workgroup_pass": per, "valu_per_workgroup_once": cj["valu_wave_instructions_per_launch"] / 256 - cj["passes"] * per,
@@ -184,7 +184,7 @@ try:
 except (OSError, KeyError, TypeError) as e:
     print("valu_counts: no cooperative counts:", e)
 try:
-    rj = json.load(open(os.path.join(dst, "r05_resident_traffic.json")))
+    rj = json.load(open(os.path.join(dst, TAG + "_resident_traffic.json")))
     if rj.get("valu_wave_instructions_per_wave_and_pass"):
         vc["resident"]["42"] = {"valu_per_wave_pass": rj["valu_wave_instructions_per_wave_and_pass"], "valu_per_point": 21.5, "lanes": 256,
                                 "pmc_read_bytes_per_batch": rj.get("pmc_read_bytes_per_batch"), "problems": rj["problems"], "kernel_us_median_rocprofv3": rj.get("kernel_us_median")}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r05_large_{plain,prof}.json + gpurun_out/prof_r05/large/l_kernel_trace.csv (scripts/r05_large_probe.py, alone and under
+"""gpurun_out/r05_large_{plain,prof}.json + gpurun_out/prof_kernels/large/l_kernel_trace.csv (scripts/large_eval_probe.py, alone and under
 rocprofv3 --kernel-trace) -> profiles/r05_large.md + profiles/r05_large_probe.json: the per-dispatch durations of the 3.2e7-observation
 evaluation kernel IN ORDER — what the 83-vs-134 us spread of VERDICT r04 is."""
 import csv, json, os, statistics
@@ -23,7 +23,7 @@ frac = lambda us: B / (us * 1e-6) / 8e12
 names = ["A: 30 groups of 10 right after the upload (+3 warm launches per group)", "B: 10 groups of 10 after 200 ms of idle", "C: 40 single launches, a synchronisation after each",
          "D: 10 groups of 100 back to back"]
 L = ["# The 83-vs-134 us spread of the beyond-the-cache evaluation kernel (VERDICT r04, weak 4 / next 6) — round 5, MI355X", "",
-     f"`scripts/r05_large_probe.py`: `eval_rows_kernel<true, true, 512, true, 12, false>` on {plain['observations']} observations = {B / 1e6:.0f} MB of rows per launch (beyond the 256 MiB "
+     f"`scripts/large_eval_probe.py`: `eval_rows_kernel<true, true, 512, true, 12, false>` on {plain['observations']} observations = {B / 1e6:.0f} MB of rows per launch (beyond the 256 MiB "
      "Infinity Cache), every launch the same work.  Run alone (HIP-event means per group) and under `rocprofv3 --kernel-trace` (per-dispatch durations).", "",
      "**Finding: it is a power-management transient after an idle -> load transition, not the kernel and not the first touch of the allocation.**  The FIRST ~1 ms of "
      "streaming after any idle period runs at 84-85 us per launch; then the launches step to 100 us and, from ~2.3 to ~6.2 ms into the burst, to 118-126 us (the SMU pulls "

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_large/* (scripts/profile_large_solve.sh) + the probe logs of scripts/large_solve_probe.py / large_solve_ab.py / r02_stamps.py
+"""gpurun_out/prof_large/* (scripts/profile_large_solve.sh) + the probe logs of scripts/large_solve_probe.py / large_solve_ab.py / stamps_step.py
 -> profiles/r06_large_solve.md, profiles/r06_large_solve_kernel_stats.csv, profiles/pmc_traffic_large_solve.json: the default-path clc_solve of ONE
 problem beyond the chip's capacity (SURVEY.md §8 row g) as a whole solve against the HBM roofline."""
 import csv, json, os, shutil, statistics as st, subprocess
@@ -84,7 +84,7 @@ for name, title in (("large_probe.log", "## `scripts/large_solve_probe.py` (no p
         L.append("")
 stamps = os.path.join(g, "keep", "large_stamps.log")
 if os.path.exists(stamps):
-    L += ["## Where a steady-state launch spends its time: `-DCLC_STAMPS` build, 100 MHz wall-clock stamps of all 256 workgroups (`scripts/r02_stamps.py 64000 500`)", "",
+    L += ["## Where a steady-state launch spends its time: `-DCLC_STAMPS` build, 100 MHz wall-clock stamps of all 256 workgroups (`scripts/stamps_step.py 64000 500`)", "",
           "(us; the stamps themselves cost a few percent: total 100 us against 96-97 unstamped on the same box)", "", "```"]
     L += [l.rstrip() for l in open(stamps).read().split("\n")[1:] if l.strip()][:2 + 3 * 6]
     L += ["```", "",

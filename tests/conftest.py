@@ -10,7 +10,7 @@ if ROOT not in sys.path:
 # The suite runs on the -DCLC_TEST_HOOKS build: the same translation units as the product library csrc/libclc_hip.so plus the
 # clc_debug_* / clc_time_* hooks the tests drive and inspect the paths with (which the product library does not export:
 # tests/test_abi_symbols.py).  tests/test_gpu_product_library.py runs the product build itself and compares bit for bit.
-# CLC_LIBRARY set by the caller (e.g. the -DCLC_LEGACY_PATHS build) wins.
+# CLC_LIBRARY set by the caller (another build of the same units) wins.
 _HOOKS = os.path.join(ROOT, "camlasercalibratool_amd", "csrc", "libclc_hip_hooks.so")
 if "CLC_LIBRARY" not in os.environ and os.path.exists(_HOOKS):
     os.environ["CLC_LIBRARY"] = _HOOKS

@@ -150,7 +150,7 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_or_refuses():
 
 def test_committed_valu_counts_belong_to_the_kernel_sources_in_the_tree():
     """profiles/valu_counts.json (the PMC instruction counts behind roofline.frac) was measured on exactly the kernel sources that are in
-    the tree: a change to any csrc header or to the compiler flags without re-running scripts/profile_r05.sh + scripts/summarize_r05.py
+    the tree: a change to any csrc header or to the compiler flags without re-running scripts/profile_kernels.sh + scripts/summarize_kernels.py
     turns this red (and bench.py would report frac = null rather than a stale figure)."""
     counts, info = bench.valu_counts()
     assert counts is not None and info["current"] is True, info

@@ -25,7 +25,7 @@ def usage(tmp_path_factory):
     tmp = tmp_path_factory.mktemp("res")
 
     def one(unit):
-        p = subprocess.run([hipcc] + _build.HIPCC_FLAGS + ["-DCLC_TEST_HOOKS", "-DCLC_LEGACY_PATHS", "-c", os.path.join(CSRC, unit), "-o", str(tmp / (unit + ".o")),
+        p = subprocess.run([hipcc] + _build.HIPCC_FLAGS + ["-DCLC_TEST_HOOKS", "-c", os.path.join(CSRC, unit), "-o", str(tmp / (unit + ".o")),
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         return p.stderr
@@ -54,7 +54,7 @@ def _find(usage, *frags):
 
 def test_hot_kernels_do_not_spill(usage):
     hot = (_find(usage, "11eval_kernel") + _find(usage, "9lm_kernel") + _find(usage, "19batched_eval_kernel") +
-           _find(usage, "17batched_lm_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "15line_fit_kernel") +
+           _find(usage, "17batched_lm_kernel") + _find(usage, "15line_fit_kernel") +
            _find(usage, "14normal9_kernel") + _find(usage, "11step_kernel") + _find(usage, "20batched_solve_kernel") +
            _find(usage, "21resident_solve_kernel") + _find(usage, "17coop_solve_kernel"))
     for k in hot:
@@ -79,7 +79,7 @@ def test_default_evaluation_kernel_occupancy(usage):
     (k,) = _find(usage, "11eval_kernelILb1ELb1ELb1ELb0ELb1ELi512E")
     assert usage[k]["Occupancy"] >= 2 and usage[k]["VGPRs"] <= 256
     assert usage[k]["TotalSGPRs"] <= 102
-    for k in _find(usage, "19batched_eval_kernel") + _find(usage, "11step_kernel") + _find(usage, "14eval_lm_kernel") + _find(usage, "20batched_solve_kernel") + _find(usage, "21resident_solve_kernel"):
+    for k in _find(usage, "19batched_eval_kernel") + _find(usage, "11step_kernel") + _find(usage, "20batched_solve_kernel") + _find(usage, "21resident_solve_kernel"):
         assert usage[k]["Occupancy"] >= 2, (k, usage[k])  # the controller inside must not cost the streaming loop its occupancy
 
 

@@ -370,34 +370,6 @@ def test_solver_options_are_honoured(sv, oracle_mod):
     assert res.summary.eval_kernel_launches == res.summary.num_evaluations and res.summary.eval_kernel_ms > 0
 
 
-@pytest.mark.parametrize("grid", [0, 7, 256, 1000, 2048])
-def test_fused_controller_launch_matches_two_kernel_path(sv, oracle_mod, grid):
-    """flags bit 8: the LM controller runs in the tail of the evaluation launch (last-arriving
-    workgroup).  Must give the same solve for any grid (more or fewer workgroups than CUs, i.e.
-    any arrival order / placement), and be bitwise repeatable — a stale or torn inter-workgroup
-    hand-off would show up as run-to-run differences.  The path lives in csrc/clc_legacy.hpp: run with
-    CLC_LIBRARY=camlasercalibratool_amd/csrc/libclc_hip_legacy.so (the -DCLC_LEGACY_PATHS build)."""
-    if not (_capi.lib().clc_debug_build_features() & 1):
-        pytest.skip("default build: the ticket-fused launch is compiled only with -DCLC_LEGACY_PATHS (libclc_hip_legacy.so)")
-    S = sd.sim_fixed_count(77, 400, 500, noise_sigma=0.01)
-    rec = clc.flatten_observations(S, False)
-    sv.upload(rec)
-    ref = oracle_mod.solve(rec, X0, linear_solver="qr")
-    sv.set_launch(grid, 6)
-    two = sv.solve(X0)
-    sv.set_launch(grid, 6 | 8)
-    first = sv.solve(X0)
-    for rep in range(60):
-        r = sv.solve(X0)
-        assert np.array_equal(r.pose, first.pose) and r.summary.final_cost == first.summary.final_cost, rep
-        assert r.summary.num_iterations == first.summary.num_iterations
-    sv.set_launch(0, -1)
-    assert np.array_equal(first.pose, two.pose) and first.summary.final_cost == two.summary.final_cost
-    assert len(first.trace) == len(two.trace) == len(ref.trace)
-    assert _dT(first.pose, ref.pose) <= T_TOL and abs(first.summary.final_cost - ref.summary.final_cost) <= COST_TOL
-    assert first.summary.num_iterations == ref.summary.num_iterations
-
-
 @pytest.mark.parametrize("base", [2 | 16 | 32, 2 | 32 | 256], ids=["compact", "rows"])
 @pytest.mark.parametrize("grid", [0, 1, 7, 256, 300, 1000, 2048])
 @pytest.mark.parametrize("n_poses,noise", [(400, 0.01), (3, 0.03)])
