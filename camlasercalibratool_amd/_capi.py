@@ -41,7 +41,7 @@ HOOKS = [
     "clc_debug_flatten_device", "clc_debug_math", "clc_debug_wave_reduce", "clc_debug_build_features", "clc_debug_rows",
     "clc_debug_wave_split", "clc_debug_resident", "clc_debug_resident_single", "clc_debug_coop", "clc_debug_coop_control",
     "clc_debug_coop_set_tag", "clc_debug_layout", "clc_debug_lm_profile", "clc_time_steps", "clc_time_batched_eval", "clc_time_eval",
-    "clc_debug_comm_create_layout", "clc_debug_single_controller",
+    "clc_debug_comm_create_layout", "clc_debug_single_controller", "clc_debug_fast_small",
 ]
 
 

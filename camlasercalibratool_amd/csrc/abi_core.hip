@@ -245,6 +245,10 @@ void clc_destroy(clc_handle* h) {
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_mailbox) (void)hipHostFree(h->h_mailbox);
   if (h->h_spose) (void)hipHostFree(h->h_spose);
+  if (h->h_stage) (void)hipHostFree(h->h_stage);
+  if (h->d_stage) (void)hipFree(h->d_stage);
+  if (h->ev_stage) (void)hipEventDestroy(h->ev_stage);
+  if (h->d_small_aos) (void)hipFree(h->d_small_aos);
   if (h->h_ms_poses) (void)hipHostFree(h->h_ms_poses);
   if (h->h_ms_summaries) (void)hipHostFree(h->h_ms_summaries);
   if (h->d_ms_results) (void)hipFree(h->d_ms_results);

@@ -180,6 +180,15 @@ extern "C" int clc_debug_single_controller(clc_handle* h, int cooperative_kernel
   return CLC_OK;
 }
 
+// Test hook: the host-planned upload of small problems (abi_layouts.hip, small_fast_upload) on / off — the A/B of the two pipelines;
+// returns through *count how many uploads have taken it on this handle.
+extern "C" int clc_debug_fast_small(clc_handle* h, int enable, long long* count) {
+  if (!h) return fail(CLC_ERR_INVALID_ARG, "clc_debug_fast_small: NULL handle");
+  if (enable >= 0) h->fast_small = enable != 0;
+  if (count) *count = h->fast_small_uploads;
+  return CLC_OK;
+}
+
 // Test hook: the next cooperative solve starts its pass tags here (to exercise the wrap of the 32-bit tags).
 extern "C" int clc_debug_coop_set_tag(clc_handle* h, unsigned int tag) {
   if (!h || tag == 0) return fail(CLC_ERR_INVALID_ARG, "clc_debug_coop_set_tag: bad argument");

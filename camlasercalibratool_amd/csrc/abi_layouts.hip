@@ -294,6 +294,208 @@ int build_layouts(clc_handle* h, const double* d_aos, size_t n_total, const std:
   return CLC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Small single problems — the reference's own sizes (main/calibr_simulation.cpp: 50 poses x ~114 points; main/calibr_offline.cpp:
+// O(10^2) poses): at most 512 x 22 records, p.z == 0, so that ONE workgroup holds the problem.  The generic pipeline above finds the
+// scan structure on the device and reads it back three times (scan count, row count, points per lane) plus two synchronisations for
+// host temporaries: ~0.2 ms of waiting for ~20 us of kernels.  Here the HOST knows the structure — from the stored scans' offsets and tag
+// poses (clc_select_observations) or from the records themselves (clc_upload) —, plans the layouts (scan starts, rows per scan, points
+// per lane: the arithmetic of scan_rows_kernel / res_plan_kernel) and enqueues ONE copy of the tables + the same build kernels, without
+// a single read-back or synchronisation.  Same kernels, same tables: the layouts are bit for bit the generic pipeline's
+// (tests/test_gpu_edge_cases.py::test_small_problems_planned_on_the_host_...).
+struct SmallFlatten {  // clc_select_observations: the records are built on the device first (flatten_kernel)
+  int n_poses;
+  bool linefit, boundary;
+  const std::vector<long long>* rec_off;  // [n_poses + 1]
+};
+
+constexpr size_t kSmallMaxRecords = (size_t)512 * (kResPR512 + kResPL512);
+
+static size_t align8(size_t b) { return (b + 7) & ~(size_t)7; }
+
+// *used = false: not a case for this path (nothing was enqueued) — the caller runs the generic pipeline.
+int small_fast_upload(clc_handle* h, const std::vector<long long>& starts, long long n, bool any_z, const clc_observation* host_records,
+                      const SmallFlatten* fj, bool* used) {
+  *used = false;
+  const size_t G = starts.size() - 1;
+  if (!h->fast_small || n <= 0 || (size_t)n > kSmallMaxRecords || any_z || h->small_on_coop || G == 0 || G > 512) return CLC_OK;
+  if ((h->launch_flags & clc::FLAG_NO_RESIDENT) != 0) return CLC_OK;
+  // ---- the plan (host): rows per scan (scan_rows_kernel), points per lane of the 512-lane layout (res_plan_kernel) ----
+  const bool sparse = G * 4 > (size_t)n;
+  std::vector<unsigned int> brbeg(G + 1, 0u);
+  for (size_t g = 0; g < G; ++g) brbeg[g + 1] = brbeg[g] + (unsigned int)((starts[g + 1] - starts[g] + clc::ROW - 1) / clc::ROW);
+  const long long R = (long long)brbeg[G];
+  const bool rows_ok = !sparse && R > 0 && (size_t)R * clc::ROW <= 3 * (size_t)n + 64;
+  int ppl = 0;
+  for (long long c = std::max<long long>(1, (n + 511) / 512); c <= kResPR512 + kResPL512 && ppl == 0; ++c) {
+    long long lanes = 0;
+    for (size_t g = 0; g < G && lanes <= 512; ++g) lanes += (starts[g + 1] - starts[g] + c - 1) / c;
+    if (lanes <= 512) ppl = (int)c;
+  }
+  if (ppl == 0) return CLC_OK;  // scans that leave too many half-filled lanes: the generic path (cooperative layout)
+  // ---- staging: [flatten's record offsets][rec_off, tile_off of the one problem][starts][gid][row_begin][res_row][records] ----
+  const size_t P1 = fj ? (size_t)fj->n_poses + 1 : 0;
+  const size_t o_foff = 0, o_off = align8(o_foff + P1 * 8), o_starts = o_off + 4 * 8, o_gid = o_starts + (G + 1) * 8,
+               o_brbeg = align8(o_gid + (size_t)n * 4), o_row = align8(o_brbeg + (G + 1) * 4), o_rec = align8(o_row + 8),
+               total = o_rec + (host_records ? (size_t)n * sizeof(clc_observation) : 0);
+  CLC_HIP(hipSetDevice(h->device));
+  if (total > h->stage_cap) {
+    CLC_HIP(hipStreamSynchronize(h->stream));
+    if (h->h_stage) CLC_HIP(hipHostFree(h->h_stage));
+    if (h->d_stage) CLC_HIP(hipFree(h->d_stage));
+    h->h_stage = h->d_stage = nullptr; h->stage_cap = 0; h->stage_busy = false;
+    const size_t cap = std::max<size_t>(total + total / 2, (size_t)256 << 10);
+    CLC_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), cap, hipHostMallocDefault));
+    CLC_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stage), cap));
+    h->stage_cap = cap;
+  }
+  if (!h->ev_stage) CLC_HIP(hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+  if (h->stage_busy) CLC_HIP(hipEventSynchronize(h->ev_stage));  // the previous copy out of the pinned block (long done in practice)
+  {
+    char* b = h->h_stage;
+    if (fj) std::memcpy(b + o_foff, fj->rec_off->data(), P1 * 8);
+    long long* off = reinterpret_cast<long long*>(b + o_off);
+    off[0] = 0; off[1] = n; off[2] = 0; off[3] = (n + clc::TILE - 1) / clc::TILE;
+    std::memcpy(b + o_starts, starts.data(), (G + 1) * 8);
+    unsigned int* gid = reinterpret_cast<unsigned int*>(b + o_gid);
+    for (size_t g = 0; g < G; ++g)
+      for (long long k = starts[g]; k < starts[g + 1]; ++k) gid[k] = (unsigned int)g;
+    std::memcpy(b + o_brbeg, brbeg.data(), (G + 1) * 4);
+    unsigned int* row = reinterpret_cast<unsigned int*>(b + o_row);
+    row[0] = 0u; row[1] = (unsigned int)ppl;
+    if (host_records) std::memcpy(b + o_rec, host_records, (size_t)n * sizeof(clc_observation));
+  }
+  // from here on things are enqueued: an error leaves the handle without observations rather than with half of them
+  h->compact_ok = false; h->rows_ok = false; h->sres.ok = false; h->cres.ok = false; h->split_grid = -1; h->selection_key = -1;
+  h->n_obs = 0;
+  CLC_HIP(hipMemcpyAsync(h->d_stage, h->h_stage, total, hipMemcpyHostToDevice, h->stream));
+  CLC_HIP(hipEventRecord(h->ev_stage, h->stream));
+  h->stage_busy = true;
+  const long long* d_off = reinterpret_cast<const long long*>(h->d_stage + o_off);
+  const long long* d_starts = reinterpret_cast<const long long*>(h->d_stage + o_starts);
+  const unsigned int* d_gid = reinterpret_cast<const unsigned int*>(h->d_stage + o_gid);
+  const unsigned int* d_brbeg = reinterpret_cast<const unsigned int*>(h->d_stage + o_brbeg);
+  const unsigned int* d_row = reinterpret_cast<const unsigned int*>(h->d_stage + o_row);
+  const double* d_aos = reinterpret_cast<const double*>(h->d_stage + o_rec);
+  const int threads = 256;
+  int rc = CLC_OK;
+  if (fj) {  // the selection's records, built on the device from the resident scans (bitwise clc_flatten_observations')
+    rc = ensure_bytes(&h->d_small_aos, &h->small_aos_cap, (size_t)n * sizeof(clc_observation));
+    if (rc != CLC_OK) return rc;
+    long long* d_soff = reinterpret_cast<long long*>(h->d_soff);
+    hipLaunchKernelGGL(clc::flatten_kernel, dim3((unsigned)fj->n_poses), dim3(clc::BLOCK), 0, h->stream, fj->n_poses, h->d_sq, h->d_st, d_soff,
+                       h->d_spts, d_soff + P1, h->d_sptl, fj->linefit ? 1 : 0, fj->boundary ? 1 : 0,
+                       reinterpret_cast<const long long*>(h->d_stage + o_foff), h->d_small_aos);
+    CLC_HIP(hipGetLastError());
+    d_aos = h->d_small_aos;
+  }
+  rc = retile_into(h, d_aos, (size_t)n, &h->d_tiles, &h->tiles_cap_bytes);
+  if (rc != CLC_OK) return rc;
+  // compact layout: group table (what the on-chip kernels take a lane's plane from) + 28-byte tiles
+  const size_t tiles = (size_t)((n + clc::TILE - 1) / clc::TILE);
+  rc = ensure_bytes(&h->d_ctiles, &h->ctiles_cap_bytes, std::max<size_t>(tiles, 1) * clc::CTILE_DOUBLES * sizeof(double));
+  if (rc == CLC_OK) rc = ensure_bytes(&h->d_groups, &h->groups_cap_bytes, G * clc::GROUP_DOUBLES * sizeof(double));
+  if (rc != CLC_OK) return rc;
+  hipLaunchKernelGGL(clc::build_groups_dev_kernel, dim3((unsigned)((G + threads - 1) / threads)), dim3(threads), 0, h->stream, d_aos, d_starts,
+                     (long long)G, h->d_groups);
+  {
+    const long long max_padded = (long long)tiles * clc::TILE;
+    const unsigned ydim = (unsigned)std::min<long long>(4096, std::max<long long>(1, (max_padded + threads - 1) / threads));
+    hipLaunchKernelGGL(clc::build_ctiles_kernel, dim3(1u, ydim), dim3(threads), 0, h->stream, d_aos, d_gid, d_off, d_off + 2, h->d_ctiles);
+  }
+  CLC_HIP(hipGetLastError());
+  if (rows_ok) {  // row layout (one padding row each: see build_layouts)
+    rc = ensure_bytes(&h->d_rxy, &h->rxy_cap_bytes, ((size_t)R + 1) * clc::ROW_DOUBLES * sizeof(double));
+    if (rc == CLC_OK) rc = ensure_bytes(&h->d_rdesc, &h->rdesc_cap_bytes, ((size_t)R + 1) * sizeof(clc::RowDesc) + clc::wave_split_bytes(R));
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(hipMemsetAsync(h->d_rxy + (size_t)R * clc::ROW_DOUBLES, 0, clc::ROW_DOUBLES * sizeof(double), h->stream));
+    CLC_HIP(hipMemsetAsync(reinterpret_cast<char*>(h->d_rdesc) + (size_t)R * sizeof(clc::RowDesc), 0, sizeof(clc::RowDesc), h->stream));
+    const long long slots = R * clc::ROW;
+    hipLaunchKernelGGL(clc::build_rows_kernel, dim3((unsigned)((slots + threads - 1) / threads)), dim3(threads), 0, h->stream, d_aos, d_starts,
+                       d_brbeg, (long long)G, R, (int)clc::ROW_DOUBLES, h->d_rxy, reinterpret_cast<clc::RowDesc*>(h->d_rdesc));
+    CLC_HIP(hipGetLastError());
+  }
+  {  // the 512-lane layout of the single-workgroup solve (build_resident for one problem, first_try = 512)
+    ResLayout& L = h->sres;
+    rc = ensure_bytes(&L.d_row, &L.row_cap, 2 * sizeof(unsigned int));
+    if (rc == CLC_OK) rc = ensure_bytes(&L.d_desc, &L.desc_cap, (size_t)512 * sizeof(clc::ResLane));
+    if (rc == CLC_OK) rc = ensure_bytes(&L.d_xy, &L.xy_cap, ((size_t)ppl + 1) * 512 * 2 * sizeof(double));
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(hipMemcpyAsync(L.d_row, d_row, 2 * sizeof(unsigned int), hipMemcpyDeviceToDevice, h->stream));
+    CLC_HIP(hipMemsetAsync(L.d_xy + (size_t)ppl * 512 * 2, 0, (size_t)512 * 2 * sizeof(double), h->stream));
+    hipLaunchKernelGGL((clc::res_build_kernel<512>), dim3(1), dim3(512), 0, h->stream, d_aos, d_off, d_gid, d_starts, n, (long long)G, d_row,
+                       reinterpret_cast<clc::ResLane*>(L.d_desc), L.d_xy, (double*)nullptr);
+    CLC_HIP(hipGetLastError());
+    L.lanes = 512; L.max_ppl = ppl; L.uni_ppl = ppl; L.rows = ppl; L.with_z = false; L.ok = true;
+  }
+  h->n_obs = (size_t)n;
+  h->n_groups = (long long)G;
+  h->compact_ok = !sparse;
+  h->n_rows = R;
+  h->rows_ok = rows_ok;
+  h->rows_z = false;
+  ++h->fast_small_uploads;
+  *used = true;
+  return CLC_OK;
+}
+
+// The scan structure of a selection of the stored scans, on the host: record k starts a scan when its (n, d, scale) differ bitwise from
+// record k - 1's (scan_flag_kernel's rule) — the records of one pose share the tag plane and the scale, its two board-edge records
+// carry the edge planes.  false: not known on the host (stored scans too large: clc_store_observations keeps no host copy).
+bool plan_selection_scans(const clc_handle* h, bool linefit, bool boundary, const std::vector<long long>& rec_off, std::vector<long long>* starts,
+                          bool* any_z) {
+  if (!h->store_small) return false;
+  const int P = h->store_poses;
+  const std::vector<long long>& off = linefit ? h->s_ptl_off : h->s_pts_off;
+  starts->clear();
+  unsigned long long prev[5] = {0, 0, 0, 0, 0};
+  bool have = false;
+  auto record = [&](long long k, const double* n3, double d, double scale) {
+    unsigned long long key[5];
+    std::memcpy(key, n3, 24); std::memcpy(key + 3, &d, 8); std::memcpy(key + 4, &scale, 8);
+    if (!have || std::memcmp(key, prev, sizeof(key)) != 0) starts->push_back(k);
+    std::memcpy(prev, key, sizeof(key));
+    have = true;
+  };
+  for (int i = 0; i < P; ++i) {
+    const long long cnt = off[(size_t)i + 1] - off[(size_t)i];
+    const bool edges = boundary && linefit;
+    if (cnt <= 0 && !edges) continue;
+    clc::host::PosePlanes pp;
+    clc::host::pose_planes(h->s_tag_q.data(), h->s_tag_t.data(), i, edges, pp);
+    const double scale = 1.0 / std::sqrt((double)cnt);  // :239-240
+    long long k = rec_off[(size_t)i];
+    if (cnt > 0) record(k, pp.n, pp.d, scale);
+    k += cnt;
+    if (edges) {
+      record(k, pp.pi1, pp.pi1[3], scale);
+      record(k + 1, pp.pi2, pp.pi2[3], scale);
+    }
+  }
+  starts->push_back(rec_off[(size_t)P]);
+  *any_z = (linefit ? h->s_any_z_ptl : h->s_any_z_pts) || (boundary && linefit && h->s_any_z_ends);
+  return true;
+}
+
+// ... and of an array of records on the host (clc_upload).
+void plan_record_scans(const clc_observation* rec, long long n, std::vector<long long>* starts, bool* any_z) {
+  starts->clear();
+  bool z = false;
+  for (long long k = 0; k < n; ++k) {
+    const clc_observation& a = rec[k];
+    bool nw = k == 0;
+    if (!nw) {
+      const clc_observation& b = rec[k - 1];
+      nw = std::memcmp(a.n, b.n, 32) != 0 || std::memcmp(&a.scale, &b.scale, 8) != 0;  // n[3], d are contiguous: 32 bytes
+    }
+    if (nw) starts->push_back(k);
+    z = z || a.p[2] != 0.0;
+  }
+  starts->push_back(n);
+  *any_z = z;
+}
+
 }  // namespace clc_abi
 
 extern "C" {
@@ -342,6 +544,13 @@ int clc_upload_device(clc_handle* h, const clc_observation* records_dev, size_t 
 int clc_upload(clc_handle* h, const clc_observation* records, size_t n) {
   if (!h || (n > 0 && !records)) return fail(CLC_ERR_INVALID_ARG, "clc_upload: bad argument");
   CLC_HIP(hipSetDevice(h->device));
+  if (n > 0 && n <= kSmallMaxRecords && h->fast_small) {  // a problem one workgroup holds: planned on the host, no read-backs
+    std::vector<long long> starts;
+    bool any_z = false, used = false;
+    plan_record_scans(records, (long long)n, &starts, &any_z);
+    const int rc = small_fast_upload(h, starts, (long long)n, any_z, records, nullptr, &used);
+    if (rc != CLC_OK || used) return rc;
+  }
   DevBuf<double> aos(&h->pool);
   if (n > 0) {
     CLC_HIP(aos.alloc(n * 8));
@@ -438,6 +647,18 @@ int clc_store_observations(clc_handle* h, int n_poses, const double* tag_q_wxyz,
   }
   if (M > 0) CLC_HIP(hipMemcpyAsync(h->d_spts, pts + 3 * pts_off[0], M * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (ML > 0) CLC_HIP(hipMemcpyAsync(h->d_sptl, ptl + 3 * ptl_off[0], ML * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // reference-size scans: the host keeps what it needs to plan a selection's layouts itself (tag poses, whether any z is non-zero)
+  h->store_small = P > 0 && P <= 4096 && M <= 16384 && ML <= 16384;
+  if (h->store_small) {
+    h->s_tag_q.assign(tag_q_wxyz, tag_q_wxyz + 4 * P);
+    h->s_tag_t.assign(tag_t, tag_t + 3 * P);
+    auto any_z = [](const double* p, size_t count) { for (size_t k = 0; k < count; ++k) if (p[3 * k + 2] != 0.0) return true; return false; };
+    h->s_any_z_pts = M > 0 && any_z(pts + 3 * pts_off[0], M);
+    h->s_any_z_ptl = ML > 0 && any_z(ptl + 3 * ptl_off[0], ML);
+    h->s_any_z_ends = false;
+    for (size_t i = 0; i < P; ++i)
+      if (pts_off[i + 1] > pts_off[i] && (pts[3 * pts_off[i] + 2] != 0.0 || pts[3 * (pts_off[i + 1] - 1) + 2] != 0.0)) h->s_any_z_ends = true;
+  }
   // points_on_line bit-identical to points (the simulation node's input): the selections (linefit, no boundary) and (no linefit) are
   // then the same records and clc_select_observations builds them once.  Checked for reference-size inputs only (a memcmp of <= 384 KB).
   h->store_lines_equal_points = M == ML && M <= 16384 && h->s_pts_off == h->s_ptl_off &&
@@ -464,6 +685,22 @@ int clc_select_observations(clc_handle* h, int use_linefitting_data, int use_bou
   if (key >= 0 && key == h->selection_key && cfg == h->selection_cfg) {
     if (n_records) *n_records = (int64_t)h->n_obs;
     return CLC_OK;
+  }
+  if (h->store_small && h->fast_small && h->store_poses > 0) {  // reference-size scans: planned on the host, enqueued without a read-back
+    std::vector<long long> rec_off, starts;
+    const int orc = selection_offsets(h, linefit, boundary, &rec_off);
+    bool any_z = false, used = false;
+    if (orc == CLC_OK && rec_off.back() > 0 && (size_t)rec_off.back() <= kSmallMaxRecords &&
+        plan_selection_scans(h, linefit, boundary, rec_off, &starts, &any_z)) {
+      const SmallFlatten fj = {h->store_poses, linefit, boundary, &rec_off};
+      const int frc = small_fast_upload(h, starts, rec_off.back(), any_z, nullptr, &fj, &used);
+      if (frc != CLC_OK) return frc;
+      if (used) {
+        if (n_records) *n_records = (int64_t)rec_off.back();
+        h->selection_key = key; h->selection_cfg = cfg;
+        return CLC_OK;
+      }
+    }
   }
   DevBuf<double> aos(&h->pool);
   long long N = 0;

@@ -164,6 +164,17 @@ struct clc_handle {
   std::vector<long long> s_pts_off, s_ptl_off;
   int store_poses = -1;                          // -1: nothing stored
   int64_t store_generation = 0;                  // bumped by every successful clc_store_observations (clc_store_generation)
+  // host-side knowledge of reference-size stored scans (<= 16 384 points, <= 4 096 poses): what lets clc_select_observations plan the
+  // layouts of the selection on the host and enqueue their construction without a single read-back (abi_layouts.hip, small_fast_upload)
+  bool store_small = false;
+  std::vector<double> s_tag_q, s_tag_t;          // tag poses (w, x, y, z) / t of the stored scans
+  bool s_any_z_pts = false, s_any_z_ptl = false, s_any_z_ends = false;  // some p.z != 0 in points / points_on_line / the first + last point of a scan
+  // staging of the small-problem upload path: ONE pinned block + its device twin per handle; `ev_stage` marks the last copy out of it
+  char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_cap = 0;
+  hipEvent_t ev_stage = nullptr; bool stage_busy = false;
+  double* d_small_aos = nullptr; size_t small_aos_cap = 0;  // the records of a small problem (never a pool block: kernels may still read it after the call returned)
+  bool fast_small = true;                        // (hooks build: clc_debug_fast_small switches the path off for the A/B tests)
+  long long fast_small_uploads = 0;
   bool store_lines_equal_points = false;         // points_on_line is bit for bit points (reference-size inputs only: see clc_store_observations)
   long long selection_key = -1;                  // the (stored scans, selection) the observation array was built from by clc_select_observations; -1: none
   long long selection_cfg = -1;                  // ... under these upload-time settings (launch flags, auto paths)

@@ -28,6 +28,36 @@ inline void pi_from_ppp(const double* x1, const double* x2, const double* x3, do
   pi[3] = -((x3[0] * c12[0] + x3[1] * c12[1]) + x3[2] * c12[2]);
 }
 
+// The planes of one board pose as the assembly loop forms them (src/LaseCamCalCeres.cpp:227-231, :258-276): the tag plane (z_tag = 0) in
+// the camera frame, (Tctag^-1)^T (0,0,1,0) = [R_ca e3 ; -(R_ca e3).t_ca], and — for the board-edge terms — the two planes through the
+// camera centre and a board edge (pi_from_ppp).  One definition for the host flatten below, the device flatten's host twin
+// (clc_flatten_observations) and the host-side scan plan of small problems (abi_layouts.hip).
+struct PosePlanes {
+  double n[3], d;      // tag plane
+  double pi1[4], pi2[4];  // edge planes (valid when asked for)
+};
+inline void pose_planes(const double* tag_q_wxyz, const double* tag_t, int i, bool edges, PosePlanes& out) {
+  const double q[4] = {tag_q_wxyz[4 * i + 1], tag_q_wxyz[4 * i + 2], tag_q_wxyz[4 * i + 3], tag_q_wxyz[4 * i]};
+  double R[9];
+  quat_to_rot(q, R);
+  const double* t = tag_t + 3 * i;
+  out.n[0] = R[2]; out.n[1] = R[5]; out.n[2] = R[8];
+  out.d = -((out.n[0] * t[0] + out.n[1] * t[1]) + out.n[2] * t[2]);
+  if (edges) {  // :258-276
+    const double orig = 0.0265 + 0.0165;                              // :262
+    const double pm[3][3] = {{0.0 - orig, 0.0 - orig, 0.0},            // :263-268
+                             {0.5 - orig, 0.0 - orig, 0.0},
+                             {0.0 - orig, 0.5 - orig, 0.0}};
+    double pc[3][3];
+    for (int k = 0; k < 3; ++k)
+      for (int a = 0; a < 3; ++a)  // :270-272
+        pc[k][a] = ((R[3 * a] * pm[k][0] + R[3 * a + 1] * pm[k][1]) + R[3 * a + 2] * pm[k][2]) + t[a];
+    const double zero[3] = {0.0, 0.0, 0.0};
+    pi_from_ppp(pc[0], pc[1], zero, out.pi1);  // :275
+    pi_from_ppp(pc[0], pc[2], zero, out.pi2);  // :276
+  }
+}
+
 // Residual-block construction of CamLaserCalibration, src/LaseCamCalCeres.cpp:222-295.
 // Returns CLC_OK / CLC_ERR_EMPTY_SCAN; *n_out = number of records.
 inline int flatten(int n_poses, const double* tag_q, const double* tag_t, const int64_t* pts_off,
@@ -35,14 +65,10 @@ inline int flatten(int n_poses, const double* tag_q, const double* tag_t, const 
                    bool boundary, clc_observation* rec, int64_t* n_out) {
   int64_t N = 0;
   for (int i = 0; i < n_poses; ++i) {
-    // plane of the tag (z_tag = 0) in the camera frame: (Tctag^-1)^T (0,0,1,0) (:227-231)
-    //   = [R_ca e3 ; -(R_ca e3).t_ca]
-    const double q[4] = {tag_q[4 * i + 1], tag_q[4 * i + 2], tag_q[4 * i + 3], tag_q[4 * i]};
-    double R[9];
-    quat_to_rot(q, R);
-    const double* t = tag_t + 3 * i;
-    const double n[3] = {R[2], R[5], R[8]};
-    const double d = -((n[0] * t[0] + n[1] * t[1]) + n[2] * t[2]);
+    PosePlanes pp;
+    pose_planes(tag_q, tag_t, i, boundary && linefit, pp);
+    const double* n = pp.n;
+    const double d = pp.d;
     const int64_t* off = linefit ? ptl_off : pts_off;  // :233-237
     const double* P = linefit ? ptl : pts;
     const int64_t cnt = off[i + 1] - off[i];
@@ -56,18 +82,8 @@ inline int flatten(int n_poses, const double* tag_q, const double* tag_t, const 
     }
     if (boundary && linefit) {  // :258-294
       if (pts_off[i + 1] - pts_off[i] <= 0) return CLC_ERR_EMPTY_SCAN;  // .at(0) throws, :278
-      const double orig = 0.0265 + 0.0165;                              // :262
-      const double pm[3][3] = {{0.0 - orig, 0.0 - orig, 0.0},            // :263-268
-                               {0.5 - orig, 0.0 - orig, 0.0},
-                               {0.0 - orig, 0.5 - orig, 0.0}};
-      double pc[3][3];
-      for (int k = 0; k < 3; ++k)
-        for (int a = 0; a < 3; ++a)  // :270-272
-          pc[k][a] = ((R[3 * a] * pm[k][0] + R[3 * a + 1] * pm[k][1]) + R[3 * a + 2] * pm[k][2]) + t[a];
-      const double zero[3] = {0.0, 0.0, 0.0};
-      double pi1[4], pi2[4];
-      pi_from_ppp(pc[0], pc[1], zero, pi1);  // :275
-      pi_from_ppp(pc[0], pc[2], zero, pi2);  // :276
+      const double* pi1 = pp.pi1;
+      const double* pi2 = pp.pi2;
       if (rec) {
         const double* front = pts + 3 * pts_off[i];            // obi.points.at(0), :278
         const double* back = pts + 3 * (pts_off[i + 1] - 1);   // obi.points.at(size-1), :279

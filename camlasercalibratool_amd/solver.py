@@ -220,6 +220,12 @@ class Solver:
         """clc_set_small_on_coop (at upload): problems one workgroup holds also get the cooperative layout and run on 32 workgroups first."""
         check(self._L.clc_set_small_on_coop(self._h, C.c_int(int(enable))), "clc_set_small_on_coop")
 
+    def debug_fast_small(self, enable: Optional[bool] = None) -> int:
+        """Test hook: switch the host-planned upload of small problems on / off (None: leave it) -> uploads that took it so far."""
+        n = C.c_longlong()
+        check(self._hook("clc_debug_fast_small")(self._h, C.c_int(-1 if enable is None else int(enable)), C.byref(n)), "clc_debug_fast_small")
+        return n.value
+
     def debug_single_controller(self, cooperative_kernels: bool):
         """Test hook: the single-workgroup solve runs the cooperative kernel's register-state LM controller instead of its own."""
         check(self._hook("clc_debug_single_controller")(self._h, C.c_int(int(cooperative_kernels))), "clc_debug_single_controller")

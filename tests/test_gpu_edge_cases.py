@@ -383,3 +383,70 @@ def test_repeated_selection_is_built_once_and_forgotten_by_any_upload(sv):
     assert a == b and ca != cb
     assert sv.select_observations(True, True) == a + 2 * S2.n_poses
     assert sv.select_observations(False, True) == b and sv.eval(X0)[0] == cb   # (no board-edge terms without points_on_line, :258)
+
+
+def test_small_problems_planned_on_the_host_build_the_same_layouts_as_the_device_pipeline(sv, oracle_mod):
+    """Reference-size problems (<= 512 x 22 records, p.z == 0) are uploaded by a host-planned path: the host derives the scan structure
+    (from the stored scans' offsets and tag poses, or from the records), plans rows and points per lane, and enqueues the same build
+    kernels without a read-back.  Against the generic device pipeline (hook: clc_debug_fast_small off), on the shapes of the reference's
+    flows — every evaluation, closed form, analysis pass and solve must be BIT-IDENTICAL (same tables -> same layouts -> same sums):
+    C1 (ragged scans, some empty), the offline shape (two points per scan: sparse rows), board-edge terms, one scan, adjacent poses
+    with the SAME plane (merged into one scan by both), and what the path must refuse (z != 0, too many records) running generically."""
+    import copy
+    sv.set_launch(0, -1)
+    x_near = oracle_mod.pose_plus(sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC)), np.array([0.03, -0.02, 0.02, 0.03, -0.04, 0.02]))
+
+    def everything():
+        out = [sv.path_info().single_resident, sv.path_info().rows_layout, sv.path_info().n_rows, sv.num_observations]
+        for x in (X0, x_near):
+            c, g, H = sv.eval(x)
+            out += [c, g.tobytes(), H.tobytes()]
+            c2, _, _ = sv.eval(x, with_loss=False)
+            out.append(c2)
+        T, un, sv9 = sv.closed_form()
+        out += [T.tobytes(), un, sv9.tobytes()]
+        r = sv.solve(x_near)
+        out += [r.pose.tobytes(), r.summary.final_cost, r.summary.num_iterations, r.summary.termination, len(r.trace)]
+        Hm, b, chi2, svals, V, nn = sv.information(r.pose)
+        out += [Hm.tobytes(), b.tobytes(), chi2, nn]
+        return out
+
+    S_c1 = sd.GenerateSimData(0, n_poses=50, noise_sigma=0.01)
+    S_edges = sd.sim_board_edges(5, 40, 60, noise_sigma=0.002)
+    S_edges.ptl = S_edges.ptl[::-1].copy()
+    S_same = sd.sim_fixed_count(4, 6, 50, noise_sigma=0.01)      # poses 2 and 3 get the same tag pose: one scan of 100 records
+    S_same = copy.deepcopy(S_same); S_same.tag_q[3] = S_same.tag_q[2]; S_same.tag_t[3] = S_same.tag_t[2]
+    S_one = sd.sim_fixed_count(6, 1, 300, noise_sigma=0.01)
+    S_line = clc.points_on_fitted_lines(sd.GenerateSimData(2, n_poses=100, noise_sigma=0.01), sv) if hasattr(clc, "points_on_fitted_lines") else None
+    if S_line is None:
+        from camlasercalibratool_amd import calib
+        S_line = calib.points_on_fitted_lines(sd.GenerateSimData(2, n_poses=100, noise_sigma=0.01), sv)
+    cases = [(S_c1, [(False, False), (True, False)]), (S_edges, [(True, False), (True, True), (False, False)]), (S_same, [(False, False)]),
+             (S_one, [(False, False)]), (S_line, [(True, False)])]
+    n0 = sv.debug_fast_small(True)
+    taken = 0
+    for S, sels in cases:
+        for lf, bd in sels:
+            res = {}
+            for fast in (True, False):
+                sv.debug_fast_small(fast)
+                sv.store_observations(S)
+                n = sv.select_observations(lf, bd)
+                res[("select", fast)] = everything()
+                sv.upload(clc.flatten_observations(S, lf, bd))   # the same records through clc_upload
+                res[("upload", fast)] = everything()
+                assert n == sv.num_observations
+            taken += 2
+            assert res[("select", True)] == res[("select", False)], (lf, bd)
+            assert res[("upload", True)] == res[("upload", False)], (lf, bd)
+            assert res[("select", True)] == res[("upload", True)], (lf, bd)
+    assert sv.debug_fast_small(True) - n0 == taken   # every fast-mode upload above really took the host-planned path
+    # refused: points off the lidar plane, and more records than one workgroup holds -> the generic pipeline, same answers as ever
+    n1 = sv.debug_fast_small()
+    Sz = copy.deepcopy(S_c1); Sz.pts[::7, 2] = 0.01
+    sv.store_observations(Sz)
+    sv.select_observations(False, False)
+    assert sv.path_info().rows_layout == 2
+    big = clc.flatten_observations(sd.sim_fixed_count(8, 30, 500, noise_sigma=0.01), False)
+    sv.upload(big)
+    assert sv.path_info().single_resident == 0 and sv.debug_fast_small() == n1
