@@ -93,7 +93,12 @@ class Session:
         n_rec = sv.select_observations(use_linefitting_data, use_boundary_constraint)
         pose0 = simdata.pose7_from_T(np.asarray(Tcl, dtype=np.float64))  # :215-219
         res = sv.solve(pose0, options)
-        if verbose:  # stands in for summary.FullReport(), :309
+        if verbose:  # stands in for summary.FullReport(), :309: the per-iteration table, then the totals
+            print("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  step")
+            for it in res.trace:
+                print(f"{it.iteration:4d}  {it.cost:.6e}  {it.cost_change:9.2e}  {it.gradient_max_norm:9.2e}  {it.step_norm:9.2e}  "
+                      f"{it.relative_decrease:9.2e}  {it.trust_region_radius:9.2e}  "
+                      f"{'invalid' if not it.step_is_valid else ('accepted' if it.step_is_successful else 'rejected')}")
             s = res.summary
             print(f"Solver Summary: iterations {s.num_iterations} (successful {s.num_successful_steps - 1}, "
                   f"unsuccessful {s.num_unsuccessful_steps}), initial cost {s.initial_cost:.6e}, "
@@ -150,24 +155,22 @@ def points_on_fitted_lines(obs_set: ObservationSet, solver: Optional[Solver] = N
     lines, _ = sv.line_fit_batched(obs_set.pts[:, :2], obs_set.pts_off, np.tile(np.asarray(line0, dtype=np.float64), (S, 1)),
                                    want_summaries=False)
 
+    # the two end points per scan, all scans at once (the per-scan arithmetic of :126-136, element for element)
+    lo, hi = obs_set.pts_off[:-1], obs_set.pts_off[1:]
+    keep = hi - lo >= 2
+    first = np.where(keep, lo, 0)
+    last = np.where(keep, hi - 1, 0)
+    P = obs_set.pts if obs_set.pts.shape[0] else np.zeros((1, 3))
+    xs, ys, xe, ye = P[first, 0].copy(), P[first, 1].copy(), P[last, 0].copy(), P[last, 1].copy()
+    m0, m1 = lines[:, 0], lines[:, 1]
+    horiz = np.abs(xe - xs) > np.abs(ye - ys)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ys = np.where(horiz, -(xs * m0 + 1) / m1, ys)   # :126-131
+        ye = np.where(horiz, -(xe * m0 + 1) / m1, ye)
+        xs = np.where(horiz, xs, -(ys * m1 + 1) / m0)   # :132-136
+        xe = np.where(horiz, xe, -(ye * m1 + 1) / m0)
     ptl = np.zeros((2 * S, 3))
-    keep = np.ones(S, dtype=bool)
-    for i in range(S):
-        lo, hi = obs_set.pts_off[i], obs_set.pts_off[i + 1]
-        if hi - lo < 2:
-            keep[i] = False
-            continue
-        xs, ys = obs_set.pts[lo, 0], obs_set.pts[lo, 1]
-        xe, ye = obs_set.pts[hi - 1, 0], obs_set.pts[hi - 1, 1]
-        m0, m1 = lines[i]
-        if abs(xe - xs) > abs(ye - ys):   # :126-131
-            ys = -(xs * m0 + 1) / m1
-            ye = -(xe * m0 + 1) / m1
-        else:                             # :132-136
-            xs = -(ys * m1 + 1) / m0
-            xe = -(ye * m1 + 1) / m0
-        ptl[2 * i] = (xs, ys, 0.0)
-        ptl[2 * i + 1] = (xe, ye, 0.0)
+    ptl[0::2, 0], ptl[0::2, 1], ptl[1::2, 0], ptl[1::2, 1] = xs, ys, xe, ye
     ptl_off = np.zeros(S + 1, dtype=np.int64)
     ptl_off[1:] = np.cumsum(np.where(keep, 2, 0))
     ptl = ptl[np.repeat(keep, 2)]

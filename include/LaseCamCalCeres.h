@@ -26,6 +26,7 @@
 #include <Eigen/Geometry>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -280,13 +281,26 @@ class Session {
         pose[0] = Tcl(0, 3); pose[1] = Tcl(1, 3); pose[2] = Tcl(2, 3);    // :219
         clc_options opt; clc_options_default(&opt);                       // DENSE_QR-equivalent, 100 iterations, :302-304
         clc_summary sum;
-        if (clc_solve(H.h, &opt, pose, &sum, NULL, 0) != CLC_OK) {
+        std::vector<clc_iteration> trace((size_t)opt.max_num_iterations + 2);  // the per-iteration table of summary.FullReport(), :309
+        if (clc_solve(H.h, &opt, pose, &sum, trace.data(), (int)trace.size()) != CLC_OK) {
             std::cerr << "[clc] " << clc_last_error() << std::endl;
             ok_ = false;
             return;
         }
         static const char* term[] = {"RUNNING", "CONVERGENCE (gradient)", "CONVERGENCE (parameter)", "CONVERGENCE (function)",
                                      "CONVERGENCE (radius)", "NO_CONVERGENCE", "FAILURE"};
+        {   // stands in for the iteration table of ceres::Solver::Summary::FullReport() (:309): one line per LM iteration
+            const int n_it = std::min<int>(sum.num_iterations + 1, (int)trace.size());
+            std::cout << "iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  step\n";
+            char line[160];
+            for (int i = 0; i < n_it; ++i) {
+                const clc_iteration& it = trace[(size_t)i];
+                std::snprintf(line, sizeof(line), "%4d  %.6e  %9.2e  %9.2e  %9.2e  %9.2e  %9.2e  %s\n", it.iteration, it.cost, it.cost_change,
+                              it.gradient_max_norm, it.step_norm, it.relative_decrease, it.trust_region_radius,
+                              !it.step_is_valid ? "invalid" : (it.step_is_successful ? "accepted" : "rejected"));
+                std::cout << line;
+            }
+        }
         std::cout << "Solver Summary (MI355X HIP backend)\n  Residuals            " << n_rec
                   << "\n  Initial cost         " << sum.initial_cost << "\n  Final cost           " << sum.final_cost
                   << "\n  Iterations           " << sum.num_iterations << " (successful " << sum.num_successful_steps - 1
