@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The five configurations of BASELINE.json on one MI355X, one line each: solve time (observations resident), passes,
-evals/s, parity against the oracle (T_cl, final cost, iteration count) — profiles/r02_configs.json (round 3: CLC_CONFIGS_OUT=r03_configs.json ->
-profiles/r03_configs.json)."""
+evals/s, parity against the oracle (T_cl, final cost, iteration count) — gpurun_out/<CLC_CONFIGS_OUT, default r06_configs.json> (copied to
+profiles/)."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -62,4 +62,4 @@ for name, P in (("C3 batch of 1024 problems x 1e4 observations", 1024), ("C4 sha
     out.append(line)
     print(json.dumps(line), flush=True)
     del rec
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", os.environ.get("CLC_CONFIGS_OUT", "r02_configs.json")), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", os.environ.get("CLC_CONFIGS_OUT", "r06_configs.json")), "w"), indent=1)

@@ -114,6 +114,14 @@ if ab:
         w = [r["per_pass_us"] for r in ab1 if r["flags"] == 438]
         e = [r["per_pass_us"] for r in ab1 if r["flags"] == -1]
         L.append(f"| 3:2 old/young wave shares instead of equal, scan-aligned shares (`clc_set_launch` 438) | {' / '.join(f'{x:.1f}' for x in w)} against {' / '.join(f'{x:.1f}' for x in e)} | {frac(st.mean(w)):.3f} vs {frac(st.mean(e)):.3f} | the evaluation kernel alone prefers 3:2 at this size, the step kernel does not |")
+    ff = jl(os.path.join(g, "keep", "large_fewer_flushes.log"))
+    if ff:
+        a = [r["solve_per_pass_us"] for r in ff if r["lib"] == "fewer_flushes"]
+        b = [r["solve_per_pass_us"] for r in ff if r["lib"] == "base"]
+        L.append(f"| TIMING BUILD ONLY (wrong sums): the per-scan expansion (`rows_flush`, ~43 % of the FP64 instructions) skipped — the upper bound of what a streaming "
+                 f"lane layout with one expansion per 40 points could save | {' / '.join(f'{x:.1f}' for x in a)} against {' / '.join(f'{x:.1f}' for x in b)} | "
+                 f"{frac(st.mean(a)):.3f} vs {frac(st.mean(b)):.3f} | -6 % per pass at most (~1 point of it from amortising the 3 no-op launches over 101 instead of 14 passes): "
+                 "a new streaming layout would end near 0.73-0.74 on this box — not built |")
     L += ["", "Every attempt to overlap the serial front with HBM traffic made the pass slower, and the evaluation kernel alone runs 5 % faster without the loss arithmetic on one box "
           "(85.9 vs 90.4 us) and 1.4 % on another: in this regime the part is power-managed (the shader clock moves between 1.96 and 2.24 GHz with the duty cycle of the load), "
           "so time follows energy per pass rather than the critical path.  What would lower the energy — fewer bytes (keeping a share of the rows on chip across passes in a "
