@@ -72,7 +72,7 @@ L = ["# The default-path `clc_solve` of ONE problem beyond the chip (SURVEY.md Â
      f"| SQ_INSTS_VALU | {pmc.get('SQ_INSTS_VALU', 0) / 1e6:.2f} M wave-instructions = {pmc.get('SQ_INSTS_VALU', 0) * 64 / probe['observations']:.1f} lane-instructions per observation | VALU issue {pmc.get('SQ_INSTS_VALU', 0) * 64 / (kd * 1e-6) / 3.93216e13:.2f} of the chip's FP64 issue peak NEXT TO 0.75 of the HBM peak: a balanced kernel, which is why it runs power-managed |",
      f"| SQ_WAIT_ANY / SQ_WAVE_CYCLES | {pmc.get('SQ_WAIT_ANY', 0) / max(pmc.get('SQ_WAVE_CYCLES', 1), 1):.2f} | waves parked on memory: a bandwidth kernel |", ""]
 for name, title in (("large_probe.log", "## `scripts/large_solve_probe.py` (no profiler; 4e6 = cache-resident, 3.2e7 = HBM)"),):
-    d = jl(os.path.join(g, "keep", name))
+    d = jl(os.path.join(root, "profiles", "r06_large_solve_logs", name))
     if d:
         L += [title, "", "| observations | rows MB | passes | solve ms (first 7) | per pass us | frac | sustained per pass us | frac sustained | step period us (events) | eval kernel alone us | frac | oracle | dT | dcost | iterations GPU / oracle |",
               "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
@@ -82,7 +82,7 @@ for name, title in (("large_probe.log", "## `scripts/large_solve_probe.py` (no p
                      f"**{r['frac_moved_whole_solve_sustained']:.3f}** | {r['step_period_us']:.1f} | {r['eval_alone_us_median']:.1f} | {r['frac_moved_eval_alone']:.3f} | {r['oracle']} | {r['dT']:.1e} | {r['dcost']:.1e} | "
                      f"{r['iterations']} / {r['iterations_oracle']} |")
         L.append("")
-stamps = os.path.join(g, "keep", "large_stamps.log")
+stamps = os.path.join(root, "profiles", "r06_large_solve_logs", "large_stamps.log")
 if os.path.exists(stamps):
     L += ["## Where a steady-state launch spends its time: `-DCLC_STAMPS` build, 100 MHz wall-clock stamps of all 256 workgroups (`scripts/stamps_step.py 64000 500`)", "",
           "(us; the stamps themselves cost a few percent: total 100 us against 96-97 unstamped on the same box)", "", "```"]
@@ -94,7 +94,7 @@ if os.path.exists(stamps):
           "finish ~10 us later: the workgroup streams for ~88 us = the evaluation kernel alone, 85.7-86.6), butterfly + row store 1.0.  "
           "**Sum: 3.9 + 6.0 in front of 88 + 1 of streaming and reduction.**  The 8 rows per wave issued before the barrier (16 MB in all) arrive during the controller: "
           "without them the front would cost 2.6 us more.", ""]
-ab = jl(os.path.join(g, "keep", "large_la.log"))
+ab = jl(os.path.join(root, "profiles", "r06_large_solve_logs", "large_la.log"))
 if ab:
     L += ["## What was tried to close the ~10 us between the pass and the evaluation kernel alone (all measured, none kept)", "",
           "| variant | per pass us (same box, sustained) | frac | finding |", "|---|---|---|---|"]
@@ -103,18 +103,18 @@ if ab:
         v = [r["per_pass_us"] for r in las[2 * i:2 * i + 2]]
         L.append(f"| launch-ahead depth {la} (`CLC_LAUNCH_AHEAD`){' = default' if la == 2 else ''} | {' / '.join(f'{x:.1f}' for x in v)} | {frac(st.mean(v)):.3f} | "
                  + ("" if la != 8 else "the gap between launches shrinks 3.9 -> 1.3 us (stamps) but the shader clock under the now gap-free load drops 2.24 -> 1.96 GHz and the streaming phase grows by more: slower in all") + " |")
-    ab3 = [r for r in jl(os.path.join(g, "keep", "large_ab3.log")) if "lib" in r]
+    ab3 = [r for r in jl(os.path.join(root, "profiles", "r06_large_solve_logs", "large_ab3.log")) if "lib" in r]
     if ab3:
         a = [r["per_pass_us"] for r in ab3 if "hooks" in r["lib"]]
         b = [r["per_pass_us"] for r in ab3 if "variants" in r["lib"]]
         L.append(f"| 8 more rows per wave prefetched by LDS-DMA (`global_load_lds_dwordx4`, 64 KB per workgroup) before the controller's barrier, consumed first | {' / '.join(f'{x:.1f}' for x in a)} "
                  f"against {' / '.join(f'{x:.1f}' for x in b)} without, alternating in one process | {frac(st.mean(a)):.3f} vs {frac(st.mean(b)):.3f} | 3 % SLOWER with 32 MB in flight during the front instead of 16 MB; bit-identical results; removed |")
-    ab1 = [r for r in jl(os.path.join(g, "keep", "large_ab.log")) if "flags" in r]
+    ab1 = [r for r in jl(os.path.join(root, "profiles", "r06_large_solve_logs", "large_ab.log")) if "flags" in r]
     if ab1:
         w = [r["per_pass_us"] for r in ab1 if r["flags"] == 438]
         e = [r["per_pass_us"] for r in ab1 if r["flags"] == -1]
         L.append(f"| 3:2 old/young wave shares instead of equal, scan-aligned shares (`clc_set_launch` 438) | {' / '.join(f'{x:.1f}' for x in w)} against {' / '.join(f'{x:.1f}' for x in e)} | {frac(st.mean(w)):.3f} vs {frac(st.mean(e)):.3f} | the evaluation kernel alone prefers 3:2 at this size, the step kernel does not |")
-    ff = jl(os.path.join(g, "keep", "large_fewer_flushes.log"))
+    ff = jl(os.path.join(root, "profiles", "r06_large_solve_logs", "large_fewer_flushes.log"))
     if ff:
         a = [r["solve_per_pass_us"] for r in ff if r["lib"] == "fewer_flushes"]
         b = [r["solve_per_pass_us"] for r in ff if r["lib"] == "base"]
