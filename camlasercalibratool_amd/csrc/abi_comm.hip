@@ -528,6 +528,8 @@ int clc_solve_batched_gather_pipelined(clc_comm* c, const clc_options* opt_in, c
   if (!c || cap_per_rank == 0 || first_global_index < 0 || !prev_records)
     return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched_gather_pipelined: bad argument");
   clc_handle* h = c->h;
+  if (c->fl.active && cap_per_rank > c->cap)  // (growing the buffers would free the twin whose records this call hands back)
+    return fail(CLC_ERR_INVALID_ARG, "clc_solve_batched_gather_pipelined: cap_per_rank grew while a step is in flight (clc_gather_flush first)");
   clc_options opt;
   if (opt_in) opt = *opt_in; else clc_options_default(&opt);
   *prev_records = nullptr;
