@@ -1069,6 +1069,32 @@ def test_pipelined_steps_return_the_previous_step_and_leave_it_untouched():
                 c.close()
 
 
+def test_a_rank_with_an_empty_shard_still_takes_part_in_every_gather_form():
+    """13 problems over 8 ranks leave some ranks one problem, and a job of fewer problems than ranks leaves some NONE: such a rank enters the
+    collective with padding records only — the plain call, the pipelined calls and the flush — and reports zero problems (layout-only
+    communicator, rank 2 of 3, capacity 4)."""
+    from camlasercalibratool_amd.solver import Comm
+
+    cap = 4
+    with clc.Solver(0, library="hooks") as s0:
+        s0.upload_batched(np.zeros((0, 8)), np.array([0], dtype=np.int64))   # this rank's shard: no problems
+        assert s0.num_problems == 0
+        c = Comm(s0, None, 2, 3)
+        try:
+            g, st = c.solve_gather(None, 8, cap)
+            assert st.problems == 0 and st.evaluations == 0
+            r0, _ = c.solve_gather_pipelined(None, 8, cap)
+            r1, st1 = c.solve_gather_pipelined(None, 8, cap)
+            r2, st2 = c.flush(cap)
+            assert r0 is None and st1.problems == 0 and st2.problems == 0
+            for rec_ in (g, r1, r2):
+                assert rec_.shape == (3 * cap, 12)
+                mine = rec_[2 * cap:]
+                assert np.all(mine[:, 11] == -1) and np.all(mine[:, :11] == 0)
+        finally:
+            c.close()
+
+
 def test_c4_full_size_shard(sv, oracle_mod):
     """configs[3], one GPU's share at full size: 8 192 independent T_cl problems x 10^4 observations (5.2 GB of
     records), solved by clc_solve_batched and gathered through RCCL.  Size-independent properties on ALL problems

@@ -328,3 +328,26 @@ def test_multistart_on_a_problem_beyond_one_workgroup_runs_the_starts_in_turn(or
         ref = oracle_mod.solve(rec, starts[k], linear_solver="qr")
         assert sms[k].num_iterations == ref.summary.num_iterations
         assert np.abs(sd.T_from_pose7(poses[k]) - sd.T_from_pose7(ref.pose)).max() <= 1e-6 and abs(sms[k].final_cost - ref.summary.final_cost) <= 1e-8
+
+
+def test_multistart_with_points_off_the_lidar_plane_and_timed(oracle_mod):
+    """The shared problem's points carry z (the 512-lane, 24-byte-slot form of the resident kernel): clc_solve_multistart on it, against the
+    oracle from every start; profile_events = 1 reports the one launch's duration in every summary."""
+    rng = np.random.default_rng(4)
+    rec = clc.flatten_observations(sd.sim_fixed_count(12, 18, 400, noise_sigma=0.01), False)
+    rec[:, 6] = rng.normal(size=rec.shape[0]) * 0.01
+    x_true = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    S = 9
+    with clc.Solver(0) as s:
+        starts = s.pose_plus(np.tile(x_true, (S, 1)), rng.normal(size=(S, 6)) * 0.03)
+        s.upload_batched(rec, np.array([0, rec.shape[0]], dtype=np.int64))
+        pi = s.path_info()
+        assert pi.batched_resident == 1 and pi.batched_points_carry_z == 1 and pi.batched_lanes == 512
+        o = clc.default_options()
+        o.profile_events = 1
+        poses, sms = s.solve_multistart(starts, o)
+    for k in range(S):
+        ref = oracle_mod.solve(rec, starts[k], linear_solver="qr")
+        assert sms[k].num_iterations == ref.summary.num_iterations and sms[k].termination == ref.summary.termination
+        assert np.abs(sd.T_from_pose7(poses[k]) - sd.T_from_pose7(ref.pose)).max() <= 1e-6 and abs(sms[k].final_cost - ref.summary.final_cost) <= 1e-8
+        assert sms[k].eval_kernel_launches == 1 and sms[k].eval_kernel_ms > 0
