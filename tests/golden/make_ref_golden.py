@@ -81,7 +81,13 @@ for kind in ("parallel_boards", "only_pitch"):
 for gen, seed, noise, lf, bd, init in [("GenerateSimData", 0, 0.0, False, False, "identity"), ("GenerateSimData", 1, 0.01, False, False, "identity"),
                                        ("GenerateSimData", 2, 0.03, False, False, "identity"), ("GenerateSimData", 3, 0.01, True, False, "identity"),
                                        ("GenerateSimData", 5, 0.01, False, False, "closed_form"), ("sim_board_edges", 11, 0.002, True, True, "near_gt"),
-                                       ("sim_fixed_count", 21, 0.01, False, False, "identity")]:
+                                       ("sim_fixed_count", 21, 0.01, False, False, "identity"),
+                                       # round 6: more of the reference's own function on the flag combinations / starts of its two programs
+                                       ("GenerateSimData", 4, 0.01, True, False, "closed_form"), ("GenerateSimData", 6, 0.0, True, False, "identity"),
+                                       ("GenerateSimData", 7, 0.03, True, False, "closed_form"), ("GenerateSimData", 8, 0.01, False, False, "closed_form"),
+                                       ("GenerateSimData", 9, 0.02, False, False, "identity"), ("sim_board_edges", 12, 0.002, True, True, "near_gt"),
+                                       ("sim_board_edges", 13, 0.005, True, False, "near_gt"), ("sim_board_edges", 14, 0.0, True, True, "near_gt"),
+                                       ("sim_fixed_count", 22, 0.02, False, False, "closed_form"), ("sim_fixed_count", 23, 0.0, True, False, "identity")]:
     if gen == "GenerateSimData":
         S = sd.GenerateSimData(seed, noise_sigma=noise)
     elif gen == "sim_board_edges":
