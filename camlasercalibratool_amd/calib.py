@@ -121,6 +121,24 @@ class Session:
         return CalibrationReport(res, H, b, chi2, svals, null)
 
 
+def CamLaserCalibrationFromStarts(obs: ObsLike, Tcls: np.ndarray, use_linefitting_data: bool = True, use_boundary_constraint: bool = False,
+                                  options: Optional[Options] = None, solver: Optional[Solver] = None):
+    """Multi-hypothesis refinement (mirror of clc_adapter::Session::CalibrationFromStarts): every Tcl of Tcls [S, 4, 4] refined on the SAME
+    observations by clc_solve_multistart — a workgroup per start on ONE copy of the data.  Tcls is overwritten with the refined matrices;
+    -> (index of the lowest final cost, final costs [S], summaries)."""
+    S = _as_set(obs)
+    sv = solver or _shared_solver()
+    rec = flatten_observations(S, use_linefitting_data, use_boundary_constraint)
+    sv.upload_batched(rec, np.array([0, rec.shape[0]], dtype=np.int64))
+    T = np.asarray(Tcls, dtype=np.float64).reshape(-1, 4, 4)
+    poses, sms = sv.solve_multistart(np.stack([simdata.pose7_from_T(t) for t in T]), options)
+    for k in range(T.shape[0]):
+        T[k] = simdata.T_from_pose7(poses[k])
+    np.asarray(Tcls)[...] = T.reshape(np.asarray(Tcls).shape)
+    costs = np.array([s.final_cost for s in sms])
+    return int(np.argmin(costs)), costs, sms
+
+
 def CamLaserCalClosedSolution(obs: ObsLike, Tlc: np.ndarray, solver: Optional[Solver] = None, verbose: bool = True):
     """Closed-form initialiser; overwrites Tlc (camera->laser) like LaseCamCalCeres.cpp:198-200."""
     return Session(obs, solver).CamLaserCalClosedSolution(Tlc, verbose)

@@ -345,6 +345,62 @@ class Session {
         ok_ = true;
     }
 
+    // Multi-hypothesis refinement (no counterpart in the reference, which refines ONE initial guess, main/calibr_offline.cpp:166-170): every
+    // Tcl of starts[0 .. n_starts) is refined on the SAME observations — one ceres::Solve per start in the reference's terms, :299-309 —
+    // by ONE launch (clc_solve_multistart: a workgroup per start on one copy of the data) when the problem fits a workgroup (the
+    // reference's sizes do), otherwise one start after the other.  starts[] are overwritten with the refined Tcl; final_costs (optional,
+    // n_starts doubles) receives each solve's final cost.  Returns the index of the lowest final cost, -1 when the call could not run.
+    int CalibrationFromStarts(Eigen::Matrix4d* starts, size_t n_starts, bool use_linefitting_data = true, bool use_boundary_constraint = false,
+                              double* final_costs = NULL)
+    {
+        Handle H;
+        ok_ = false;
+        if (!H.h || !starts || n_starts == 0) return -1;
+        const Flat f = flatten(*obs_);
+        const int P = (int)(f.pts_off.size() - 1);
+        int64_t n_rec = 0;
+        if (clc_flatten_observations(P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts, f.ptl_off.data(), f.ptl,
+                                     use_linefitting_data, use_boundary_constraint, NULL, &n_rec) != CLC_OK) {
+            std::cerr << "[clc] " << clc_last_error() << std::endl;
+            return -1;
+        }
+        std::vector<clc_observation> rec((size_t)n_rec);
+        clc_flatten_observations(P, f.tag_q.data(), f.tag_t.data(), f.pts_off.data(), f.pts, f.ptl_off.data(), f.ptl,
+                                 use_linefitting_data, use_boundary_constraint, rec.data(), &n_rec);
+        const int64_t off[2] = {0, n_rec};
+        std::vector<double> poses(7 * n_starts);
+        for (size_t k = 0; k < n_starts; ++k) {
+            double R[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = starts[k](i, j);
+            rot_to_quat_xyzw(R, &poses[7 * k + 3]);                                                     // :215
+            for (int i = 0; i < 3; ++i) poses[7 * k + i] = starts[k](i, 3);                             // :219
+        }
+        std::vector<clc_summary> sums(n_starts);
+        clc_options opt; clc_options_default(&opt);
+        if (clc_upload_batched(H.h, rec.data(), off, 1) != CLC_OK ||
+            clc_solve_multistart(H.h, &opt, n_starts, poses.data(), sums.data()) != CLC_OK) {
+            std::cerr << "[clc] " << clc_last_error() << std::endl;
+            return -1;
+        }
+        int best = 0;
+        for (size_t k = 0; k < n_starts; ++k) {
+            const double* q = &poses[7 * k];
+            const double x = q[3], y = q[4], z = q[5], w = q[6];                                        // write-back, :311-314
+            const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+            const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+            Eigen::Matrix4d& T = starts[k];
+            T(0, 0) = 1 - (tyy + tzz); T(0, 1) = txy - twz;       T(0, 2) = txz + twy;
+            T(1, 0) = txy + twz;       T(1, 1) = 1 - (txx + tzz); T(1, 2) = tyz - twx;
+            T(2, 0) = txz - twy;       T(2, 1) = tyz + twx;       T(2, 2) = 1 - (txx + tyy);
+            T(0, 3) = q[0]; T(1, 3) = q[1]; T(2, 3) = q[2];
+            T(3, 0) = 0; T(3, 1) = 0; T(3, 2) = 0; T(3, 3) = 1;
+            if (final_costs) final_costs[k] = sums[k].final_cost;
+            if (sums[k].final_cost < sums[(size_t)best].final_cost) best = (int)k;
+        }
+        ok_ = true;
+        return best;
+    }
+
  private:
     bool store(clc_handle* h)
     {

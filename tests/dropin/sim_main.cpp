@@ -141,8 +141,48 @@ static int replaced_flow() {
     return 0;
 }
 
+// Multi-hypothesis refinement through the drop-in header: 64 initial guesses around the identity (rotations up to ~0.5 rad about random
+// axes, translations up to 0.3 m) refined on the SAME simulated observations by ONE launch (clc_adapter::Session::CalibrationFromStarts);
+// the lowest final cost wins and recovers the ground truth; a start equal to the winner's start refined alone gives the same matrix.
+static int multistart_flow() {
+    std::vector<Oberserve> obs;
+    GenerateSimData(obs, 7u, 0.0, 50, 180);
+    clc_adapter::Session run(obs);
+    const size_t S = 64;
+    std::vector<Eigen::Matrix4d> T(S, Eigen::Matrix4d::Identity()), T0;
+    unsigned int lcg = 12345u;
+    for (size_t k = 1; k < S; ++k) {  // (start 0 = the identity, the simulation node's own start, :126-129)
+        double v[6];
+        for (int i = 0; i < 6; ++i) { lcg = lcg * 1664525u + 1013904223u; v[i] = ((double)(lcg >> 8) / 16777216.0 - 0.5); }
+        const double ax = v[0], ay = v[1], az = v[2], th = std::sqrt(ax * ax + ay * ay + az * az) + 1e-12, c = std::cos(th), s = std::sin(th);
+        const double ux = ax / th, uy = ay / th, uz = az / th;
+        Eigen::Matrix4d& M = T[k];
+        M(0, 0) = c + ux * ux * (1 - c);      M(0, 1) = ux * uy * (1 - c) - uz * s; M(0, 2) = ux * uz * (1 - c) + uy * s;
+        M(1, 0) = uy * ux * (1 - c) + uz * s; M(1, 1) = c + uy * uy * (1 - c);      M(1, 2) = uy * uz * (1 - c) - ux * s;
+        M(2, 0) = uz * ux * (1 - c) - uy * s; M(2, 1) = uz * uy * (1 - c) + ux * s; M(2, 2) = c + uz * uz * (1 - c);
+        M(0, 3) = 0.6 * v[3]; M(1, 3) = 0.6 * v[4]; M(2, 3) = 0.6 * v[5];
+    }
+    T0 = T;
+    std::vector<double> cost(S);
+    const int best = run.CalibrationFromStarts(T.data(), S, false, false, cost.data());
+    if (best < 0 || !run.ok()) { std::printf("MULTISTART failed\n"); return 1; }
+    Eigen::Matrix4d one = T0[(size_t)best];
+    run.CalibrationFromStarts(&one, 1, false, false, NULL);
+    double same = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) same = std::fmax(same, std::fabs(one(i, j) - T[(size_t)best](i, j)));
+    size_t reached = 0;
+    for (size_t k = 0; k < S; ++k) reached += cost[k] <= cost[(size_t)best] + 1e-12;
+    Eigen::Matrix4d Tlc = invert(T[(size_t)best]);
+    const double Rgt[3][3] = {{0, 0, 1}, {-1, 0, 0}, {0, -1, 0}}, tgt[3] = {0.1, 0.2, 0.3};
+    double eR = 0, et = 0;
+    for (int i = 0; i < 3; ++i) { et = std::fmax(et, std::fabs(Tlc(i, 3) - tgt[i])); for (int j = 0; j < 3; ++j) eR = std::fmax(eR, std::fabs(Tlc(i, j) - Rgt[i][j])); }
+    std::printf("MULTISTART best=%d cost=%.3e reached=%zu of %zu same=%.3e %.3e %.3e\n", best, cost[(size_t)best], reached, S, same, et, eR);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && std::string(argv[1]) == "replaced") return replaced_flow();
+    if (argc > 1 && std::string(argv[1]) == "multistart") return multistart_flow();
     if (argc > 1 && std::string(argv[1]) == "session")
         return session_flow(argc > 2 ? (size_t)std::atol(argv[2]) : 2000, argc > 3 ? (size_t)std::atol(argv[3]) : 900);
     const bool offline_flow = argc > 1 && std::string(argv[1]) == "offline";

@@ -81,3 +81,15 @@ def test_dropin_session_whose_scans_were_replaced_stores_them_again():
     m = re.search(r"REPLACED ok_a=(\d) ok_b=(\d) (\S+) (\S+)", p.stdout)
     assert m and m.group(1) == "1" and m.group(2) == "1", p.stdout[-600:]
     assert float(m.group(3)) < 1e-7 and float(m.group(4)) < 1e-7, p.stdout[-600:]
+
+
+@pytest.mark.gpu
+def test_dropin_multistart_refines_many_initial_guesses_in_one_launch():
+    """clc_adapter::Session::CalibrationFromStarts: 64 initial guesses on the same (noise-free) observations, ONE launch; the lowest final
+    cost recovers the simulation's ground truth, several starts reach it, and the winner's start refined alone gives the same matrix."""
+    p = subprocess.run([_build_exe(), "multistart"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    m = re.search(r"MULTISTART best=(\d+) cost=(\S+) reached=(\d+) of 64 same=(\S+) (\S+) (\S+)", p.stdout)
+    assert m, p.stdout[-600:]
+    assert float(m.group(2)) < 1e-12 and int(m.group(3)) >= 2 and float(m.group(4)) == 0.0
+    assert float(m.group(5)) < 1e-7 and float(m.group(6)) < 1e-7, p.stdout[-300:]

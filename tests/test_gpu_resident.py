@@ -351,3 +351,19 @@ def test_multistart_with_points_off_the_lidar_plane_and_timed(oracle_mod):
         assert sms[k].num_iterations == ref.summary.num_iterations and sms[k].termination == ref.summary.termination
         assert np.abs(sd.T_from_pose7(poses[k]) - sd.T_from_pose7(ref.pose)).max() <= 1e-6 and abs(sms[k].final_cost - ref.summary.final_cost) <= 1e-8
         assert sms[k].eval_kernel_launches == 1 and sms[k].eval_kernel_ms > 0
+
+
+def test_calibration_from_starts_mirror_picks_the_lowest_cost(oracle_mod):
+    """clc.CamLaserCalibrationFromStarts (the Python mirror of clc_adapter::Session::CalibrationFromStarts): 24 initial guesses on the
+    simulation node's observations, refined in place; the winner is the oracle's solve from the same start."""
+    S = sd.GenerateSimData(3, noise_sigma=0.01)
+    rng = np.random.default_rng(8)
+    x_true = sd.pose7_from_T(sd.tlc_to_tcl(sd.GT_RLC, sd.GT_TLC))
+    starts = np.stack([sd.T_from_pose7(oracle_mod.pose_plus(x_true, rng.normal(size=6) * 0.1)) for _ in range(24)])
+    T = starts.copy()
+    best, costs, sms = clc.CamLaserCalibrationFromStarts(S, T, False, False)
+    assert costs[best] == costs.min() and not np.array_equal(T, starts)
+    rec = clc.flatten_observations(S, False, False)
+    ref = oracle_mod.solve(rec, sd.pose7_from_T(starts[best]), linear_solver="qr")
+    assert np.abs(T[best] - sd.T_from_pose7(ref.pose)).max() <= 1e-6 and abs(costs[best] - ref.summary.final_cost) <= 1e-8
+    assert sms[best].num_iterations == ref.summary.num_iterations
