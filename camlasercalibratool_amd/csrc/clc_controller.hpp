@@ -87,7 +87,7 @@ __device__ __forceinline__ void lm_pub_pose(double* pub, const double* x) {  // 
 }
 __device__ __forceinline__ int lm_pub_status(const double* pub) { return reinterpret_cast<const int*>(pub + 12)[0]; }
 
-// Cycle stamps inside lm_advance_wave (debug build -DCLC_STAMPS, scripts/r02_stamps.py); nothing otherwise.
+// Cycle stamps inside lm_advance_wave (debug build -DCLC_STAMPS, scripts/stamps_step.py); nothing otherwise.
 #ifdef CLC_STAMPS
 #define CLC_CK() do { ck[nck++] = clock64(); } while (0)
 #else
@@ -98,7 +98,7 @@ __device__ __forceinline__ int lm_pub_status(const double* pub) { return reinter
 // lm_advance on a wavefront (the step kernel's controller)
 // ---------------------------------------------------------------------------------------
 // The serial controller (clc_lm.hpp, one lane, state in LDS) is a chain of dependent FP64 instructions and LDS round
-// trips: 7 300 cycles = 3.0 us of every step_kernel launch, in every workgroup (scripts/r02_stamps.py).  What the
+// trips: 7 300 cycles = 3.0 us of every step_kernel launch, in every workgroup (scripts/stamps_step.py).  What the
 // instructions cost when ONE wave runs them alone (scripts/probes/latency_probe.hip, cycles): dependent FMA 4-6, a
 // value through v_readlane into the next FMA 24-31, IEEE division 72-98, IEEE sqrt 108-146, dependent LDS read 72-93,
 // compare + select (or branch) 40-50.  So the controller here is written for a short critical path and few branches:

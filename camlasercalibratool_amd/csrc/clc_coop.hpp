@@ -133,7 +133,7 @@ __device__ __forceinline__ void coop_wait_until(const long long t) {
 }
 
 #ifdef CLC_STAMPS
-// Debug build only (scripts/r04_coop_stamps.py): shader-clock stamps of point wave 0 and the controller wave (row 0: they stamp disjoint
+// Debug build only (scripts/stamps_coop.py): shader-clock stamps of point wave 0 and the controller wave (row 0: they stamp disjoint
 // slots; point wave 3 in row 1) of workgroups 0, 7 (leaders), 8 and 255, per pass p < COOP_STAMP_PASSES at 12 p: 0 pass start, 1 pass done (partials in LDS), 2 row published, 3 (leaders) group rows
 // gathered, 4 group row published, 5 the 8 group rows arrived, 6 totals in LDS, 7 controller done (behind its barrier); inside the pass:
 // 8 pose + plane set up, 9 points done, 10 expansion done; 11 lmu_pre done.  Slot 12 * COOP_STAMP_PASSES: kernel entry, + 1: points in.

@@ -190,7 +190,7 @@ static_assert(sizeof(SolveParams) % 8 == 0 && offsetof(SolveBlock, st) == sizeof
 static_assert(LM_STATE_WORDS + PRM_WORDS <= 256, "one block word per thread");
 
 #ifdef CLC_STAMPS
-// Debug build only (scripts/r02_stamps.py): wall-clock (100 MHz) stamps of every workgroup of the first 64 launches.
+// Debug build only (scripts/stamps_step.py): wall-clock (100 MHz) stamps of every workgroup of the first 64 launches.
 constexpr int STAMP_LAUNCHES = 64, STAMP_WGS = 512, STAMP_SLOTS = 16;
 static __device__ unsigned long long clc_stamp_buf[STAMP_LAUNCHES][STAMP_WGS][STAMP_SLOTS];
 #define CLC_STAMP(slot, tid)                                                                                        \

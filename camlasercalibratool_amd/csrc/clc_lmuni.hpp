@@ -38,7 +38,7 @@
 namespace clc {
 
 #ifdef CLC_STAMPS
-// Debug build only (scripts/r04_coop_stamps.py): shader-clock stamps inside lmu_post of workgroup 8 (non-first passes; the last one wins).
+// Debug build only (scripts/stamps_coop.py): shader-clock stamps inside lmu_post of workgroup 8 (non-first passes; the last one wins).
 static __device__ long long clc_lmu_ck[16];
 #define LMU_CK(i) do { if (blockIdx.x == 8 && lane == 0 && !first) clc_lmu_ck[i] = clock64(); } while (0)
 #else

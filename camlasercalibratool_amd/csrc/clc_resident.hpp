@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NL) void res_build_kernel(const double* __restrict_
 }
 
 #ifdef CLC_STAMPS
-// Debug build only (scripts/r03_res_stamps.py): stamps of the first RES_STAMP_WGS problems' waves 0 and 1 —
+// Debug build only (scripts/stamps_resident.py): stamps of the first RES_STAMP_WGS problems' waves 0 and 1 —
 // slot 0: wall clock (100 MHz) at kernel entry, 1: wall clock at exit, 2: shader clock at entry, 3: after the loads landed;
 // then per pass p < RES_STAMP_PASSES at 4 + 6 p: shader clock at pass start, after the point loop, after the wave
 // reduction, after barrier 1, (wave 0) after the totals, after the controller / barrier 2.
